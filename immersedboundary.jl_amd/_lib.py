@@ -1,0 +1,102 @@
+"""ctypes binding of libibhip.so (the C ABI declared in include/ibhip.h).
+
+There is no CPU fallback: if the shared library is missing, or a call returns
+an error code, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_here = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_here, "libibhip.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+c_vp = C.c_void_p
+c_i64 = C.c_int64
+c_int = C.c_int
+
+
+class IbhError(RuntimeError):
+    pass
+
+
+class ibh_fluid(C.Structure):
+    _fields_ = [("R", C.c_float), ("gamma", C.c_float)]
+
+
+_SIGS = {
+    "ibh_init": [c_int],
+    "ibh_set_stream": [c_vp],
+    "ibh_sync": [],
+    "ibh_version": [],
+    "ibh_malloc": [C.POINTER(c_vp), C.c_size_t],
+    "ibh_free": [c_vp],
+    "ibh_h2d": [c_vp, c_vp, C.c_size_t],
+    "ibh_d2h": [c_vp, c_vp, C.c_size_t],
+    "ibh_memset": [c_vp, c_int, C.c_size_t],
+    "ibh_partition_create": [C.POINTER(c_vp), c_int, C.c_int32, c_vp, c_vp, c_vp,
+                             C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_vp),
+                             C.POINTER(c_vp), C.POINTER(c_vp), C.c_int32, c_vp, c_vp, c_int, c_int],
+    "ibh_partition_destroy": [c_vp],
+    "ibh_partition_info": [c_vp, C.POINTER(c_i64), c_int],
+    "ibh_at_owners": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_at_neighbors": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_at_faces": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_green_gauss": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64, c_int],
+    "ibh_cell_gradient": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_face_distance": [c_vp, c_int, c_vp],
+    "ibh_owner_distance": [c_vp, c_int, c_vp],
+    "ibh_neighbor_distance": [c_vp, c_int, c_vp],
+    "ibh_face_gradient": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_jst_sensor": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_muscl": [c_vp, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_i64],
+    "ibh_acc_create": [C.POINTER(c_vp), C.c_int32, C.c_int32, c_vp, c_vp, c_vp, c_int],
+    "ibh_acc_destroy": [c_vp],
+    "ibh_accumulate": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_bc_create": [C.POINTER(c_vp), C.c_int32, c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_int],
+    "ibh_bc_destroy": [c_vp],
+    "ibh_bc_interp": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_bc_blend": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "ibh_bc_apply": [c_vp, c_vp, c_int, c_i64, c_int, c_vp],
+    "ibh_gather_rows": [c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_scatter_rows": [c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_copy_rows": [c_vp, c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_residual_advection": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
+    "ibh_residual_euler_hll": [c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(ibh_fluid), c_int],
+    "ibh_axpy_clamped": [c_i64, C.c_float, c_vp, c_vp],
+    "ibh_axpy": [c_i64, C.c_float, c_vp, c_vp],
+    "ibh_sumsq": [c_i64, c_vp, c_vp],
+}
+
+EXPORTS = sorted(list(_SIGS) + ["ibh_last_error"])
+
+_lib = None
+
+
+def load():
+    """Load libibhip.so (no GPU needed for loading); raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IbhError(
+            f"{LIB_PATH} not found: the HIP library is not built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C immersedboundary.jl_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int
+    lib.ibh_last_error.argtypes = []
+    lib.ibh_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise IbhError(f"{name} failed (code {rc}): {lib.ibh_last_error().decode()}")
+    return rc

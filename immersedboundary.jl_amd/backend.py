@@ -1,0 +1,489 @@
+"""GPU backend: the reference's plug-in surface re-implemented over libibhip.
+
+Mirrors, for the hot path only,
+  * ``conv_to_backend`` / ``conv_from_backend`` converters and ``to_backend`` for the structs
+    (/root/reference/src/arraybends.jl:14-77, src/ImmersedBoundary.jl:788-790, :846-855);
+  * the grid operators on a Partition (src/ImmersedBoundary.jl:873-1157) -- same names,
+    argument order and return shapes (fresh arrays), ``dim`` 1-based;
+  * ``(dom::Domain)(f, args...)`` (:820-864) and ``impose_bc!`` (:1197-1247).
+
+Device memory, streams and (elsewhere) torch.distributed come from PyTorch -- plumbing only;
+all arithmetic is in the HIP kernels of libibhip.so, reached through the C ABI with raw device
+pointers.  Nothing here computes on the CPU: operators raise if handed host arrays, and loading
+fails loudly if the library is missing.
+
+Device field layout = the reference's column-major ``(ncells, nvars)``: a torch tensor of shape
+``(n, nv)`` with strides ``(1, ld)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, c_vp
+from .accumulator import Accumulator
+from .domain import Boundary, Partition
+
+IBH_FORCE_GENERAL = 1
+IBH_IMAGE_ONLY = 2
+
+_initialised = {}
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise _lib.IbhError("no HIP device visible: the ImmersedBoundary hot path runs on the GPU only "
+                            "(there is no CPU fallback)")
+    d = torch.cuda.current_device()
+    if d not in _initialised:
+        call("ibh_init", d)
+        _initialised[d] = True
+    return torch.device("cuda", d)
+
+
+def _stream():
+    call("ibh_set_stream", c_vp(torch.cuda.current_stream().cuda_stream))
+
+
+def _ptr(t):
+    return c_vp(t.data_ptr()) if t is not None else c_vp(None)
+
+
+def _hptr(a):
+    return a.ctypes.data_as(c_vp)
+
+
+# ---------------------------------------------------------------------------
+# converters (conv_to_backend / conv_from_backend)
+# ---------------------------------------------------------------------------
+def colmajor_empty(n, nv=None, dtype=torch.float32):
+    """Uninitialised device array ``(n,)`` or ``(n, nv)`` in column-major layout."""
+    dev = _dev()
+    if nv is None:
+        return torch.empty(n, dtype=dtype, device=dev)
+    return torch.empty((nv, n), dtype=dtype, device=dev).T
+
+
+def hip(a):
+    """``conv_to_backend``: host array -> device array (column-major)."""
+    dev = _dev()
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    a = np.asarray(a)
+    if a.dtype == np.float64:
+        a = a.astype(np.float32)
+    if a.ndim == 1:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if a.ndim == 2:
+        return torch.from_numpy(np.ascontiguousarray(a.T)).to(dev).T
+    raise ValueError("hip(): only 1-D and 2-D fields are supported")
+
+
+def to_host(t):
+    """``conv_from_backend``: device array -> numpy array."""
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+def _field(t, n=None):
+    """Validate a device field and return (tensor, nv, ld)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("expected a device array (convert with ibamd.hip); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError("fields must be Float32")
+    if t.ndim == 1:
+        if t.stride(0) != 1:
+            t = t.contiguous()
+        nv, ld = 1, t.shape[0]
+    elif t.ndim == 2:
+        if t.stride(0) != 1 or (t.shape[1] > 1 and t.stride(1) < t.shape[0]):
+            t = t.T.contiguous().T
+        nv, ld = t.shape[1], (t.stride(1) if t.shape[1] > 1 else t.shape[0])
+    else:
+        raise ValueError("fields are (n,) or (n, nv)")
+    if n is not None and t.shape[0] != n:
+        raise ValueError(f"field has {t.shape[0]} rows, expected {n}")
+    return t, nv, ld
+
+
+def _like(t, n):
+    return colmajor_empty(n) if t.ndim == 1 else colmajor_empty(n, t.shape[1])
+
+
+# ---------------------------------------------------------------------------
+# structs on the device
+# ---------------------------------------------------------------------------
+class DevicePartition:
+    """Device-resident Partition: ``to_backend(part, hip)`` (uploads once, caches the handle)."""
+
+    def __init__(self, part: Partition):
+        dev = _dev()
+        self.host = part
+        self.id = part.id
+        self.nd = part.ndims
+        self.nc = part.spacing.shape[0]
+        nd, nc = self.nd, self.nc
+        spacing = np.asfortranarray(part.spacing, dtype=np.float32)
+        centers = np.asfortranarray(part.centers, dtype=np.float32)
+        self.nf = [int(part.face_owners_neighbors[d + 1][0].shape[0]) for d in range(nd)]
+        nf = np.array(self.nf, dtype=np.int32)
+        keep = []
+
+        def parr(arrs):
+            arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in arrs]
+            keep.append(arrs)
+            return (c_vp * nd)(*[a.ctypes.data for a in arrs])
+
+        owners = parr([part.face_owners_neighbors[d + 1][0] for d in range(nd)])
+        neighbors = parr([part.face_owners_neighbors[d + 1][1] for d in range(nd)])
+        loff = parr([part.face_accumulators[(d + 1, False)].off for d in range(nd)])
+        lidx = parr([part.face_accumulators[(d + 1, False)].idx for d in range(nd)])
+        roff = parr([part.face_accumulators[(d + 1, True)].off for d in range(nd)])
+        ridx = parr([part.face_accumulators[(d + 1, True)].idx for d in range(nd)])
+        iid = np.ascontiguousarray(part.image_in_domain, dtype=np.int32)
+        dom = np.ascontiguousarray(part.domain, dtype=np.int32)
+        h = c_vp()
+        call("ibh_partition_create", C.byref(h), nd, nc, spacing.ctypes.data_as(c_vp), centers.ctypes.data_as(c_vp),
+             nf.ctypes.data_as(c_vp), owners, neighbors, loff, lidx, roff, ridx, int(iid.size), _hptr(iid),
+             _hptr(dom), int(getattr(part, "block_size", 0)), 0)
+        self.handle = h
+        # device copies of what user closures read (part.spacing[:, dim], part.centers)
+        self.spacing = hip(part.spacing)
+        self.centers = hip(part.centers)
+        self.domain = torch.from_numpy(dom).to(dev)
+        self.image = torch.from_numpy(np.ascontiguousarray(part.image, dtype=np.int32)).to(dev)
+        self.image_in_domain = torch.from_numpy(iid).to(dev)
+        info = (C.c_int64 * 8)()
+        call("ibh_partition_info", h, info, 8)
+        self.info = dict(full_blocks=info[0], irregular_cells=info[1], sides_same=info[2], sides_mirror=info[3],
+                         sides_coarse=info[4], sides_fine=info[5], sides_general=info[6])
+
+    @property
+    def ndims(self):
+        return self.nd
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().ibh_partition_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class DeviceAccumulator:
+    """Device-resident Accumulator; callable like the reference's (accumulator.jl:78-130)."""
+
+    def __init__(self, acc: Accumulator):
+        _dev()
+        self.n_output, self.n_input = acc.n_output, acc.n_input
+        self.first_index = acc.first_index
+        h = c_vp()
+        w = None if acc.w is None else np.ascontiguousarray(acc.w, dtype=np.float32)
+        call("ibh_acc_create", C.byref(h), acc.n_output, acc.n_input, _hptr(acc.off), _hptr(acc.idx),
+             _hptr(w) if w is not None else c_vp(None), 0)
+        self.handle = h
+
+    def __call__(self, v):
+        v, nv, ld = _field(v, self.n_input)
+        out = _like(v, self.n_output)
+        _stream()
+        call("ibh_accumulate", self.handle, _ptr(v), nv, ld, _ptr(out), self.n_output)
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().ibh_acc_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class DeviceBoundary:
+    """Device-resident Boundary (ImmersedBoundary.jl:406-414)."""
+
+    def __init__(self, b: Boundary):
+        self.host = b
+        self.ng = int(b.ghost_indices.shape[0])
+        acc = b.image_interpolator
+        h = c_vp()
+        gi = np.ascontiguousarray(b.ghost_indices, dtype=np.int32)
+        idm = np.ascontiguousarray(b.image_domain, dtype=np.int32)
+        gd = np.ascontiguousarray(b.ghost_distances, dtype=np.float32)
+        idist = np.ascontiguousarray(b.image_distances, dtype=np.float32)
+        _dev()
+        call("ibh_bc_create", C.byref(h), self.ng, _hptr(gi), _hptr(gd), _hptr(idist), int(idm.size), _hptr(idm),
+             _hptr(acc.off), _hptr(acc.idx), _hptr(np.ascontiguousarray(acc.w, dtype=np.float32)), 0)
+        self.handle = h
+        self.ghost_indices = torch.from_numpy(gi).to(_dev())
+        self.projections = hip(b.projections)
+        self.normals = hip(b.normals)
+        self.image_distances = hip(b.image_distances)
+        self.ghost_distances = hip(b.ghost_distances)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().ibh_bc_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def to_backend(x, converter=hip):
+    """``ArrayBackends.to_backend`` (arraybends.jl:14-77) for the structs on the hot path."""
+    if isinstance(x, (DevicePartition, DeviceAccumulator, DeviceBoundary)):
+        return x
+    if isinstance(x, Partition):
+        if getattr(x, "_device", None) is None:
+            x._device = DevicePartition(x)
+        return x._device
+    if isinstance(x, Accumulator):
+        if getattr(x, "_device", None) is None:
+            x._device = DeviceAccumulator(x)
+        return x._device
+    if isinstance(x, Boundary):
+        if getattr(x, "_device", None) is None:
+            x._device = DeviceBoundary(x)
+        return x._device
+    if isinstance(x, tuple):
+        return tuple(to_backend(v, converter) for v in x)
+    if isinstance(x, dict):
+        return {k: to_backend(v, converter) for k, v in x.items()}
+    if isinstance(x, (np.ndarray, torch.Tensor)):
+        return converter(x)
+    return x
+
+
+def _part(p):
+    if not isinstance(p, DevicePartition):
+        raise TypeError("operators run on a device Partition (to_backend(part, hip)); there is no CPU path")
+    return p
+
+
+# ---------------------------------------------------------------------------
+# grid operators (ImmersedBoundary.jl:873-1157)
+# ---------------------------------------------------------------------------
+def _cell_to_face(name, part, u, dim):
+    part = _part(part)
+    u, nv, ld = _field(u, part.nc)
+    out = _like(u, part.nf[dim - 1])
+    _stream()
+    call(name, part.handle, dim, _ptr(u), nv, ld, _ptr(out), part.nf[dim - 1])
+    return out
+
+
+def at_owners(part, u, dim):
+    """:879"""
+    return _cell_to_face("ibh_at_owners", part, u, dim)
+
+
+def at_neighbors(part, u, dim):
+    """:889"""
+    return _cell_to_face("ibh_at_neighbors", part, u, dim)
+
+
+def at_faces(part, u, dim):
+    """:899"""
+    return _cell_to_face("ibh_at_faces", part, u, dim)
+
+
+def face_gradient(part, u, a, b=None):
+    """:1039 ``face_gradient(part,u,dim)`` / :1051 ``face_gradient(part,u,grad_u,dim)``."""
+    if b is None:
+        return _cell_to_face("ibh_face_gradient", part, u, a)
+    gu, dim = a, b
+    return tuple(face_gradient(part, u, dim) if i == dim else at_faces(part, gu[i - 1], dim)
+                 for i in range(1, _part(part).nd + 1))
+
+
+def _gg(part, uf, dim, uns):
+    part = _part(part)
+    uf, nv, ld = _field(uf, part.nf[dim - 1])
+    out = _like(uf, part.nc)
+    _stream()
+    call("ibh_green_gauss", part.handle, dim, _ptr(uf), nv, ld, _ptr(out), part.nc, uns)
+    return out
+
+
+def green_gauss(part, uf, dim):
+    """:918"""
+    return _gg(part, uf, dim, 0)
+
+
+def unsigned_green_gauss(part, uf, dim):
+    """:934"""
+    return _gg(part, uf, dim, 1)
+
+
+def divergent(part, uf):
+    """:950"""
+    s = green_gauss(part, uf[0], 1)
+    for d in range(2, _part(part).nd + 1):
+        s = s + green_gauss(part, uf[d - 1], d)
+    return s
+
+
+def cell_gradient(part, u, dim=None):
+    """:965 / :980"""
+    part = _part(part)
+    if dim is None:
+        return tuple(cell_gradient(part, u, d) for d in range(1, part.nd + 1))
+    u, nv, ld = _field(u, part.nc)
+    out = _like(u, part.nc)
+    _stream()
+    call("ibh_cell_gradient", part.handle, dim, _ptr(u), nv, ld, _ptr(out), part.nc)
+    return out
+
+
+def _dist(name, part, dim):
+    part = _part(part)
+    out = colmajor_empty(part.nf[dim - 1])
+    _stream()
+    call(name, part.handle, dim, _ptr(out))
+    return out
+
+
+def face_distance(part, dim):
+    """:995"""
+    return _dist("ibh_face_distance", part, dim)
+
+
+def owner_distance(part, dim):
+    """:1010"""
+    return _dist("ibh_owner_distance", part, dim)
+
+
+def neighbor_distance(part, dim):
+    """:1024"""
+    return _dist("ibh_neighbor_distance", part, dim)
+
+
+def JST_sensor(part, p, dim=0):
+    """:1077"""
+    part = _part(part)
+    p, nv, ld = _field(p, part.nc)
+    out = _like(p, part.nc)
+    _stream()
+    call("ibh_jst_sensor", part.handle, dim, _ptr(p), nv, ld, _ptr(out), part.nc)
+    return out
+
+
+def MUSCL(part, u, du, dim, D=None, high_order=False):
+    """:1113"""
+    part = _part(part)
+    u, nv, ld = _field(u, part.nc)
+    du, nv2, ld2 = _field(du, part.nc)
+    if nv2 != nv:
+        raise ValueError("u and du must have the same shape")
+    if ld2 != ld and u.ndim == 2:
+        du = du.T.contiguous().T
+        u = u.T.contiguous().T
+        ld = part.nc
+    if D is not None:
+        D, nvd, _ = _field(D, part.nc)
+        if nvd != 1:
+            raise ValueError("D must be a vector")
+    nf = part.nf[dim - 1]
+    uL, uR = _like(u, nf), _like(u, nf)
+    _stream()
+    call("ibh_muscl", part.handle, dim, _ptr(u), _ptr(du), nv, ld, _ptr(D), int(bool(high_order)), _ptr(uL),
+         _ptr(uR), nf)
+    return uL, uR
+
+
+# ---------------------------------------------------------------------------
+# fused residual sweeps
+# ---------------------------------------------------------------------------
+def residual_advection(part, u, C_, out=None, flags=0):
+    """Fused closure of test/advection.jl:67-83 (``ud`` from zero): returns ``ud``."""
+    part = _part(part)
+    u, nv, _ = _field(u, part.nc)
+    if nv != 1:
+        raise ValueError("u must be a scalar field")
+    C_, nvc, ldc = _field(C_, part.nc)
+    if nvc != part.nd:
+        raise ValueError("C must be (nc, nd)")
+    ud = out if out is not None else torch.zeros(part.nc, dtype=torch.float32, device=u.device)
+    _stream()
+    call("ibh_residual_advection", part.handle, _ptr(u), _ptr(C_), ldc, _ptr(ud), flags)
+    return ud
+
+
+def residual_euler_hll(part, P, fluid_R=283.0, fluid_gamma=1.4, out=None, flags=0):
+    """Fused Euler residual R2: JST(p) + cell_gradient + MUSCL(high_order) + HLL + green_gauss."""
+    part = _part(part)
+    P, nv, ldp = _field(P, part.nc)
+    if nv != part.nd + 2:
+        raise ValueError("P must be (nc, nd+2) = [p T u v (w)]")
+    R = out if out is not None else torch.zeros((nv, part.nc), dtype=torch.float32, device=P.device).T
+    R, _, ldr = _field(R, part.nc)
+    fl = _lib.ibh_fluid(float(fluid_R), float(fluid_gamma))
+    _stream()
+    call("ibh_residual_euler_hll", part.handle, _ptr(P), ldp, _ptr(R), ldr, C.byref(fl), flags)
+    return R
+
+
+# ---------------------------------------------------------------------------
+# partition runtime and ghost-cell BC
+# ---------------------------------------------------------------------------
+def domain_call(dom, f, args, conv_to_backend, conv_from_backend, kwargs):
+    """``(dom::Domain)(f, args...)`` (ImmersedBoundary.jl:820-864) with the GPU backend."""
+    if (conv_to_backend is None) != (conv_from_backend is None):
+        raise AssertionError("Backend converters must be provided at the same time")
+    if conv_to_backend is None:
+        raise TypeError("Domain call needs conv_to_backend=ibamd.hip, conv_from_backend=ibamd.to_host: "
+                        "the per-partition compute runs on the GPU only (no CPU path)")
+    results = []
+    for i in dom.partitions:
+        part = dom.partitions[i]
+        dargs = [np.array(a[part.domain]) for a in args]
+        dargs = [conv_to_backend(a) for a in dargs]
+        dpart = to_backend(part, conv_to_backend)
+        r = f(dpart, *dargs, **kwargs)
+        dargs = [conv_from_backend(a) for a in dargs]
+        for a, da in zip(args, dargs):
+            a[part.image] = da[part.image_in_domain]
+        results.append(r)
+    return results
+
+
+def impose_bc(f, dom, bname, *args, conv_to_backend=None, conv_from_backend=None, **kwargs):
+    """``impose_bc!(f, dom, bname, args...)`` (ImmersedBoundary.jl:1197-1247).
+
+    ``args`` are global arrays.  Device arrays are updated in place on the GPU; host arrays need
+    both converters (the reference's calling convention) and are copied back.
+    """
+    if (conv_to_backend is None) != (conv_from_backend is None):
+        raise AssertionError("Backend converters must be provided at the same time")
+    host_args = None
+    if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
+        if conv_to_backend is None:
+            raise TypeError("impose_bc needs device arrays or conv_to_backend/conv_from_backend (no CPU path)")
+        host_args = args
+        args = tuple(conv_to_backend(a) for a in args)
+    fields = [_field(a) for a in args]
+    for ipart in dom.boundaries[bname]:
+        bdry = to_backend(dom.boundaries[bname][ipart])
+        iargs = []
+        _stream()
+        for (a, nv, ld) in fields:
+            ia = _like(a, bdry.ng)
+            call("ibh_bc_interp", bdry.handle, _ptr(a), nv, ld, _ptr(ia), bdry.ng)
+            iargs.append(ia)
+        r = f(bdry, *iargs, **kwargs)
+        if not isinstance(r, tuple):
+            r = (r,)
+        for (a, nv, ld), ba, ia in zip(fields, r, iargs):
+            if isinstance(ba, torch.Tensor):
+                ba, nvb, ldb = _field(ba.expand_as(ia) if ba.shape != ia.shape else ba, bdry.ng)
+                call("ibh_bc_blend", bdry.handle, _ptr(a), nv, ld, _ptr(ia), bdry.ng, _ptr(ba), ldb, c_vp(None))
+            else:
+                const = np.full(nv, ba, dtype=np.float32) if np.isscalar(ba) else np.asarray(ba, dtype=np.float32)
+                call("ibh_bc_blend", bdry.handle, _ptr(a), nv, ld, _ptr(ia), bdry.ng, c_vp(None), 0, _hptr(const))
+    if host_args is not None:
+        for h, (a, _, _) in zip(host_args, fields):
+            h[...] = conv_from_backend(a)

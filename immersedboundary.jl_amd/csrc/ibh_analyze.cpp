@@ -1,0 +1,172 @@
+// libibhip: host-side analysis that recovers the block structure of a Partition from the
+// reference's own data (part.domain global ids + face lists) and classifies every block side
+// for the block fast path.  Nothing is assumed: a side gets a fast class only if the faces the
+// reference actually registered for its 8 boundary cells are exactly the faces that class
+// implies (this also covers the reference's search-radius rule that can drop faces at >2:1
+// jumps, ImmersedBoundary.jl:85,114-116).  Everything else falls back to the face-list kernels.
+//
+// Cell numbering inside a block is x-fastest (mesher.jl:1064-1112): local = i + 8*j.
+#include <unordered_map>
+
+#include "ibh_common.h"
+
+namespace {
+
+inline int pos_own(int s, int t) { return s == 0 ? 8 * t : s == 1 ? 7 + 8 * t : s == 2 ? t : t + 56; }
+inline int pos_opp(int s, int tt) { return s == 0 ? 7 + 8 * tt : s == 1 ? 8 * tt : s == 2 ? tt + 56 : tt; }
+inline int tang_of_pos(int s, int pos) { return s < 2 ? pos / 8 : pos % 8; }
+inline bool on_opp_edge(int s, int pos) {
+    return s == 0 ? (pos % 8 == 7) : s == 1 ? (pos % 8 == 0) : s == 2 ? (pos / 8 == 7) : (pos / 8 == 0);
+}
+
+}  // namespace
+
+void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks, std::vector<int32_t>& irr,
+                         int64_t* info) {
+    const int32_t nc = v.nc;
+    const int NPB = 64;
+    const float* hx = v.spacing;
+    const float* hy = v.spacing + nc;
+    auto gid = [&](int32_t c) { return (int64_t)v.domain[c] - v.index_base; };
+
+    // 1. full blocks: 64 consecutive local cells = one whole global block, uniform spacing
+    std::unordered_map<int64_t, int32_t> blockbase;
+    std::vector<int32_t> bases;
+    std::vector<char> in_full(nc, 0);
+    for (int32_t c = 0; c + NPB <= nc;) {
+        int64_t g = gid(c);
+        bool ok = (g % NPB == 0) && gid(c + NPB - 1) == g + NPB - 1;
+        if (ok)
+            for (int k = 1; k < NPB && ok; ++k)
+                ok = gid(c + k) == g + k && hx[c + k] == hx[c] && hy[c + k] == hy[c];
+        if (ok) {
+            blockbase[g / NPB] = c;
+            bases.push_back(c);
+            for (int k = 0; k < NPB; ++k) in_full[c + k] = 1;
+            c += NPB;
+        } else {
+            ++c;
+        }
+    }
+
+    auto single = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& idx, int32_t c) -> int32_t {
+        return (off[c + 1] - off[c] == 1) ? idx[off[c]] : -1;
+    };
+
+    std::vector<char> cell_irr(nc, 0);
+    for (int32_t c = 0; c < nc; ++c) cell_irr[c] = !in_full[c];
+    int64_t counts[5] = {0, 0, 0, 0, 0};
+
+    for (int32_t base : bases) {
+        // 2. interior faces must be the implicit ones
+        bool good = true;
+        for (int pos = 0; pos < NPB && good; ++pos) {
+            int i = pos % 8, j = pos / 8;
+            int32_t c = base + pos;
+            for (int d = 0; d < 2 && good; ++d) {
+                int step = d == 0 ? 1 : 8;
+                int ij = d == 0 ? i : j;
+                if (ij < 7) {
+                    int32_t f = single(v.roff[d], v.ridx[d], c);
+                    good = f >= 0 && v.owners[d][f] == c && v.neighbors[d][f] == c + step;
+                }
+                if (good && ij > 0) {
+                    int32_t f = single(v.loff[d], v.lidx[d], c);
+                    good = f >= 0 && v.owners[d][f] == c - step && v.neighbors[d][f] == c;
+                }
+            }
+        }
+        if (!good) {
+            for (int k = 0; k < NPB; ++k) cell_irr[base + k] = 1;
+            continue;
+        }
+        BlockDesc2 b;
+        b.base = base;
+        b.h[0] = hx[base];
+        b.h[1] = hy[base];
+        // 3. sides
+        for (int s = 0; s < 4; ++s) {
+            const int d = s / 2;
+            const bool low = (s % 2) == 0;
+            const float* h = d == 0 ? hx : hy;
+            const float hc = h[base];
+            const std::vector<int32_t>& off = low ? v.loff[d] : v.roff[d];
+            const std::vector<int32_t>& idx = low ? v.lidx[d] : v.ridx[d];
+            int type = -1;
+            int32_t nb[2] = {-1, -1};
+            int sub = -1;
+            bool ok = true;
+            for (int t = 0; t < 8 && ok; ++t) {
+                int32_t c = base + pos_own(s, t);
+                int nfc = off[c + 1] - off[c];
+                int32_t other[2] = {-1, -1};
+                if (nfc < 1 || nfc > 2) { ok = false; break; }
+                for (int k = 0; k < nfc; ++k) {
+                    int32_t f = idx[off[c] + k];
+                    int32_t me = low ? v.neighbors[d][f] : v.owners[d][f];
+                    if (me != c) ok = false;
+                    other[k] = low ? v.owners[d][f] : v.neighbors[d][f];
+                }
+                if (!ok) break;
+                int ty;
+                if (nfc == 1 && other[0] == c) {
+                    ty = SIDE_MIRROR;
+                } else if (nfc == 1) {
+                    int32_t o = other[0];
+                    if (!in_full[o]) { ok = false; break; }
+                    int64_t g = gid(o);
+                    int32_t ob = blockbase[g / NPB];
+                    int pos = (int)(g % NPB);
+                    if (!on_opp_edge(s, pos)) { ok = false; break; }
+                    int tt = tang_of_pos(s, pos);
+                    if (h[o] == hc) {
+                        ty = SIDE_SAME;
+                        if (tt != t) { ok = false; break; }
+                        if (t == 0) nb[0] = ob; else if (nb[0] != ob) { ok = false; break; }
+                    } else if (h[o] == hc * 2.0f) {
+                        ty = SIDE_COARSE;
+                        int q = (tt - t / 2);
+                        if (q != 0 && q != 4) { ok = false; break; }
+                        q /= 4;
+                        if (t == 0) { nb[0] = ob; sub = q; } else if (nb[0] != ob || sub != q) { ok = false; break; }
+                    } else { ok = false; break; }
+                } else {
+                    ty = SIDE_FINE;
+                    int32_t obk = -1;
+                    bool seen[2] = {false, false};
+                    for (int k = 0; k < 2; ++k) {
+                        int32_t o = other[k];
+                        if (o == c || !in_full[o] || h[o] != hc * 0.5f) { ok = false; break; }
+                        int64_t g = gid(o);
+                        int32_t ob = blockbase[g / NPB];
+                        int pos = (int)(g % NPB);
+                        if (!on_opp_edge(s, pos)) { ok = false; break; }
+                        int tt = tang_of_pos(s, pos) - 2 * (t & 3);
+                        if (tt != 0 && tt != 1) { ok = false; break; }
+                        if (seen[tt]) { ok = false; break; }
+                        seen[tt] = true;
+                        if (obk < 0) obk = ob; else if (obk != ob) { ok = false; break; }
+                    }
+                    if (!ok) break;
+                    int kb = t >> 2;
+                    if ((t & 3) == 0) nb[kb] = obk; else if (nb[kb] != obk) { ok = false; break; }
+                }
+                if (t == 0) type = ty; else if (type != ty) { ok = false; break; }
+            }
+            if (!ok) type = SIDE_GENERAL;
+            b.type[s] = type;
+            b.nb[s][0] = nb[0];
+            b.nb[s][1] = nb[1];
+            b.sub[s] = sub < 0 ? 0 : sub;
+            counts[type]++;
+            if (type == SIDE_GENERAL)
+                for (int t = 0; t < 8; ++t) cell_irr[base + pos_own(s, t)] = 1;
+        }
+        blocks.push_back(b);
+    }
+    for (int32_t c = 0; c < nc; ++c)
+        if (cell_irr[c]) irr.push_back(c);
+    info[0] = (int64_t)blocks.size();
+    info[1] = (int64_t)irr.size();
+    for (int k = 0; k < 5; ++k) info[2 + k] = counts[k];
+}

@@ -1,0 +1,249 @@
+// libibhip: runtime, memory and handle management (host side of the C ABI).
+#include <string.h>
+
+#include "ibh_common.h"
+
+thread_local std::string ibh_err;
+thread_local hipStream_t ibh_stream = nullptr;
+
+int ibh_fail(int code, const char* what, const char* file, int line) {
+    ibh_err = std::string(what) + " (" + file + ":" + std::to_string(line) + ")";
+    return code ? code : -1;
+}
+
+template <class T>
+int ibh_upload(T** dptr, const T* host, size_t n) {
+    *dptr = nullptr;
+    if (n == 0) return 0;
+    IBH_HIP(hipMalloc((void**)dptr, n * sizeof(T)));
+    IBH_HIP(hipMemcpy(*dptr, host, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+template int ibh_upload<int32_t>(int32_t**, const int32_t*, size_t);
+template int ibh_upload<float>(float**, const float*, size_t);
+template int ibh_upload<BlockDesc2>(BlockDesc2**, const BlockDesc2*, size_t);
+
+extern "C" {
+
+int ibh_version(void) { return 100; }
+
+const char* ibh_last_error(void) { return ibh_err.c_str(); }
+
+int ibh_init(int device) {
+    IBH_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    IBH_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return ibh_fail(-2, (std::string("libibhip is built for gfx950 only, device is ") + prop.gcnArchName).c_str(),
+                        __FILE__, __LINE__);
+    return 0;
+}
+
+int ibh_set_stream(void* s) {
+    ibh_stream = (hipStream_t)s;
+    return 0;
+}
+
+int ibh_sync(void) {
+    IBH_HIP(hipStreamSynchronize(ibh_stream));
+    return 0;
+}
+
+int ibh_malloc(void** p, size_t bytes) {
+    IBH_HIP(hipMalloc(p, bytes ? bytes : 4));
+    return 0;
+}
+int ibh_free(void* p) {
+    if (p) IBH_HIP(hipFree(p));
+    return 0;
+}
+int ibh_h2d(void* dst, const void* src, size_t bytes) {
+    IBH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ibh_stream));
+    IBH_HIP(hipStreamSynchronize(ibh_stream));
+    return 0;
+}
+int ibh_d2h(void* dst, const void* src, size_t bytes) {
+    IBH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ibh_stream));
+    IBH_HIP(hipStreamSynchronize(ibh_stream));
+    return 0;
+}
+int ibh_memset(void* dst, int value, size_t bytes) {
+    IBH_HIP(hipMemsetAsync(dst, value, bytes, ibh_stream));
+    return 0;
+}
+
+static std::vector<int32_t> rebased(const int32_t* p, size_t n, int base) {
+    std::vector<int32_t> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = p[i] - base;
+    return v;
+}
+
+int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacing, const float* centers,
+                         const int32_t* nf, const int32_t* const* owners, const int32_t* const* neighbors,
+                         const int32_t* const* left_off, const int32_t* const* left_idx,
+                         const int32_t* const* right_off, const int32_t* const* right_idx, int32_t n_image,
+                         const int32_t* image_in_domain, const int32_t* domain, int block_size, int index_base) {
+    IBH_REQUIRE(out && spacing && nf && owners && neighbors && left_off && left_idx && right_off && right_idx,
+                "ibh_partition_create: null argument");
+    IBH_REQUIRE(nd == 2 || nd == 3, "ibh_partition_create: nd must be 2 or 3");
+    IBH_REQUIRE(nc >= 0 && (index_base == 0 || index_base == 1), "ibh_partition_create: bad nc/index_base");
+    HostPartView v;
+    v.nd = nd;
+    v.nc = nc;
+    v.spacing = spacing;
+    v.nf = nf;
+    v.domain = domain;
+    v.index_base = index_base;
+    v.bs = block_size;
+    v.owners.resize(nd); v.neighbors.resize(nd);
+    v.loff.resize(nd); v.lidx.resize(nd); v.roff.resize(nd); v.ridx.resize(nd);
+    for (int d = 0; d < nd; ++d) {
+        IBH_REQUIRE(nf[d] >= 0, "ibh_partition_create: negative face count");
+        v.owners[d] = rebased(owners[d], nf[d], index_base);
+        v.neighbors[d] = rebased(neighbors[d], nf[d], index_base);
+        // offsets: accept either base (first entry tells)
+        int32_t ob = left_off[d][0];
+        v.loff[d] = rebased(left_off[d], (size_t)nc + 1, ob);
+        v.lidx[d] = rebased(left_idx[d], v.loff[d][nc], index_base);
+        ob = right_off[d][0];
+        v.roff[d] = rebased(right_off[d], (size_t)nc + 1, ob);
+        v.ridx[d] = rebased(right_idx[d], v.roff[d][nc], index_base);
+        for (int32_t f = 0; f < nf[d]; ++f)
+            IBH_REQUIRE(v.owners[d][f] >= 0 && v.owners[d][f] < nc && v.neighbors[d][f] >= 0 && v.neighbors[d][f] < nc,
+                        "ibh_partition_create: owner/neighbour index out of range");
+        for (int32_t c = 0; c < nc; ++c)
+            IBH_REQUIRE(v.loff[d][c + 1] >= v.loff[d][c] && v.roff[d][c + 1] >= v.roff[d][c],
+                        "ibh_partition_create: CSR offsets not monotone");
+        for (int32_t x : v.lidx[d]) IBH_REQUIRE(x >= 0 && x < nf[d], "ibh_partition_create: left face id out of range");
+        for (int32_t x : v.ridx[d]) IBH_REQUIRE(x >= 0 && x < nf[d], "ibh_partition_create: right face id out of range");
+    }
+    ibh_part* p = new ibh_part();
+    p->nd = nd;
+    p->nc = nc;
+    int rc = 0;
+    if ((rc = ibh_upload(&p->spacing, spacing, (size_t)nc * nd))) return rc;
+    if (centers && (rc = ibh_upload(&p->centers, centers, (size_t)nc * nd))) return rc;
+    for (int d = 0; d < nd; ++d) {
+        DimData& D = p->dim[d];
+        D.nf = nf[d];
+        if ((rc = ibh_upload(&D.owners, v.owners[d].data(), v.owners[d].size()))) return rc;
+        if ((rc = ibh_upload(&D.neighbors, v.neighbors[d].data(), v.neighbors[d].size()))) return rc;
+        if ((rc = ibh_upload(&D.loff, v.loff[d].data(), v.loff[d].size()))) return rc;
+        if ((rc = ibh_upload(&D.lidx, v.lidx[d].data(), v.lidx[d].size()))) return rc;
+        if ((rc = ibh_upload(&D.roff, v.roff[d].data(), v.roff[d].size()))) return rc;
+        if ((rc = ibh_upload(&D.ridx, v.ridx[d].data(), v.ridx[d].size()))) return rc;
+    }
+    p->n_image = n_image;
+    if (n_image > 0 && image_in_domain) {
+        std::vector<int32_t> iid = rebased(image_in_domain, n_image, index_base);
+        for (int32_t x : iid) IBH_REQUIRE(x >= 0 && x < nc, "ibh_partition_create: image_in_domain out of range");
+        if ((rc = ibh_upload(&p->image_in_domain, iid.data(), iid.size()))) return rc;
+    }
+    p->bs = 0;
+    if (domain && block_size > 0 && nd == 2 && block_size == 8) {
+        std::vector<BlockDesc2> blocks;
+        std::vector<int32_t> irr;
+        ibh_analyze_blocks2(v, blocks, irr, p->info);
+        p->bs = block_size;
+        p->nblk = (int32_t)blocks.size();
+        p->n_irr = (int32_t)irr.size();
+        if ((rc = ibh_upload(&p->blocks2, blocks.data(), blocks.size()))) return rc;
+        if ((rc = ibh_upload(&p->irr_cells, irr.data(), irr.size()))) return rc;
+    } else {
+        p->info[0] = 0;
+        p->info[1] = nc;
+    }
+    *out = p;
+    return 0;
+}
+
+int ibh_partition_destroy(ibh_part* p) {
+    if (!p) return 0;
+    hipFree(p->spacing);
+    hipFree(p->centers);
+    for (int d = 0; d < p->nd; ++d) {
+        DimData& D = p->dim[d];
+        hipFree(D.owners); hipFree(D.neighbors);
+        hipFree(D.loff); hipFree(D.lidx); hipFree(D.roff); hipFree(D.ridx);
+    }
+    hipFree(p->image_in_domain);
+    hipFree(p->blocks2);
+    hipFree(p->irr_cells);
+    hipFree(p->G);
+    delete p;
+    return 0;
+}
+
+int ibh_partition_info(const ibh_part* p, int64_t* info, int n) {
+    IBH_REQUIRE(p && info, "ibh_partition_info: null argument");
+    for (int i = 0; i < n && i < 8; ++i) info[i] = p->info[i];
+    return 0;
+}
+
+static int acc_fill(ibh_acc* a, int32_t n_output, int32_t n_input, const int32_t* off, const int32_t* idx,
+                    const float* w, int index_base) {
+    IBH_REQUIRE(off && (n_output >= 0), "ibh_acc_create: null offsets");
+    int32_t ob = off[0];
+    std::vector<int32_t> o = rebased(off, (size_t)n_output + 1, ob);
+    for (int32_t r = 0; r < n_output; ++r) IBH_REQUIRE(o[r + 1] >= o[r], "ibh_acc_create: offsets not monotone");
+    size_t nnz = o[n_output];
+    IBH_REQUIRE(nnz == 0 || idx, "ibh_acc_create: null indices");
+    std::vector<int32_t> ix = rebased(idx, nnz, index_base);
+    for (int32_t x : ix) IBH_REQUIRE(x >= 0 && x < n_input, "ibh_acc_create: donor index out of range");
+    a->n_out = n_output;
+    a->n_in = n_input;
+    int rc;
+    if ((rc = ibh_upload(&a->off, o.data(), o.size()))) return rc;
+    if ((rc = ibh_upload(&a->idx, ix.data(), ix.size()))) return rc;
+    a->w = nullptr;
+    if (w && (rc = ibh_upload(&a->w, w, nnz))) return rc;
+    return 0;
+}
+
+int ibh_acc_create(ibh_acc** out, int32_t n_output, int32_t n_input, const int32_t* off, const int32_t* idx,
+                   const float* w, int index_base) {
+    IBH_REQUIRE(out, "ibh_acc_create: null out");
+    ibh_acc* a = new ibh_acc();
+    int rc = acc_fill(a, n_output, n_input, off, idx, w, index_base);
+    if (rc) { delete a; return rc; }
+    *out = a;
+    return 0;
+}
+
+int ibh_acc_destroy(ibh_acc* a) {
+    if (!a) return 0;
+    hipFree(a->off); hipFree(a->idx); hipFree(a->w);
+    delete a;
+    return 0;
+}
+
+int ibh_bc_create(ibh_bc** out, int32_t ng, const int32_t* ghost_indices, const float* ghost_distances,
+                  const float* image_distances, int32_t nid, const int32_t* image_domain,
+                  const int32_t* interp_off, const int32_t* interp_idx, const float* interp_w, int index_base) {
+    IBH_REQUIRE(out && ghost_indices && ghost_distances && image_distances && image_domain,
+                "ibh_bc_create: null argument");
+    ibh_bc* b = new ibh_bc();
+    b->ng = ng;
+    b->nid = nid;
+    std::vector<int32_t> g = rebased(ghost_indices, ng, index_base);
+    std::vector<int32_t> idm = rebased(image_domain, nid, index_base);
+    std::vector<float> eta(ng);
+    for (int32_t i = 0; i < ng; ++i) eta[i] = ghost_distances[i] / image_distances[i];  // :1220
+    int rc;
+    if ((rc = ibh_upload(&b->ghost, g.data(), g.size()))) return rc;
+    if ((rc = ibh_upload(&b->image_domain, idm.data(), idm.size()))) return rc;
+    if ((rc = ibh_upload(&b->eta, eta.data(), eta.size()))) return rc;
+    if ((rc = acc_fill(&b->interp, ng, nid, interp_off, interp_idx, interp_w, index_base))) return rc;
+    *out = b;
+    return 0;
+}
+
+int ibh_bc_destroy(ibh_bc* b) {
+    if (!b) return 0;
+    hipFree(b->ghost); hipFree(b->image_domain); hipFree(b->eta);
+    hipFree(b->interp.off); hipFree(b->interp.idx); hipFree(b->interp.w);
+    delete b;
+    return 0;
+}
+
+}  // extern "C"

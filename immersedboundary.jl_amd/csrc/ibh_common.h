@@ -1,0 +1,108 @@
+// Internal declarations shared by the libibhip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ibhip.h"
+
+#define IBH_MAXD 3
+
+// Block-side classes of the block-structured fast path (see ibh_analyze.cpp).
+enum : int32_t { SIDE_SAME = 0, SIDE_MIRROR = 1, SIDE_COARSE = 2, SIDE_FINE = 3, SIDE_GENERAL = 4 };
+
+// One full block (all bs^nd cells present, consecutive local ids starting at `base`).
+// side s = 2*d + (0: low / left, 1: high / right).
+// nb[s][k]: local id of the first cell (`base`) of the k-th neighbour block across side s
+//   SAME:   nb[s][0]
+//   COARSE: nb[s][0], and sub[s] = which half (2-D) / quadrant (3-D) of the coarse side we abut
+//   FINE:   nb[s][0..2^(nd-1)-1], ordered x-fastest over the tangential directions
+struct BlockDesc2 {  // 2-D
+    int32_t base;
+    int32_t type[4];
+    int32_t nb[4][2];
+    int32_t sub[4];
+    float h[2];
+};
+
+struct DimData {
+    int32_t nf = 0;
+    int32_t *owners = nullptr, *neighbors = nullptr;  // [nf] 0-based
+    int32_t *loff = nullptr, *lidx = nullptr;         // CSR of left faces  (cell is the neighbour)
+    int32_t *roff = nullptr, *ridx = nullptr;         // CSR of right faces (cell is the owner)
+};
+
+struct ibh_part {
+    int nd = 0;
+    int32_t nc = 0;
+    float* spacing = nullptr;  // (nc, nd) column-major
+    float* centers = nullptr;  // (nc, nd) or null
+    DimData dim[IBH_MAXD];
+    int32_t n_image = 0;
+    int32_t* image_in_domain = nullptr;
+    // block-structured fast path
+    int bs = 0;
+    int32_t nblk = 0;            // full blocks handled by the fast kernels
+    BlockDesc2* blocks2 = nullptr;
+    int32_t n_irr = 0;           // cells handled by the general kernels when the fast path is on
+    int32_t* irr_cells = nullptr;
+    int64_t info[8] = {0};
+    // workspace for per-cell gradients + sensor (pass A output)
+    float* G = nullptr;
+    size_t G_bytes = 0;
+};
+
+struct ibh_acc {
+    int32_t n_out = 0, n_in = 0;
+    int32_t *off = nullptr, *idx = nullptr;
+    float* w = nullptr;
+};
+
+struct ibh_bc {
+    int32_t ng = 0, nid = 0;
+    int32_t *ghost = nullptr, *image_domain = nullptr;
+    float* eta = nullptr;
+    ibh_acc interp;
+};
+
+// thread-local state
+extern thread_local std::string ibh_err;
+extern thread_local hipStream_t ibh_stream;
+
+int ibh_fail(int code, const char* what, const char* file, int line);
+
+#define IBH_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return ibh_fail((int)e__, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define IBH_REQUIRE(cond, msg)                                               \
+    do {                                                                     \
+        if (!(cond)) return ibh_fail(-1, msg, __FILE__, __LINE__);           \
+    } while (0)
+#define IBH_LAUNCH_CHECK() IBH_HIP(hipGetLastError())
+
+template <class T>
+int ibh_upload(T** dptr, const T* host, size_t n);
+
+// host-side block analysis (ibh_analyze.cpp)
+struct HostPartView {
+    int nd;
+    int32_t nc;
+    const float* spacing;
+    const int32_t* nf;
+    std::vector<std::vector<int32_t>> owners, neighbors, loff, lidx, roff, ridx;  // 0-based copies
+    const int32_t* domain;  // global ids, base `index_base`
+    int index_base;
+    int bs;
+};
+void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
+                         std::vector<int32_t>& irr_cells, int64_t* info);
+
+static inline int ibh_grid(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 65535 * 16) g = 65535 * 16;
+    return (int)g;
+}

@@ -1,0 +1,553 @@
+// libibhip: fused residual sweeps (the headline hot path).
+//
+// One sweep = two kernels:
+//   pass A  per cell : Green-Gauss gradients of every variable along every dim + JST sensor
+//                      (cell_gradient :965, JST_sensor :1077)          -> workspace G
+//   pass B  per cell : for each face of the cell MUSCL(high_order) states, flux, and the
+//                      Green-Gauss sum of the fluxes (MUSCL :1113, green_gauss :918)
+// Each pass has two bodies launched together in ONE grid:
+//   * block fast path (2-D, 8x8 blocks): one 64-lane wavefront per block, lane = cell,
+//     x-fastest like the reference's cell numbering (mesher.jl:1064-1112).  Cell values are
+//     staged in LDS; the halo across the four block sides (same level, mirror, 2:1 coarse,
+//     2:1 fine -- classified and verified against the face lists by ibh_analyze.cpp) is
+//     fetched by one gather instruction per field and staged next to the tile.  No index
+//     arrays are read for these cells.
+//   * face-list path: one thread per cell walking the CSR left/right face lists; used for
+//     cells of partial (skirt) blocks, sides the analysis could not classify, 3-D, and when
+//     IBH_FORCE_GENERAL is set.
+// Both bodies call the same per-face functions (ibh_flux.h) in the same order, so they agree
+// bit for bit with each other and with the oracle's array-at-a-time evaluation.
+#include "ibh_common.h"
+#include "ibh_flux.h"
+
+using namespace ibhf;
+
+namespace {
+
+struct PartView {
+    int32_t nc;
+    const float* spacing;
+    DimData dim[IBH_MAXD];
+};
+
+// ------------------------------------------------------------------------------------------
+// face-list bodies
+// ------------------------------------------------------------------------------------------
+// G layout: gradient of variable v along dim d at G[(d*NV + v)*nc + c]; sensor at G[ND*NV*nc + c].
+template <int ND, int NV>
+__device__ __forceinline__ void passA_cell(const PartView& p, const float* __restrict__ u, int64_t ldu,
+                                           float* __restrict__ G, int32_t c) {
+    const int64_t nc = p.nc;
+    float D = 1e-7f;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const DimData& dd = p.dim[d];
+        const float* h = p.spacing + d * nc;
+        float hc = h[c];
+        float sr[NV], sl[NV];
+        float dr = 0.f, ar = 0.f, dl = 0.f, al = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) sr[v] = sl[v] = 0.f;
+        {
+            int32_t b = dd.roff[c], e = dd.roff[c + 1];
+            float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
+            for (int32_t k = b; k < e; ++k) {
+                int32_t f = dd.ridx[k];
+                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                float ho = h[o], hn = h[n];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float uo = u[o + v * ldu], un = u[n + v * ldu];
+                    float t = face_avg(uo, un, ho, hn) * w;
+                    sr[v] = (k == b) ? t : sr[v] + t;
+                    if (v == 0) {
+                        float df = un - uo;
+                        float td = df * w, ta = fabsf(df) * w;
+                        dr = (k == b) ? td : dr + td;
+                        ar = (k == b) ? ta : ar + ta;
+                    }
+                }
+            }
+        }
+        {
+            int32_t b = dd.loff[c], e = dd.loff[c + 1];
+            float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
+            for (int32_t k = b; k < e; ++k) {
+                int32_t f = dd.lidx[k];
+                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                float ho = h[o], hn = h[n];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float uo = u[o + v * ldu], un = u[n + v * ldu];
+                    float t = face_avg(uo, un, ho, hn) * w;
+                    sl[v] = (k == b) ? t : sl[v] + t;
+                    if (v == 0) {
+                        float df = un - uo;
+                        float td = df * w, ta = fabsf(df) * w;
+                        dl = (k == b) ? td : dl + td;
+                        al = (k == b) ? ta : al + ta;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) G[(int64_t)(d * NV + v) * nc + c] = (sr[v] - sl[v]) / hc;
+        float gg = (dr - dl) / hc;
+        float ugg = (ar + al) / hc;
+        D = fmaxf(D, (1e-7f + fabsf(gg)) / (1e-7f + ugg));
+    }
+    G[(int64_t)(ND * NV) * nc + c] = D;
+}
+
+template <int ND>
+__device__ __forceinline__ void passB_adv_cell(const PartView& p, const float* __restrict__ u,
+                                               const float* __restrict__ C, int64_t ldc, const float* __restrict__ G,
+                                               float* __restrict__ ud, int32_t c) {
+    const int64_t nc = p.nc;
+    const float* Ds = G + (int64_t)ND * nc;
+    float r = 0.0f;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const DimData& dd = p.dim[d];
+        const float* h = p.spacing + d * nc;
+        const float* g = G + (int64_t)d * nc;
+        const float* Cd = C + (int64_t)d * ldc;
+        float fr = 0.f, fl = 0.f;
+        {
+            int32_t b = dd.roff[c], e = dd.roff[c + 1];
+            float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
+            for (int32_t k = b; k < e; ++k) {
+                int32_t f = dd.ridx[k];
+                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                float t = adv_flux(u[o], u[n], g[o], g[n], Ds[o], Ds[n], Cd[o], Cd[n], h[o], h[n]) * w;
+                fr = (k == b) ? t : fr + t;
+            }
+        }
+        {
+            int32_t b = dd.loff[c], e = dd.loff[c + 1];
+            float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
+            for (int32_t k = b; k < e; ++k) {
+                int32_t f = dd.lidx[k];
+                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                float t = adv_flux(u[o], u[n], g[o], g[n], Ds[o], Ds[n], Cd[o], Cd[n], h[o], h[n]) * w;
+                fl = (k == b) ? t : fl + t;
+            }
+        }
+        r = r - (fr - fl) / h[c];
+    }
+    ud[c] = r;
+}
+
+template <int ND>
+__device__ __forceinline__ void passB_euler_cell(const PartView& p, const float* __restrict__ P, int64_t ldp,
+                                                 const float* __restrict__ G, float* __restrict__ Rr, int64_t ldr,
+                                                 float Rgas, float gamma, int32_t c) {
+    constexpr int NV = ND + 2;
+    const int64_t nc = p.nc;
+    const float* Ds = G + (int64_t)(ND * NV) * nc;
+    float res[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) res[v] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const DimData& dd = p.dim[d];
+        const float* h = p.spacing + d * nc;
+        double fr[NV], fl[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) fr[v] = fl[v] = 0.0;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int32_t* off = side ? dd.roff : dd.loff;
+            const int32_t* idx = side ? dd.ridx : dd.lidx;
+            double* acc = side ? fr : fl;
+            int32_t b = off[c], e = off[c + 1];
+            float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
+            for (int32_t k = b; k < e; ++k) {
+                int32_t f = idx[k];
+                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                float Po[NV], Pn[NV], dPo[NV], dPn[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    Po[v] = P[o + v * ldp];
+                    Pn[v] = P[n + v * ldp];
+                    dPo[v] = G[(int64_t)(d * NV + v) * nc + o];
+                    dPn[v] = G[(int64_t)(d * NV + v) * nc + n];
+                }
+                double F[NV];
+                euler_face_flux<ND>(Po, Pn, dPo, dPn, Ds[o], Ds[n], h[o], h[n], d, Rgas, gamma, F);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    double t = F[v] * (double)w;
+                    acc[v] = (k == b) ? t : acc[v] + t;
+                }
+            }
+        }
+        double hc = (double)h[c];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) res[v] = (float)((double)res[v] - (fr[v] - fl[v]) / hc);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) Rr[c + v * ldr] = res[v];
+}
+
+// ------------------------------------------------------------------------------------------
+// block fast path, 2-D, 8x8 blocks.  LDS per wave and per field: tile[64] + halo[4][8][2].
+// halo slot (s, t, k): side s, boundary cell t along the side, k-th face (k = 1 only on FINE sides)
+// ------------------------------------------------------------------------------------------
+#define WPB 4  // waves (= blocks) per 256-thread workgroup
+
+// Local id of the k-th neighbour cell across side s for boundary cell t, or -1 (mirror/general/none).
+__device__ __forceinline__ int32_t halo_cell(const BlockDesc2& b, int s, int t, int k) {
+    int ty = b.type[s];
+    // position of the opposite edge inside the neighbour block
+    // s=0 (x-): neighbour column 7; s=1 (x+): column 0; s=2 (y-): row 7; s=3 (y+): row 0
+    int tt;
+    int32_t base;
+    if (ty == SIDE_SAME) {
+        if (k) return -1;
+        tt = t;
+        base = b.nb[s][0];
+    } else if (ty == SIDE_COARSE) {
+        if (k) return -1;
+        tt = 4 * b.sub[s] + (t >> 1);
+        base = b.nb[s][0];
+    } else if (ty == SIDE_FINE) {
+        tt = 2 * (t & 3) + k;
+        base = b.nb[s][t >> 2];
+    } else {
+        return -1;
+    }
+    int pos = (s == 0) ? 7 + 8 * tt : (s == 1) ? 8 * tt : (s == 2) ? tt + 56 : tt;
+    return base + pos;
+}
+
+struct Nb {  // data of one neighbour direction for one lane
+    float v0, v1;  // neighbour value(s)
+    float hn;      // neighbour spacing along the face normal
+    bool two;      // two faces (FINE side)
+};
+
+// Fetch the neighbour across direction s (0:x- 1:x+ 2:y- 3:y+) of the field staged in `tile`/`halo`.
+__device__ __forceinline__ void nb_fetch(const float* tile, const float* halo, int lane, int i, int j, int s, float self,
+                                         float& v0, float& v1) {
+    bool edge = (s == 0) ? (i == 0) : (s == 1) ? (i == 7) : (s == 2) ? (j == 0) : (j == 7);
+    int t = (s < 2) ? j : i;
+    if (!edge) {
+        int off = (s == 0) ? -1 : (s == 1) ? 1 : (s == 2) ? -8 : 8;
+        v0 = tile[lane + off];
+        v1 = v0;
+    } else {
+        v0 = halo[(s * 8 + t) * 2];
+        v1 = halo[(s * 8 + t) * 2 + 1];
+    }
+    (void)self;
+}
+
+// Stage one field: tile[lane] = own value, halo slots gathered by lanes 0..63 (slot = lane).
+// MIRROR sides take the boundary cell's own value (o == n faces, ImmersedBoundary.jl:653-660).
+__device__ __forceinline__ float stage_field(const float* __restrict__ f, const BlockDesc2& b, int lane, float* tile,
+                                             float* halo, int32_t hc_idx, int32_t mirror_idx) {
+    float self = f[b.base + lane];
+    tile[lane] = self;
+    float hv = 0.0f;
+    if (hc_idx >= 0) hv = f[hc_idx];
+    else if (mirror_idx >= 0) hv = f[mirror_idx];
+    halo[lane] = hv;
+    return self;
+}
+
+__device__ __forceinline__ void lane_halo_role(const BlockDesc2& b, int lane, int32_t& hc_idx, int32_t& mirror_idx,
+                                               float& hn_slot) {
+    // lane -> halo slot (s, t, k): slot index = (s*8 + t)*2 + k
+    int k = lane & 1, t = (lane >> 1) & 7, s = lane >> 4;
+    hc_idx = halo_cell(b, s, t, k);
+    mirror_idx = -1;
+    if (b.type[s] == SIDE_MIRROR && k == 0) {
+        int own = (s == 0) ? 8 * t : (s == 1) ? 7 + 8 * t : (s == 2) ? t : t + 56;
+        mirror_idx = b.base + own;
+    }
+    (void)hn_slot;
+}
+
+template <int NV>
+__device__ __forceinline__ void passA_block2(const BlockDesc2* __restrict__ blocks, int32_t blk, const float* spacing,
+                                             int64_t nc, const float* __restrict__ u, int64_t ldu, float* __restrict__ G,
+                                             float* lds, int lane) {
+    const BlockDesc2& b = blocks[blk];
+    const int i = lane & 7, j = lane >> 3;
+    int32_t hc_idx, mirror_idx;
+    float dummy;
+    lane_halo_role(b, lane, hc_idx, mirror_idx, dummy);
+    float* tile = lds;         // [NV][64]
+    float* halo = lds + NV * 64;  // [NV][64]
+    float self[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) self[v] = stage_field(u + v * ldu, b, lane, tile + v * 64, halo + v * 64, hc_idx, mirror_idx);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int32_t c = b.base + lane;
+    float D = 1e-7f;
+    const bool general = (i == 0 && b.type[0] == SIDE_GENERAL) || (i == 7 && b.type[1] == SIDE_GENERAL) ||
+                         (j == 0 && b.type[2] == SIDE_GENERAL) || (j == 7 && b.type[3] == SIDE_GENERAL);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float hc = b.h[d];
+        const int sL = 2 * d, sR = 2 * d + 1;
+        const bool edgeL = d == 0 ? (i == 0) : (j == 0);
+        const bool edgeR = d == 0 ? (i == 7) : (j == 7);
+        const int tyL = b.type[sL], tyR = b.type[sR];
+        // neighbour spacing: same inside the block; 2h / h/2 across a 2:1 side (exact: powers of two
+        // times h would also be exact, but take the stored value to stay literal)
+        float hL = hc, hR = hc;
+        bool twoL = false, twoR = false;
+        if (edgeL) { hL = (tyL == SIDE_COARSE) ? hc * 2.0f : (tyL == SIDE_FINE) ? hc * 0.5f : hc; twoL = tyL == SIDE_FINE; }
+        if (edgeR) { hR = (tyR == SIDE_COARSE) ? hc * 2.0f : (tyR == SIDE_FINE) ? hc * 0.5f : hc; twoR = tyR == SIDE_FINE; }
+        float sr[NV], sl[NV], dr = 0.f, ar = 0.f, dl = 0.f, al = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float l0, l1, r0, r1;
+            nb_fetch(tile + v * 64, halo + v * 64, lane, i, j, sL, self[v], l0, l1);
+            nb_fetch(tile + v * 64, halo + v * 64, lane, i, j, sR, self[v], r0, r1);
+            // right faces: owner = this cell; left faces: neighbour = this cell
+            float fr0 = face_avg(self[v], r0, hc, hR);
+            float fl0 = face_avg(l0, self[v], hL, hc);
+            float wr = twoR ? 0.5f : 1.0f, wl = twoL ? 0.5f : 1.0f;
+            float a = fr0 * wr;
+            if (twoR) a = a + face_avg(self[v], r1, hc, hR) * wr;
+            float bb = fl0 * wl;
+            if (twoL) bb = bb + face_avg(l1, self[v], hL, hc) * wl;
+            sr[v] = a;
+            sl[v] = bb;
+            if (v == 0) {
+                float d0 = r0 - self[v];
+                dr = d0 * wr;
+                ar = fabsf(d0) * wr;
+                if (twoR) { float d1 = r1 - self[v]; dr = dr + d1 * wr; ar = ar + fabsf(d1) * wr; }
+                float e0 = self[v] - l0;
+                dl = e0 * wl;
+                al = fabsf(e0) * wl;
+                if (twoL) { float e1 = self[v] - l1; dl = dl + e1 * wl; al = al + fabsf(e1) * wl; }
+            }
+        }
+        if (!general) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) G[(int64_t)(d * NV + v) * nc + c] = (sr[v] - sl[v]) / hc;
+        }
+        float gg = (dr - dl) / hc;
+        float ugg = (ar + al) / hc;
+        D = fmaxf(D, (1e-7f + fabsf(gg)) / (1e-7f + ugg));
+    }
+    if (!general) G[(int64_t)(2 * NV) * nc + c] = D;
+    (void)spacing;
+}
+
+__device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ blocks, int32_t blk, int64_t nc,
+                                                 const float* __restrict__ u, const float* __restrict__ C, int64_t ldc,
+                                                 const float* __restrict__ G, float* __restrict__ ud, float* lds,
+                                                 int lane) {
+    const BlockDesc2& b = blocks[blk];
+    const int i = lane & 7, j = lane >> 3;
+    int32_t hc_idx, mirror_idx;
+    float dummy;
+    lane_halo_role(b, lane, hc_idx, mirror_idx, dummy);
+    // fields: 0:u 1:D 2:gx 3:gy 4:Cx 5:Cy   (halo of gx/Cx only meaningful on x sides, gy/Cy on y sides;
+    // every slot is gathered anyway: one instruction per field)
+    float* tile = lds;
+    float* halo = lds + 6 * 64;
+    const float* fld[6] = {u, G + 2 * nc, G, G + nc, C, C + ldc};
+    float self[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) self[q] = stage_field(fld[q], b, lane, tile + q * 64, halo + q * 64, hc_idx, mirror_idx);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int32_t c = b.base + lane;
+    float r = 0.0f;
+    const bool general = (i == 0 && b.type[0] == SIDE_GENERAL) || (i == 7 && b.type[1] == SIDE_GENERAL) ||
+                         (j == 0 && b.type[2] == SIDE_GENERAL) || (j == 7 && b.type[3] == SIDE_GENERAL);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float hc = b.h[d];
+        const int sL = 2 * d, sR = 2 * d + 1;
+        const bool edgeL = d == 0 ? (i == 0) : (j == 0);
+        const bool edgeR = d == 0 ? (i == 7) : (j == 7);
+        const int tyL = b.type[sL], tyR = b.type[sR];
+        float hL = hc, hR = hc;
+        bool twoL = false, twoR = false;
+        if (edgeL) { hL = (tyL == SIDE_COARSE) ? hc * 2.0f : (tyL == SIDE_FINE) ? hc * 0.5f : hc; twoL = tyL == SIDE_FINE; }
+        if (edgeR) { hR = (tyR == SIDE_COARSE) ? hc * 2.0f : (tyR == SIDE_FINE) ? hc * 0.5f : hc; twoR = tyR == SIDE_FINE; }
+        const int qg = 2 + d, qc = 4 + d;
+        float uL0, uL1, uR0, uR1, gL0, gL1, gR0, gR1, DL0, DL1, DR0, DR1, CL0, CL1, CR0, CR1;
+        nb_fetch(tile, halo, lane, i, j, sL, self[0], uL0, uL1);
+        nb_fetch(tile, halo, lane, i, j, sR, self[0], uR0, uR1);
+        nb_fetch(tile + 64, halo + 64, lane, i, j, sL, self[1], DL0, DL1);
+        nb_fetch(tile + 64, halo + 64, lane, i, j, sR, self[1], DR0, DR1);
+        nb_fetch(tile + qg * 64, halo + qg * 64, lane, i, j, sL, self[qg], gL0, gL1);
+        nb_fetch(tile + qg * 64, halo + qg * 64, lane, i, j, sR, self[qg], gR0, gR1);
+        nb_fetch(tile + qc * 64, halo + qc * 64, lane, i, j, sL, self[qc], CL0, CL1);
+        nb_fetch(tile + qc * 64, halo + qc * 64, lane, i, j, sR, self[qc], CR0, CR1);
+        float wr = twoR ? 0.5f : 1.0f, wl = twoL ? 0.5f : 1.0f;
+        float fr = adv_flux(self[0], uR0, self[qg], gR0, self[1], DR0, self[qc], CR0, hc, hR) * wr;
+        if (twoR) fr = fr + adv_flux(self[0], uR1, self[qg], gR1, self[1], DR1, self[qc], CR1, hc, hR) * wr;
+        float fl = adv_flux(uL0, self[0], gL0, self[qg], DL0, self[1], CL0, self[qc], hL, hc) * wl;
+        if (twoL) fl = fl + adv_flux(uL1, self[0], gL1, self[qg], DL1, self[1], CL1, self[qc], hL, hc) * wl;
+        r = r - (fr - fl) / hc;
+    }
+    if (!general) ud[c] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels: grid = [fast-path workgroups | face-list workgroups]
+// ------------------------------------------------------------------------------------------
+template <int ND, int NV>
+__global__ __launch_bounds__(256) void k_passA(PartView p, const float* __restrict__ u, int64_t ldu,
+                                               float* __restrict__ G, const BlockDesc2* __restrict__ blocks,
+                                               int32_t nblk, int32_t nwg_fast, const int32_t* __restrict__ cells,
+                                               int32_t ncells) {
+    __shared__ float lds[WPB * NV * 128];
+    if ((int32_t)blockIdx.x < nwg_fast) {
+        if constexpr (ND == 2) {
+            int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            int32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+            if (blk < nblk) passA_block2<NV>(blocks, blk, p.spacing, p.nc, u, ldu, G, lds + wave * NV * 128, lane);
+        }
+        return;
+    }
+    int64_t t = (int64_t)(blockIdx.x - nwg_fast) * blockDim.x + threadIdx.x;
+    if (t >= ncells) return;
+    int32_t c = cells ? cells[t] : (int32_t)t;
+    passA_cell<ND, NV>(p, u, ldu, G, c);
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void k_passB_adv(PartView p, const float* __restrict__ u, const float* __restrict__ C,
+                                                   int64_t ldc, const float* __restrict__ G, float* __restrict__ ud,
+                                                   const BlockDesc2* __restrict__ blocks, int32_t nblk,
+                                                   int32_t nwg_fast, const int32_t* __restrict__ cells,
+                                                   int32_t ncells) {
+    __shared__ float lds[WPB * 6 * 128];
+    if ((int32_t)blockIdx.x < nwg_fast) {
+        if constexpr (ND == 2) {
+            int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            int32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+            if (blk < nblk) passB_adv_block2(blocks, blk, p.nc, u, C, ldc, G, ud, lds + wave * 6 * 128, lane);
+        }
+        return;
+    }
+    int64_t t = (int64_t)(blockIdx.x - nwg_fast) * blockDim.x + threadIdx.x;
+    if (t >= ncells) return;
+    int32_t c = cells ? cells[t] : (int32_t)t;
+    passB_adv_cell<ND>(p, u, C, ldc, G, ud, c);
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void k_passB_euler(PartView p, const float* __restrict__ P, int64_t ldp,
+                                                     const float* __restrict__ G, float* __restrict__ R, int64_t ldr,
+                                                     float Rgas, float gamma, const int32_t* __restrict__ cells,
+                                                     int32_t ncells) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncells) return;
+    int32_t c = cells ? cells[t] : (int32_t)t;
+    passB_euler_cell<ND>(p, P, ldp, G, R, ldr, Rgas, gamma, c);
+}
+
+PartView view(const ibh_part* p) {
+    PartView v;
+    v.nc = p->nc;
+    v.spacing = p->spacing;
+    for (int d = 0; d < IBH_MAXD; ++d) v.dim[d] = p->dim[d];
+    return v;
+}
+
+int ensure_G(ibh_part* p, size_t floats) {
+    size_t bytes = floats * sizeof(float);
+    if (p->G_bytes >= bytes) return 0;
+    if (p->G) IBH_HIP(hipFree(p->G));
+    p->G = nullptr;
+    p->G_bytes = 0;
+    IBH_HIP(hipMalloc((void**)&p->G, bytes));
+    p->G_bytes = bytes;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t ldc, float* ud, int flags) {
+    IBH_REQUIRE(p && u && C && ud, "ibh_residual_advection: null argument");
+    if (p->nc == 0) return 0;
+    int rc = ensure_G(p, (size_t)(p->nd + 1) * p->nc);
+    if (rc) return rc;
+    const bool fast = p->bs == 8 && p->nd == 2 && p->nblk > 0 && !(flags & IBH_FORCE_GENERAL);
+    const int32_t nwg_fast = fast ? (p->nblk + WPB - 1) / WPB : 0;
+    // pass A always covers every cell of the partition (skirt cells feed the faces of image cells)
+    const int32_t* cellsA = fast ? p->irr_cells : nullptr;
+    const int32_t nA = fast ? p->n_irr : p->nc;
+    // pass B: every cell, or image cells only
+    const int32_t* cellsB = cellsA;
+    int32_t nB = nA;
+    int32_t nwgB_fast = nwg_fast;
+    if ((flags & IBH_IMAGE_ONLY) && !fast) {
+        cellsB = p->image_in_domain;
+        nB = p->n_image;
+    }
+    PartView v = view(p);
+    dim3 blk(256);
+    dim3 gA(nwg_fast + (nA + 255) / 256), gB(nwgB_fast + (nB + 255) / 256);
+    if (p->nd == 2) {
+        if (gA.x)
+            hipLaunchKernelGGL((k_passA<2, 1>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2, p->nblk,
+                               nwg_fast, cellsA, nA);
+        if (gB.x)
+            hipLaunchKernelGGL((k_passB_adv<2>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2, p->nblk,
+                               nwgB_fast, cellsB, nB);
+    } else {
+        if (gA.x)
+            hipLaunchKernelGGL((k_passA<3, 1>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2, p->nblk, 0,
+                               cellsA, nA);
+        if (gB.x)
+            hipLaunchKernelGGL((k_passB_adv<3>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2, p->nblk, 0,
+                               cellsB, nB);
+    }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, int64_t ldr, const ibh_fluid* fluid,
+                           int flags) {
+    IBH_REQUIRE(p && P && R && fluid, "ibh_residual_euler_hll: null argument");
+    if (p->nc == 0) return 0;
+    const int nv = p->nd + 2;
+    int rc = ensure_G(p, (size_t)(p->nd * nv + 1) * p->nc);
+    if (rc) return rc;
+    PartView v = view(p);
+    dim3 blk(256);
+    const int32_t* cellsB = nullptr;
+    int32_t nB = p->nc;
+    if (flags & IBH_IMAGE_ONLY) {
+        cellsB = p->image_in_domain;
+        nB = p->n_image;
+    }
+    dim3 gA((p->nc + 255) / 256), gB((nB + 255) / 256);
+    if (p->nd == 2) {
+        hipLaunchKernelGGL((k_passA<2, 4>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, (const BlockDesc2*)nullptr, 0, 0,
+                           (const int32_t*)nullptr, p->nc);
+        if (gB.x)
+            hipLaunchKernelGGL((k_passB_euler<2>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
+                               fluid->gamma, cellsB, nB);
+    } else {
+        hipLaunchKernelGGL((k_passA<3, 5>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, (const BlockDesc2*)nullptr, 0, 0,
+                           (const int32_t*)nullptr, p->nc);
+        if (gB.x)
+            hipLaunchKernelGGL((k_passB_euler<3>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
+                               fluid->gamma, cellsB, nB);
+    }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,460 @@
+// libibhip: face-list ("general") grid-operator kernels -- one entry point per reference
+// operator (ImmersedBoundary.jl:873-1157), accumulators, ghost-cell BC, row gather/scatter
+// and the small vector ops of the FAS loop.  HBM-bound gathers: threads run over the
+// contiguous row index (cell or face) so loads/stores of the row-major side are coalesced;
+// the variable index is the slow grid dimension.
+//
+// Arithmetic follows the reference's broadcast order operation by operation (compiled
+// with -ffp-contract=off, IEEE divide/sqrt) so results are bit-comparable with the oracle.
+#include "ibh_common.h"
+
+#define OPS_BLOCK 256
+
+namespace {
+
+__device__ __forceinline__ float face_avg(float uo, float un, float ho, float hn) {
+    // at_faces (:907-909): (u_o*h_n + u_n*h_o)/(h_n + h_o)
+    return (uo * hn + un * ho) / (hn + ho);
+}
+
+__global__ void k_gather(const int32_t* __restrict__ rows, int32_t n, const float* __restrict__ src, int64_t lds,
+                         float* __restrict__ dst, int64_t ldd) {
+    int64_t v = blockIdx.y;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i + v * ldd] = src[rows[i] + v * lds];
+}
+
+__global__ void k_scatter(const int32_t* __restrict__ rows, int32_t n, const float* __restrict__ src, int64_t lds,
+                          float* __restrict__ dst, int64_t ldd) {
+    int64_t v = blockIdx.y;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[rows[i] + v * ldd] = src[i + v * lds];
+}
+
+__global__ void k_copy_rows(const int32_t* __restrict__ drows, const int32_t* __restrict__ srows, int32_t n,
+                            const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd) {
+    int64_t v = blockIdx.y;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[drows[i] + v * ldd] = src[srows[i] + v * lds];
+}
+
+__global__ void k_at_faces(int32_t nf, const int32_t* __restrict__ own, const int32_t* __restrict__ nei,
+                           const float* __restrict__ h, const float* __restrict__ u, int64_t ldu,
+                           float* __restrict__ out, int64_t ldo) {
+    int64_t v = blockIdx.y;
+    for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < nf; f += (int64_t)gridDim.x * blockDim.x) {
+        int32_t o = own[f], n = nei[f];
+        out[f + v * ldo] = face_avg(u[o + v * ldu], u[n + v * ldu], h[o], h[n]);
+    }
+}
+
+// mode 0: face_distance, 1: owner_distance, 2: neighbor_distance
+__global__ void k_distances(int32_t nf, const int32_t* __restrict__ own, const int32_t* __restrict__ nei,
+                            const float* __restrict__ h, int mode, float* __restrict__ out) {
+    for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < nf; f += (int64_t)gridDim.x * blockDim.x) {
+        float ho = h[own[f]], hn = h[nei[f]];
+        out[f] = mode == 0 ? (ho + hn) / 2.0f : (mode == 1 ? ho / 2.0f : hn / 2.0f);
+    }
+}
+
+__global__ void k_face_gradient(int32_t nf, const int32_t* __restrict__ own, const int32_t* __restrict__ nei,
+                                const float* __restrict__ h, const float* __restrict__ u, int64_t ldu,
+                                float* __restrict__ out, int64_t ldo) {
+    int64_t v = blockIdx.y;
+    for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < nf; f += (int64_t)gridDim.x * blockDim.x) {
+        int32_t o = own[f], n = nei[f];
+        float fd = (h[o] + h[n]) / 2.0f;                       // face_distance (:1001)
+        out[f + v * ldo] = (u[n + v * ldu] - u[o + v * ldu]) / fd;  // :1041-1043
+    }
+}
+
+// mean over a CSR row of a face field (face accumulator with weights 1/len, :501-506)
+__device__ __forceinline__ float csr_mean(const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int32_t c,
+                                          const float* __restrict__ uf) {
+    int32_t b = off[c], e = off[c + 1];
+    if (e == b) return 0.0f;
+    float w = 1.0f / (float)(e - b);
+    float s = uf[idx[b]] * w;
+    for (int32_t k = b + 1; k < e; ++k) s = s + uf[idx[k]] * w;
+    return s;
+}
+
+__global__ void k_green_gauss(int32_t nc, const int32_t* __restrict__ loff, const int32_t* __restrict__ lidx,
+                              const int32_t* __restrict__ roff, const int32_t* __restrict__ ridx,
+                              const float* __restrict__ h, const float* __restrict__ uf, int64_t ldf,
+                              float* __restrict__ out, int64_t ldo, int uns) {
+    int64_t v = blockIdx.y;
+    const float* ufv = uf + v * ldf;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        float ar = csr_mean(roff, ridx, (int32_t)c, ufv);
+        float al = csr_mean(loff, lidx, (int32_t)c, ufv);
+        out[c + v * ldo] = (uns ? (ar + al) : (ar - al)) / h[c];  // :925 / :941
+    }
+}
+
+// cell_gradient = green_gauss(at_faces(u)) without materialising the face field (:965-972)
+__device__ __forceinline__ float csr_mean_face_avg(const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                                   int32_t c, const int32_t* __restrict__ own,
+                                                   const int32_t* __restrict__ nei, const float* __restrict__ h,
+                                                   const float* __restrict__ u) {
+    int32_t b = off[c], e = off[c + 1];
+    if (e == b) return 0.0f;
+    float w = 1.0f / (float)(e - b);
+    float s = 0.0f;
+    for (int32_t k = b; k < e; ++k) {
+        int32_t f = idx[k];
+        int32_t o = own[f], n = nei[f];
+        float t = face_avg(u[o], u[n], h[o], h[n]) * w;
+        s = (k == b) ? t : s + t;
+    }
+    return s;
+}
+
+__global__ void k_cell_gradient(int32_t nc, DimData D, const float* __restrict__ h, const float* __restrict__ u,
+                                int64_t ldu, float* __restrict__ out, int64_t ldo) {
+    int64_t v = blockIdx.y;
+    const float* uv = u + v * ldu;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        float ar = csr_mean_face_avg(D.roff, D.ridx, (int32_t)c, D.owners, D.neighbors, h, uv);
+        float al = csr_mean_face_avg(D.loff, D.lidx, (int32_t)c, D.owners, D.neighbors, h, uv);
+        out[c + v * ldo] = (ar - al) / h[c];
+    }
+}
+
+// JST_sensor for one dim (:1091-1096): nu = (1e-7 + |gg(dp)|)/(1e-7 + ugg(|dp|)), dp = p_n - p_o
+__device__ __forceinline__ void csr_mean_diff(const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int32_t c,
+                                              const int32_t* __restrict__ own, const int32_t* __restrict__ nei,
+                                              const float* __restrict__ p, float& sd, float& sa) {
+    int32_t b = off[c], e = off[c + 1];
+    sd = 0.0f;
+    sa = 0.0f;
+    if (e == b) return;
+    float w = 1.0f / (float)(e - b);
+    for (int32_t k = b; k < e; ++k) {
+        int32_t f = idx[k];
+        float d = p[nei[f]] - p[own[f]];
+        float td = d * w, ta = fabsf(d) * w;
+        sd = (k == b) ? td : sd + td;
+        sa = (k == b) ? ta : sa + ta;
+    }
+}
+
+__device__ __forceinline__ float jst_dim(const DimData& D, const float* __restrict__ h, const float* __restrict__ p,
+                                         int32_t c) {
+    float dr, ar, dl, al;
+    csr_mean_diff(D.roff, D.ridx, c, D.owners, D.neighbors, p, dr, ar);
+    csr_mean_diff(D.loff, D.lidx, c, D.owners, D.neighbors, p, dl, al);
+    float hc = h[c];
+    float gg = (dr - dl) / hc;
+    float ugg = (ar + al) / hc;
+    return (1e-7f + fabsf(gg)) / (1e-7f + ugg);
+}
+
+__global__ void k_jst(int32_t nc, int nd, int dim, DimData D0, DimData D1, DimData D2,
+                      const float* __restrict__ spacing, const float* __restrict__ p, int64_t ldp,
+                      float* __restrict__ out, int64_t ldo) {
+    int64_t v = blockIdx.y;
+    const float* pv = p + v * ldp;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        float nu;
+        if (dim > 0) {
+            const DimData& D = dim == 1 ? D0 : (dim == 2 ? D1 : D2);
+            nu = jst_dim(D, spacing + (int64_t)(dim - 1) * nc, pv, (int32_t)c);
+        } else {
+            nu = 1e-7f;  // :1082-1086
+            nu = fmaxf(nu, jst_dim(D0, spacing, pv, (int32_t)c));
+            nu = fmaxf(nu, jst_dim(D1, spacing + (int64_t)nc, pv, (int32_t)c));
+            if (nd == 3) nu = fmaxf(nu, jst_dim(D2, spacing + 2 * (int64_t)nc, pv, (int32_t)c));
+        }
+        out[c + v * ldo] = nu;
+    }
+}
+
+__device__ __forceinline__ float sgn(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+__device__ __forceinline__ float minmod(float a, float b) {  // :1099
+    return fminf(fabsf(a), fabsf(b)) * (sgn(a) + sgn(b)) / 2.0f;
+}
+
+__global__ void k_muscl(int32_t nf, const int32_t* __restrict__ own, const int32_t* __restrict__ nei,
+                        const float* __restrict__ h, const float* __restrict__ u, const float* __restrict__ du,
+                        int64_t ld, const float* __restrict__ Dsens, int high_order, float* __restrict__ uL,
+                        float* __restrict__ uR, int64_t ldf) {
+    int64_t v = blockIdx.y;
+    for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < nf; f += (int64_t)gridDim.x * blockDim.x) {
+        int32_t o = own[f], n = nei[f];
+        float dow = h[o] / 2.0f, dn = h[n] / 2.0f;  // owner/neighbor_distance
+        float uo = u[o + v * ld], un = u[n + v * ld];
+        float guf = (un - uo) / (dow + dn);
+        float duo = du[o + v * ld], dun = du[n + v * ld];
+        float gu = (2.0f * duo - guf) * dow;
+        float Du = (2.0f * dun - guf) * dn;
+        float s = minmod(Du, gu);
+        float l = uo + s, r = un - s;
+        if (Dsens) {
+            float Df = fmaxf(fmaxf(Dsens[o], Dsens[n]), 1e-7f);
+            float uf = (uo * dn + un * dow) / (dow + dn);
+            if (high_order) uf = uf + (duo * dow - dun * dn) / 8.0f;
+            l = l * Df + (1.0f - Df) * uf;
+            r = r * Df + (1.0f - Df) * uf;
+        }
+        uL[f + v * ldf] = l;
+        uR[f + v * ldf] = r;
+    }
+}
+
+__global__ void k_accumulate(int32_t n_out, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                             const float* __restrict__ w, const int32_t* __restrict__ remap,
+                             const float* __restrict__ v, int64_t ldv, float* __restrict__ out, int64_t ldo) {
+    int64_t var = blockIdx.y;
+    const float* vv = v + var * ldv;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
+        int32_t b = off[r], e = off[r + 1];
+        float s = 0.0f;
+        for (int32_t k = b; k < e; ++k) {
+            int32_t j = idx[k];
+            if (remap) j = remap[j];
+            float t = w ? vv[j] * w[k] : vv[j];
+            s = (k == b) ? t : s + t;
+        }
+        out[r + var * ldo] = s;
+    }
+}
+
+// a[ghost] = eta*ia + (1-eta)*ba (:1242-1245); ba from array, constant, or ia (copy BC)
+__global__ void k_bc_blend(int32_t ng, const int32_t* __restrict__ ghost, const float* __restrict__ eta,
+                           float* __restrict__ a, int64_t lda, const float* __restrict__ ia, int64_t ldi,
+                           const float* __restrict__ ba, int64_t ldb, const float* __restrict__ bconst) {
+    int64_t v = blockIdx.y;
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < ng; g += (int64_t)gridDim.x * blockDim.x) {
+        float e = eta[g];
+        float i = ia[g + v * ldi];
+        float b = ba ? ba[g + v * ldb] : bconst[v];
+        a[ghost[g] + v * lda] = e * i + (1.0f - e) * b;
+    }
+}
+
+__global__ void k_axpy_clamped(int64_t n, float omega, const float* __restrict__ r, float* __restrict__ q) {
+    float w = fminf(fmaxf(omega, 0.0f), 1.0f);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        q[i] = q[i] + w * r[i];
+}
+
+__global__ void k_axpy(int64_t n, float a, const float* __restrict__ x, float* __restrict__ y) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + y[i];
+}
+
+__global__ void k_sumsq(int64_t n, const float* __restrict__ x, double* __restrict__ out) {
+    double s = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double t = (double)x[i];
+        s += t * t;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ double part[OPS_BLOCK / 64];
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) part[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < OPS_BLOCK / 64; ++i) t += part[i];
+        atomicAdd(out, t);
+    }
+}
+
+inline dim3 grid2(int64_t n, int nv) { return dim3(ibh_grid(n, OPS_BLOCK) > 4096 ? 4096 : ibh_grid(n, OPS_BLOCK), nv); }
+
+}  // namespace
+
+#define CHECK_DIM(p, dim) IBH_REQUIRE((p) && (dim) >= 1 && (dim) <= (p)->nd, "dim out of range or null partition")
+#define CHECK_NV(nv) IBH_REQUIRE((nv) >= 1 && (nv) <= 65535, "nv out of range")
+
+extern "C" {
+
+int ibh_gather_rows(const int32_t* rows, int32_t n, const float* src, int nv, int64_t lds, float* dst, int64_t ldd) {
+    CHECK_NV(nv);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_gather, grid2(n, nv), dim3(OPS_BLOCK), 0, ibh_stream, rows, n, src, lds, dst, ldd);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_scatter_rows(const int32_t* rows, int32_t n, const float* src, int nv, int64_t lds, float* dst, int64_t ldd) {
+    CHECK_NV(nv);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_scatter, grid2(n, nv), dim3(OPS_BLOCK), 0, ibh_stream, rows, n, src, lds, dst, ldd);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_copy_rows(const int32_t* drows, const int32_t* srows, int32_t n, const float* src, int nv, int64_t lds,
+                  float* dst, int64_t ldd) {
+    CHECK_NV(nv);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_copy_rows, grid2(n, nv), dim3(OPS_BLOCK), 0, ibh_stream, drows, srows, n, src, lds, dst, ldd);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_at_owners(const ibh_part* p, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo) {
+    CHECK_DIM(p, dim);
+    return ibh_gather_rows(p->dim[dim - 1].owners, p->dim[dim - 1].nf, u, nv, ldu, out, ldo);
+}
+int ibh_at_neighbors(const ibh_part* p, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo) {
+    CHECK_DIM(p, dim);
+    return ibh_gather_rows(p->dim[dim - 1].neighbors, p->dim[dim - 1].nf, u, nv, ldu, out, ldo);
+}
+
+int ibh_at_faces(const ibh_part* p, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo) {
+    CHECK_DIM(p, dim);
+    CHECK_NV(nv);
+    const DimData& D = p->dim[dim - 1];
+    if (D.nf == 0) return 0;
+    hipLaunchKernelGGL(k_at_faces, grid2(D.nf, nv), dim3(OPS_BLOCK), 0, ibh_stream, D.nf, D.owners, D.neighbors,
+                       p->spacing + (int64_t)(dim - 1) * p->nc, u, ldu, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_green_gauss(const ibh_part* p, int dim, const float* uf, int nv, int64_t ldf, float* out, int64_t ldo,
+                    int uns) {
+    CHECK_DIM(p, dim);
+    CHECK_NV(nv);
+    const DimData& D = p->dim[dim - 1];
+    if (p->nc == 0) return 0;
+    hipLaunchKernelGGL(k_green_gauss, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, D.loff, D.lidx, D.roff,
+                       D.ridx, p->spacing + (int64_t)(dim - 1) * p->nc, uf, ldf, out, ldo, uns);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_cell_gradient(const ibh_part* p, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo) {
+    CHECK_DIM(p, dim);
+    CHECK_NV(nv);
+    if (p->nc == 0) return 0;
+    hipLaunchKernelGGL(k_cell_gradient, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, p->dim[dim - 1],
+                       p->spacing + (int64_t)(dim - 1) * p->nc, u, ldu, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+static int distances(const ibh_part* p, int dim, int mode, float* out) {
+    CHECK_DIM(p, dim);
+    const DimData& D = p->dim[dim - 1];
+    if (D.nf == 0) return 0;
+    hipLaunchKernelGGL(k_distances, grid2(D.nf, 1), dim3(OPS_BLOCK), 0, ibh_stream, D.nf, D.owners, D.neighbors,
+                       p->spacing + (int64_t)(dim - 1) * p->nc, mode, out);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_face_distance(const ibh_part* p, int dim, float* out) { return distances(p, dim, 0, out); }
+int ibh_owner_distance(const ibh_part* p, int dim, float* out) { return distances(p, dim, 1, out); }
+int ibh_neighbor_distance(const ibh_part* p, int dim, float* out) { return distances(p, dim, 2, out); }
+
+int ibh_face_gradient(const ibh_part* p, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo) {
+    CHECK_DIM(p, dim);
+    CHECK_NV(nv);
+    const DimData& D = p->dim[dim - 1];
+    if (D.nf == 0) return 0;
+    hipLaunchKernelGGL(k_face_gradient, grid2(D.nf, nv), dim3(OPS_BLOCK), 0, ibh_stream, D.nf, D.owners, D.neighbors,
+                       p->spacing + (int64_t)(dim - 1) * p->nc, u, ldu, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_jst_sensor(const ibh_part* p, int dim, const float* q, int nv, int64_t ldp, float* out, int64_t ldo) {
+    IBH_REQUIRE(p && dim >= 0 && dim <= p->nd, "ibh_jst_sensor: dim out of range");
+    CHECK_NV(nv);
+    if (p->nc == 0) return 0;
+    hipLaunchKernelGGL(k_jst, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, p->nd, dim, p->dim[0], p->dim[1],
+                       p->dim[2], p->spacing, q, ldp, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_muscl(const ibh_part* p, int dim, const float* u, const float* du, int nv, int64_t ld, const float* D,
+              int high_order, float* uL, float* uR, int64_t ldf) {
+    CHECK_DIM(p, dim);
+    CHECK_NV(nv);
+    const DimData& DD = p->dim[dim - 1];
+    if (DD.nf == 0) return 0;
+    hipLaunchKernelGGL(k_muscl, grid2(DD.nf, nv), dim3(OPS_BLOCK), 0, ibh_stream, DD.nf, DD.owners, DD.neighbors,
+                       p->spacing + (int64_t)(dim - 1) * p->nc, u, du, ld, D, high_order, uL, uR, ldf);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_accumulate(const ibh_acc* a, const float* v, int nv, int64_t ldv, float* out, int64_t ldo) {
+    IBH_REQUIRE(a, "ibh_accumulate: null accumulator");
+    CHECK_NV(nv);
+    if (a->n_out == 0) return 0;
+    hipLaunchKernelGGL(k_accumulate, grid2(a->n_out, nv), dim3(OPS_BLOCK), 0, ibh_stream, a->n_out, a->off, a->idx,
+                       a->w, (const int32_t*)nullptr, v, ldv, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_bc_interp(const ibh_bc* b, const float* a, int nv, int64_t lda, float* ia, int64_t ldi) {
+    IBH_REQUIRE(b, "ibh_bc_interp: null boundary");
+    CHECK_NV(nv);
+    if (b->ng == 0) return 0;
+    hipLaunchKernelGGL(k_accumulate, grid2(b->ng, nv), dim3(OPS_BLOCK), 0, ibh_stream, b->ng, b->interp.off,
+                       b->interp.idx, b->interp.w, b->image_domain, a, lda, ia, ldi);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_bc_blend(const ibh_bc* b, float* a, int nv, int64_t lda, const float* ia, int64_t ldi, const float* ba,
+                 int64_t ldb, const float* ba_const) {
+    IBH_REQUIRE(b && (ba || ba_const), "ibh_bc_blend: need ba or ba_const");
+    CHECK_NV(nv);
+    if (b->ng == 0) return 0;
+    float* dconst = nullptr;
+    if (!ba) {
+        IBH_HIP(hipMallocAsync((void**)&dconst, sizeof(float) * nv, ibh_stream));
+        IBH_HIP(hipMemcpyAsync(dconst, ba_const, sizeof(float) * nv, hipMemcpyHostToDevice, ibh_stream));
+    }
+    hipLaunchKernelGGL(k_bc_blend, grid2(b->ng, nv), dim3(OPS_BLOCK), 0, ibh_stream, b->ng, b->ghost, b->eta, a, lda,
+                       ia, ldi, ba, ldb, dconst);
+    IBH_LAUNCH_CHECK();
+    if (dconst) IBH_HIP(hipFreeAsync(dconst, ibh_stream));
+    return 0;
+}
+
+int ibh_bc_apply(const ibh_bc* b, float* a, int nv, int64_t lda, int mode, const float* ba_const) {
+    IBH_REQUIRE(b && (mode == 0 || mode == 1), "ibh_bc_apply: bad mode");
+    CHECK_NV(nv);
+    if (b->ng == 0) return 0;
+    float* ia = nullptr;
+    IBH_HIP(hipMallocAsync((void**)&ia, sizeof(float) * (size_t)b->ng * nv, ibh_stream));
+    int rc = ibh_bc_interp(b, a, nv, lda, ia, b->ng);
+    if (!rc) rc = (mode == 0) ? ibh_bc_blend(b, a, nv, lda, ia, b->ng, nullptr, 0, ba_const)
+                              : ibh_bc_blend(b, a, nv, lda, ia, b->ng, ia, b->ng, nullptr);
+    hipError_t e = hipFreeAsync(ia, ibh_stream);
+    if (rc) return rc;
+    IBH_HIP(e);
+    return 0;
+}
+
+int ibh_axpy_clamped(int64_t n, float omega, const float* r, float* q) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_axpy_clamped, dim3(ibh_grid(n, OPS_BLOCK) > 2048 ? 2048 : ibh_grid(n, OPS_BLOCK)),
+                       dim3(OPS_BLOCK), 0, ibh_stream, n, omega, r, q);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_axpy(int64_t n, float a, const float* x, float* y) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_axpy, dim3(ibh_grid(n, OPS_BLOCK) > 2048 ? 2048 : ibh_grid(n, OPS_BLOCK)), dim3(OPS_BLOCK), 0,
+                       ibh_stream, n, a, x, y);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_sumsq(int64_t n, const float* x, double* out) {
+    IBH_HIP(hipMemsetAsync(out, 0, sizeof(double), ibh_stream));
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_sumsq, dim3(ibh_grid(n, OPS_BLOCK) > 1024 ? 1024 : ibh_grid(n, OPS_BLOCK)), dim3(OPS_BLOCK), 0,
+                       ibh_stream, n, x, out);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -256,7 +256,13 @@ def proj2simplex(simplex, pt):
         p0 = simplex[:, 0]
         p1 = simplex[:, 1]
         u = p1 - p0
-        xi = np.dot(pt - p0, u) / (np.dot(u, u) + eps_)
+        a = (pt - p0) * u
+        b = u * u
+        num, den = a[0], b[0]
+        for q in range(1, a.shape[0]):
+            num = num + a[q]
+            den = den + b[q]
+        xi = num / (den + eps_)
         if xi < -eps_:
             return p0.copy()
         elif xi > 1.0 + eps_:

@@ -1,0 +1,173 @@
+/*
+ * libibhip -- C ABI of the MI355X (gfx950) residual hot path for
+ * ImmersedBoundary.jl-style block-octree partitions.
+ *
+ * This header is the drop-in boundary.  The reference has no
+ * FFI of its own: its plug-in hook is `conv_to_backend` / `to_backend`
+ * (/root/reference/src/ImmersedBoundary.jl:846-855, src/arraybends.jl:14-77)
+ * plus Julia multiple dispatch on the operators
+ * (/root/reference/src/ImmersedBoundary.jl:873-1157).  Each entry point below
+ * names the reference function it replaces; julia/IBHip.jl shows the `ccall`
+ * binding a maintainer would add.
+ *
+ * Conventions
+ *   - fields are Float32, column-major `(rows, nv)` with leading dimension
+ *     `ld` (in elements): variable v of row i is `a[i + v*ld]`  (README.md:172);
+ *   - `dim` is 1-based like the reference; `dim = 0` means "all dims" where
+ *     the reference allows it (JST_sensor);
+ *   - index arrays handed to the *_create functions are HOST pointers in the
+ *     caller's base (`index_base` = 1 for Julia, 0 for C/Python); the library
+ *     keeps its own device copies;
+ *   - field pointers (`u`, `out`, ...) are DEVICE pointers (from ibh_malloc or
+ *     any HIP allocation of the caller, e.g. a torch tensor's data_ptr);
+ *   - every function returns 0 on success, a non-zero code otherwise and
+ *     never throws; `ibh_last_error()` gives the message (thread-local);
+ *   - kernels are launched on the stream given to `ibh_set_stream` (per host
+ *     thread; default: the null stream) and are asynchronous.
+ */
+#ifndef IBHIP_H
+#define IBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ibh_part ibh_part; /* device-resident Partition  (ImmersedBoundary.jl:383-392) */
+typedef struct ibh_acc ibh_acc;   /* device-resident Accumulator (accumulator.jl:12-16)        */
+typedef struct ibh_bc ibh_bc;     /* device-resident Boundary    (ImmersedBoundary.jl:406-414) */
+
+/* Ideal-gas constants used by the fused Euler residual (cfd.jl:14-53). */
+typedef struct ibh_fluid {
+    float R;
+    float gamma;
+} ibh_fluid;
+
+/* ---- runtime ---------------------------------------------------------- */
+int ibh_init(int device);             /* hipSetDevice + sanity check that the device is gfx950 */
+const char* ibh_last_error(void);
+int ibh_set_stream(void* hip_stream); /* stream for subsequent calls of this host thread */
+int ibh_sync(void);                   /* hipStreamSynchronize on that stream */
+int ibh_version(void);
+
+/* ---- memory (for hosts without their own HIP allocator, e.g. julia/IBHip.jl) */
+int ibh_malloc(void** dptr, size_t bytes);
+int ibh_free(void* dptr);
+int ibh_h2d(void* dst, const void* src, size_t bytes);
+int ibh_d2h(void* dst, const void* src, size_t bytes);
+int ibh_memset(void* dst, int value, size_t bytes);
+
+/* ---- Partition: replaces `to_backend(part, conv)` (ImmersedBoundary.jl:848, :788) ----
+ * Uploads once.  `spacing`/`centers` are `(nc, nd)` column-major (part.spacing,
+ * part.centers).  For each dim d (0..nd-1): `nf[d]` faces with
+ * `owners[d]`/`neighbors[d]` (part.face_owners_neighbors[dim]); left/right
+ * incidence in CSR form (`*_off[d]` has nc+1 entries, `*_idx[d]` face ids in
+ * the accumulator's stencil order) = part.face_accumulators[(dim,false/true)]
+ * whose weights are 1/len (ImmersedBoundary.jl:501-506, :675-684).
+ * `domain` = part.domain (global cell ids, sorted) and `block_size` let the
+ * library recover the block structure for the block-structured fast path;
+ * pass domain = NULL or block_size = 0 to disable it.
+ */
+int ibh_partition_create(ibh_part** out, int nd, int32_t nc,
+                         const float* spacing, const float* centers,
+                         const int32_t* nf,
+                         const int32_t* const* owners, const int32_t* const* neighbors,
+                         const int32_t* const* left_off, const int32_t* const* left_idx,
+                         const int32_t* const* right_off, const int32_t* const* right_idx,
+                         int32_t n_image, const int32_t* image_in_domain,
+                         const int32_t* domain, int block_size, int index_base);
+int ibh_partition_destroy(ibh_part* part);
+/* Introspection of the block analysis: info[0]=full blocks, [1]=irregular cells,
+ * [2..6] = number of block sides classified SAME, MIRROR, COARSE, FINE, GENERAL. */
+int ibh_partition_info(const ibh_part* part, int64_t* info, int n);
+
+/* ---- grid operators on a Partition (ImmersedBoundary.jl:873-1157) ----------
+ * `u`: (nc, nv) cell field; `uf`: (nf_dim, nv) face field.  Outputs are new
+ * arrays supplied by the caller (the reference returns fresh arrays).        */
+int ibh_at_owners(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo);    /* :879 */
+int ibh_at_neighbors(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo); /* :889 */
+int ibh_at_faces(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo);     /* :899 */
+int ibh_green_gauss(const ibh_part*, int dim, const float* uf, int nv, int64_t ldf, float* out, int64_t ldo,
+                    int unsigned_sum);                                                                         /* :918, :934 */
+int ibh_cell_gradient(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo); /* :965 */
+int ibh_face_distance(const ibh_part*, int dim, float* out);     /* :995  */
+int ibh_owner_distance(const ibh_part*, int dim, float* out);    /* :1010 */
+int ibh_neighbor_distance(const ibh_part*, int dim, float* out); /* :1024 */
+int ibh_face_gradient(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo); /* :1039 */
+int ibh_jst_sensor(const ibh_part*, int dim, const float* p, int nv, int64_t ldp, float* out, int64_t ldo);    /* :1077 */
+/* MUSCL(part,u,du,dim;D,high_order) :1113.  `D` may be NULL (no sensor blending). */
+int ibh_muscl(const ibh_part*, int dim, const float* u, const float* du, int nv, int64_t ld,
+              const float* D, int high_order, float* uL, float* uR, int64_t ldf);
+
+/* ---- Accumulator (accumulator.jl:39-130): CSR form of the bucketed stencils ----
+ * Row r sums `w[k]*v[idx[k]]` for k in [off[r], off[r+1]) in that order; `w` may
+ * be NULL (unweighted).  Used for face incidence, BC image interpolation and
+ * multigrid coarseners/prolongators (ImmersedBoundary.jl:1391-1392).           */
+int ibh_acc_create(ibh_acc** out, int32_t n_output, int32_t n_input,
+                   const int32_t* off, const int32_t* idx, const float* w, int index_base);
+int ibh_acc_destroy(ibh_acc*);
+int ibh_accumulate(const ibh_acc*, const float* v, int nv, int64_t ldv, float* out, int64_t ldo);
+
+/* ---- ghost-cell BC: impose_bc! (ImmersedBoundary.jl:1197-1247) ----------------
+ * Boundary data: ghost ids (global rows of `a`), image-point interpolator
+ * already re-indexed to `image_domain` (Boundary ctor :436-447), and
+ * eta = ghost_distances ./ image_distances (:1220).                             */
+int ibh_bc_create(ibh_bc** out, int32_t n_ghost, const int32_t* ghost_indices,
+                  const float* ghost_distances, const float* image_distances,
+                  int32_t n_image_domain, const int32_t* image_domain,
+                  const int32_t* interp_off, const int32_t* interp_idx, const float* interp_w,
+                  int index_base);
+int ibh_bc_destroy(ibh_bc*);
+/* ia = image_interpolator(a[image_domain, :])  (:1228-1230); ia is (n_ghost, nv) */
+int ibh_bc_interp(const ibh_bc*, const float* a, int nv, int64_t lda, float* ia, int64_t ldi);
+/* a[ghost, :] = eta*ia + (1-eta)*ba (:1242-1245).  `ba` (n_ghost, nv), or NULL
+ * to use the per-variable constants `ba_const[nv]` (closures returning a scalar,
+ * test/advection.jl:34).                                                        */
+int ibh_bc_blend(const ibh_bc*, float* a, int nv, int64_t lda, const float* ia, int64_t ldi,
+                 const float* ba, int64_t ldb, const float* ba_const);
+/* Fused interp + blend for the two closures the reference's tests use:
+ * mode 0: Dirichlet constant  (ba = ba_const),  mode 1: copy / zero-gradient (ba = ia). */
+int ibh_bc_apply(const ibh_bc*, float* a, int nv, int64_t lda, int mode, const float* ba_const);
+
+/* ---- partition runtime: (dom::Domain)(f, args...) (ImmersedBoundary.jl:836-859) ----
+ * gather: local[i,:] = global[domain[i],:]; scatter: global[image[j],:] = local[image_in_domain[j],:].
+ * `rows` is a DEVICE index array (0-based) of length n.                          */
+int ibh_gather_rows(const int32_t* rows, int32_t n, const float* src, int nv, int64_t lds, float* dst, int64_t ldd);
+int ibh_scatter_rows(const int32_t* rows, int32_t n, const float* src, int nv, int64_t lds, float* dst, int64_t ldd);
+/* dst[dst_rows[i],:] = src[src_rows[i],:] (halo unpack / image scatter) */
+int ibh_copy_rows(const int32_t* dst_rows, const int32_t* src_rows, int32_t n,
+                  const float* src, int nv, int64_t lds, float* dst, int64_t ldd);
+
+/* ---- fused residual sweeps (the headline hot path) --------------------------------
+ * ibh_residual_advection: exactly the closure of test/advection.jl:67-83,
+ *     D = JST_sensor(part,u); per dim: Cf = at_faces(C[:,dim]); gu = cell_gradient(u,dim);
+ *     uL,uR = MUSCL(u,gu,dim; D, high_order=true);
+ *     ud -= green_gauss((uL+uR)*Cf/2 + |Cf|*(uL-uR)/2, dim)
+ *   with ud starting from 0.  `C` is (nc, nd) with leading dimension ldc.
+ * ibh_residual_euler_hll: R2 of SURVEY.md 8d composed from reference operators,
+ *     D = JST_sensor(part,P[:,1]); per dim: gP = cell_gradient(P,dim);
+ *     PL,PR = MUSCL(P,gP,dim; D, high_order=true); F = inviscid_fluxes(fluid,PL,PR,dim)
+ *     (cfd.jl:459-508); R -= green_gauss(F,dim), R starting from 0;  P = [p T u v (w)].
+ * flags: bit0 = force the general face-list kernels (no block fast path);
+ *        bit1 = image cells only (skirt rows of the output are left untouched).
+ */
+#define IBH_FORCE_GENERAL 1
+#define IBH_IMAGE_ONLY 2
+int ibh_residual_advection(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags);
+int ibh_residual_euler_hll(ibh_part*, const float* P, int64_t ldp, float* R, int64_t ldr,
+                           const ibh_fluid* fluid, int flags);
+
+/* ---- small device-resident vector ops for the FAS loop (solver.jl:79-88) ---------- */
+/* q += clamp(omega,0,1) * r ; omega scalar */
+int ibh_axpy_clamped(int64_t n, float omega, const float* r, float* q);
+/* y = a*x + y */
+int ibh_axpy(int64_t n, float a, const float* x, float* y);
+/* *out (device, double) = sum(x^2) */
+int ibh_sumsq(int64_t n, const float* x, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBHIP_H */
