@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Residual-sweep benchmark: Mcells*iters/s of the fused advection-JST-MUSCL residual (R1 of
+SURVEY.md 8d = the closure of /root/reference/test/advection.jl:67-83) on the 2-D RAE2822
+block-quadtree mesh at ~1 M cells (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one residual sweep over the rank's partition with all fields resident in HBM; for
+N > 1 the ~1 M-cell domain is cut into N contiguous partitions (one per GPU, strong scaling)
+and every step first refreshes the skirt cells from their owners (RCCL grouped send/recv).
+Rank 0 prints ONE JSON line.  The oracle is used only in the `cpu_baseline` leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+B_ALG_2D = 16.0        # algorithmic bytes per cell and sweep: u, Cx, Cy in, ud out
+
+WORKLOADS = {
+    # name: (h_wall, h_feature)  -- reference mesher semantics on test/rae2822.dat, domain [-25,25]^2
+    "rae2822_0.87M": (2.5e-4, 1.25e-4),
+    "rae2822_3.47M": (6e-5, 3e-5),
+    "rae2822_37k": (1e-2, 5e-3),
+}
+
+
+def build_mesh(name):
+    import ibamd
+    from ibamd.mesher import DistanceField, Mesh, Stereolitography, feature_regions, merge_points
+    hw, hf = WORKLOADS[name]
+    f32 = np.float32
+    stl = merge_points(Stereolitography(os.path.join(ROOT, "tests", "golden", "rae2822.dat")))
+    features = DistanceField(feature_regions(stl, radius=0.05))
+    return Mesh(f32([-25.0, -25.0]), f32([50.0, 50.0]), ("wall", stl, f32(hw)),
+                refinement_regions=[(features, f32(hf))])
+
+
+def synthetic_fields(centers, seed=12345):
+    """u = sin(2 pi x) cos(2 pi y) + 0.1 noise, C = (1, 1)  (SURVEY.md 8d)."""
+    rng = np.random.default_rng(seed)
+    x, y = centers[:, 0].astype(np.float64), centers[:, 1].astype(np.float64)
+    u = (np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) + 0.1 * rng.uniform(-1, 1, x.size)).astype(np.float32)
+    C = np.ones((x.size, 2), dtype=np.float32)
+    return u, C
+
+
+def cpu_baseline(part, u, C, budget_s=12.0):
+    """Oracle (numpy restatement, array-at-a-time like the Julia broadcasts) timed on this host."""
+    from oracle import domain as od
+    from oracle.accumulator import Accumulator as OAcc
+
+    class P:  # oracle-side view of the same partition
+        pass
+    op = P()
+    op.ndims = part.ndims
+    op.spacing, op.centers = part.spacing, part.centers
+    op.face_owners_neighbors = part.face_owners_neighbors
+    op.face_accumulators = {}
+    for k, acc in part.face_accumulators.items():
+        o = object.__new__(OAcc)
+        o.n_output, o.first_index, o.stencils = acc.n_output, True, acc.stencils
+        op.face_accumulators[k] = o
+    f32 = np.float32
+
+    def sweep():
+        ud = np.zeros_like(u)
+        D = od.JST_sensor(op, u)
+        for dim in (1, 2):
+            Cf = od.at_faces(op, np.ascontiguousarray(C[:, dim - 1]), dim)
+            gu = od.cell_gradient(op, u, dim)
+            uL, uR = od.MUSCL(op, u, gu, dim, D=D, high_order=True)
+            ud -= od.green_gauss(op, (uL + uR) * Cf / f32(2) + np.abs(Cf) * (uL - uR) / f32(2), dim)
+        return ud
+    sweep()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        sweep()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return u.shape[0] * n / dt / 1e6, n, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="rae2822_0.87M", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--general", action="store_true", help="force the face-list kernels (no block fast path)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ibamd
+    from ibamd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    msh = build_mesh(args.workload)
+    ncells = len(msh)
+    mps = -(-ncells // world)
+    mps = -(-mps // 64) * 64  # block-aligned partitions
+    dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=False, only=[rank + 1])
+    part = dom.partitions[rank + 1]
+    n_image = int(part.image.size)
+    u_h, C_h = synthetic_fields(part.centers)
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    u, C = ibamd.hip(u_h), ibamd.hip(C_h)
+    ud = torch.zeros(dpart.nc, dtype=torch.float32, device=u.device)
+    flags = ibamd.IBH_FORCE_GENERAL if args.general else 0
+
+    hx = None
+    if world > 1:
+        from ibamd.halo import HaloExchange, HaloPlan
+        hx = HaloExchange(HaloPlan(dom, rank + 1), u.device)
+
+    def step():
+        if hx is not None:
+            hx.exchange(u)
+        ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=u.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([n_image], dtype=torch.int64, device=u.device)
+        dist.all_reduce(tot)
+        total_cells = int(tot.item())
+    else:
+        total_cells = n_image
+    ms_per_step = dt / args.steps * 1e3
+    value = total_cells * args.steps / dt / 1e6
+
+    # --- roofline of the dominant kernel (pass B: MUSCL + flux + Green-Gauss), HIP events on the launch stream
+    def time_pass(f, reps):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)  # valid workspace
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags | f)
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / reps * 1e-3
+    reps = max(20, min(args.steps, 200))
+    tB = time_pass(ibamd.IBH_PASS_B_ONLY, reps)
+    tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
+    cells_launch = dpart.nc
+    achieved = B_ALG_2D * cells_launch / tB / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "k_passB_adv<2>", "kernel_us": round(tB * 1e6, 3), "passA_us": round(tA * 1e6, 3),
+                "alg_bytes_per_cell": B_ALG_2D, "cells_per_launch": cells_launch,
+                "sweep_frac": round(B_ALG_2D * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    out = {
+        "metric": "Mcells*iters/s residual sweep (advection-JST-MUSCL), 2D RAE2822",
+        "value": round(value, 2), "unit": "Mcells*iters/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: 2D RAE2822 block quadtree, {ncells} cells, "
+                               f"{msh.nblocks} 8x8 blocks, {world} partition(s), skirt depth 2, "
+                               f"R1 advection-JST-MUSCL residual, fields resident in HBM",
+                   "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
+                   "path": "face-list" if args.general else "block-fast-path",
+                   "block_analysis": dpart.info},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        v, n, secs = cpu_baseline(part, u_h, C_h)
+        out["cpu_baseline"] = {"value": round(v, 3), "unit": "Mcells*iters/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} sweeps of the same {u_h.shape[0]}-cell partition in {secs:.1f} s, "
+                                         "numpy oracle (array-at-a-time restatement of the Julia closure), "
+                                         f"host has {os.cpu_count()} cores"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

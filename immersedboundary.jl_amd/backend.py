@@ -29,6 +29,8 @@ from .domain import Boundary, Partition
 
 IBH_FORCE_GENERAL = 1
 IBH_IMAGE_ONLY = 2
+IBH_PASS_A_ONLY = 4
+IBH_PASS_B_ONLY = 8
 
 _initialised = {}
 

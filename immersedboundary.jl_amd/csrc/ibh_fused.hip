@@ -499,17 +499,17 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     dim3 blk(256);
     dim3 gA(nwg_fast + (nA + 255) / 256), gB(nwgB_fast + (nB + 255) / 256);
     if (p->nd == 2) {
-        if (gA.x)
+        if (gA.x && !(flags & IBH_PASS_B_ONLY))
             hipLaunchKernelGGL((k_passA<2, 1>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2, p->nblk,
                                nwg_fast, cellsA, nA);
-        if (gB.x)
+        if (gB.x && !(flags & IBH_PASS_A_ONLY))
             hipLaunchKernelGGL((k_passB_adv<2>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2, p->nblk,
                                nwgB_fast, cellsB, nB);
     } else {
-        if (gA.x)
+        if (gA.x && !(flags & IBH_PASS_B_ONLY))
             hipLaunchKernelGGL((k_passA<3, 1>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2, p->nblk, 0,
                                cellsA, nA);
-        if (gB.x)
+        if (gB.x && !(flags & IBH_PASS_A_ONLY))
             hipLaunchKernelGGL((k_passB_adv<3>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2, p->nblk, 0,
                                cellsB, nB);
     }

@@ -246,8 +246,8 @@ def build_faces(msh, centers, widths):
 # ---------------------------------------------------------------------------
 # partitions (ImmersedBoundary.jl:594-703)
 # ---------------------------------------------------------------------------
-def _build_partition(ipart, image, ncells, fd, fo, fn, centers, widths, skirt_depth, block_size):
-    nd = centers.shape[0]
+def partition_domain_mask(image, ncells, fo, fn, skirt_depth):
+    """Skirt growth (ImmersedBoundary.jl:609-621): image cells + `skirt_depth` rings of face neighbours."""
     mask = np.zeros(ncells + 1, dtype=bool)  # slot ncells = "no cell"
     mask[image] = True
     fo_ = np.where(fo < 0, ncells, fo)
@@ -257,6 +257,12 @@ def _build_partition(ipart, image, ncells, fd, fo, fn, centers, widths, skirt_de
         mask[fo_[touch]] = True
         mask[fn_[touch]] = True
         mask[ncells] = False
+    return mask, fo_, fn_
+
+
+def _build_partition(ipart, image, ncells, fd, fo, fn, centers, widths, skirt_depth, block_size):
+    nd = centers.shape[0]
+    mask, fo_, fn_ = partition_domain_mask(image, ncells, fo, fn, skirt_depth)
     domain = np.nonzero(mask[:ncells])[0].astype(np.int32)
     g2l = np.full(ncells + 1, -1, dtype=np.int32)
     g2l[domain] = np.arange(domain.size, dtype=np.int32)
@@ -463,17 +469,27 @@ class Domain:
     """
 
     def __init__(self, msh, max_partition_size=100_000, partition_skirt_depth=2, ghost_layer_ratio=f32(1.5),
-                 hypercube_families=(), verbose=False, boundaries=True):
+                 hypercube_families=(), verbose=False, boundaries=True, only=None):
+        """``only``: iterable of partition ids to build fully (one-partition-per-GPU runs build their own
+        partition only); ``self.domains[id]`` (global cell ids of image + skirt) is kept for every partition."""
         nd = msh.ndims
         ncells = len(msh)
         centers, widths = get_cells(msh)
         fd, fo, fn = build_faces(msh, centers, widths)
         self.faces = (fd, fo, fn)
         self.partitions = {}
+        self.domains = {}
+        self.images = {}
         for ipart, start in enumerate(range(0, ncells, max_partition_size)):
             image = np.arange(start, min(ncells, start + max_partition_size), dtype=np.int32)
+            self.images[ipart + 1] = (start, int(image[-1]) + 1)
+            if only is not None and (ipart + 1) not in only:
+                mask, _, _ = partition_domain_mask(image, ncells, fo, fn, partition_skirt_depth)
+                self.domains[ipart + 1] = np.nonzero(mask[:ncells])[0].astype(np.int32)
+                continue
             self.partitions[ipart + 1] = _build_partition(
                 ipart + 1, image, ncells, fd, fo, fn, centers, widths, partition_skirt_depth, msh.block_size)
+            self.domains[ipart + 1] = self.partitions[ipart + 1].domain
         self.boundaries = {}
         if boundaries:
             cT = np.ascontiguousarray(centers.T)
@@ -497,7 +513,7 @@ class Domain:
 
     @property
     def ndims(self):
-        return self.partitions[1].ndims
+        return self.mesh.ndims
 
     def __len__(self):
         return self.ncells

@@ -151,10 +151,13 @@ int ibh_copy_rows(const int32_t* dst_rows, const int32_t* src_rows, int32_t n,
  *     PL,PR = MUSCL(P,gP,dim; D, high_order=true); F = inviscid_fluxes(fluid,PL,PR,dim)
  *     (cfd.jl:459-508); R -= green_gauss(F,dim), R starting from 0;  P = [p T u v (w)].
  * flags: bit0 = force the general face-list kernels (no block fast path);
- *        bit1 = image cells only (skirt rows of the output are left untouched).
+ *        bit1 = image cells only (skirt rows of the output are left untouched);
+ *        bit2 / bit3 = run only pass A / only pass B of the two-kernel sweep.
  */
 #define IBH_FORCE_GENERAL 1
 #define IBH_IMAGE_ONLY 2
+#define IBH_PASS_A_ONLY 4 /* launch only the gradient+sensor kernel (profiling / overlap staging) */
+#define IBH_PASS_B_ONLY 8 /* launch only the flux kernel; the workspace must hold a current pass A */
 int ibh_residual_advection(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags);
 int ibh_residual_euler_hll(ibh_part*, const float* P, int64_t ldp, float* R, int64_t ldr,
                            const ibh_fluid* fluid, int flags);
