@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--workload", default="rae2822_0.87M", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general", action="store_true", help="force the face-list kernels (no block fast path)")
+    ap.add_argument("--exact", action="store_true", help="block path with the literal IEEE arithmetic")
+    ap.add_argument("--graph-batch", type=int, default=20,
+                    help="sweeps captured per HIP graph (launch-bound loop; 0 = eager launches)")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +130,7 @@ def main():
     dpart = ibamd.to_backend(part, ibamd.hip)
     u, C = ibamd.hip(u_h), ibamd.hip(C_h)
     ud = torch.zeros(dpart.nc, dtype=torch.float32, device=u.device)
-    flags = ibamd.IBH_FORCE_GENERAL if args.general else 0
+    flags = (ibamd.IBH_FORCE_GENERAL if args.general else 0) | (ibamd.IBH_EXACT if args.exact else 0)
 
     hx = None
     if world > 1:
@@ -144,12 +147,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # The sweep is ~10 us of GPU work: a Python/ctypes launch per step would be host-bound, so on one GPU
+    # the step loop is captured into HIP graphs of `graph_batch` sweeps each (every sweep still runs in full).
+    batch = args.graph_batch if (world == 1 and args.graph_batch > 0) else 0
+    graph = None
+    side = torch.cuda.Stream()
+    if batch:
+        batch = min(batch, args.steps)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(batch):
+                    step()
+        torch.cuda.synchronize()
+
+    def run(nsteps):
+        if graph is None:
+            for _ in range(nsteps):
+                step()
+            return
+        with torch.cuda.stream(side):
+            for _ in range(nsteps // batch):
+                graph.replay()
+            for _ in range(nsteps % batch):
+                step()
+
+    run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -166,16 +195,24 @@ def main():
 
     # --- roofline of the dominant kernel (pass B: MUSCL + flux + Green-Gauss), HIP events on the launch stream
     def time_pass(f, reps):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)  # valid workspace
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(reps):
-            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags | f)
-        ev1.record()
-        torch.cuda.synchronize()
-        return ev0.elapsed_time(ev1) / reps * 1e-3
-    reps = max(20, min(args.steps, 200))
+        # `reps` launches of one kernel captured in a graph, timed with events on the launch stream
+        with torch.cuda.stream(side):
+            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)  # valid workspace
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps):
+                    ibamd.residual_advection(dpart, u, C, out=ud, flags=flags | f)
+            g.replay()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(side)
+            for _ in range(5):
+                g.replay()
+            ev1.record(side)
+            torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / (5 * reps) * 1e-3
+    reps = 50
     tB = time_pass(ibamd.IBH_PASS_B_ONLY, reps)
     tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
     cells_launch = dpart.nc
@@ -195,7 +232,8 @@ def main():
                                f"{msh.nblocks} 8x8 blocks, {world} partition(s), skirt depth 2, "
                                f"R1 advection-JST-MUSCL residual, fields resident in HBM",
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
-                   "path": "face-list" if args.general else "block-fast-path",
+                   "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else "block-fast-path"),
+                   "launch": f"hip-graph x{batch}" if batch else "eager",
                    "block_analysis": dpart.info},
         "roofline": roofline,
     }

@@ -31,6 +31,7 @@ IBH_FORCE_GENERAL = 1
 IBH_IMAGE_ONLY = 2
 IBH_PASS_A_ONLY = 4
 IBH_PASS_B_ONLY = 8
+IBH_EXACT = 16
 
 _initialised = {}
 

@@ -194,7 +194,24 @@ __device__ __forceinline__ void passB_euler_cell(const PartView& p, const float*
 // block fast path, 2-D, 8x8 blocks.  LDS per wave and per field: tile[64] + halo[4][8][2].
 // halo slot (s, t, k): side s, boundary cell t along the side, k-th face (k = 1 only on FINE sides)
 // ------------------------------------------------------------------------------------------
-#define WPB 4  // waves (= blocks) per 256-thread workgroup
+#define WPB 4  // waves per 256-thread workgroup
+
+// XCD-aware workgroup remap (cdna_hip_programming.md T1): workgroups are dealt round-robin over the
+// 8 XCDs, each with its own non-coherent L2.  Give every XCD one CONTIGUOUS chunk of the block list
+// (blocks are in depth-first/Morton order, so a chunk is a compact patch of the mesh): halo lines of
+// neighbouring blocks are then served by the same L2 instead of being fetched once per XCD.
+// Bijective for any nwg; placement only affects speed.
+__device__ __forceinline__ int32_t xcd_remap(int32_t wg, int32_t nwg) {
+#ifdef IBH_NO_XCD_REMAP
+    return wg;
+#else
+    const int32_t q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+#endif
+}
+#ifndef IBH_BPW
+#define IBH_BPW 1  // blocks per wave in the tuned block path (2-4 measured: no gain, see profiles/r1_v1)
+#endif
 
 // Local id of the k-th neighbour cell across side s for boundary cell t, or -1 (mirror/general/none).
 __device__ __forceinline__ int32_t halo_cell(const BlockDesc2& b, int s, int t, int k) {
@@ -399,20 +416,35 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
     if (!general) ud[c] = r;
 }
 
+}  // namespace
+
+#include "ibh_block2d.h"
+
+namespace {
+
 // ------------------------------------------------------------------------------------------
 // kernels: grid = [fast-path workgroups | face-list workgroups]
+// EXACT = literal IEEE arithmetic in the block path (bit-comparable with the face-list path);
+// otherwise the tuned block path of ibh_block2d.h.
 // ------------------------------------------------------------------------------------------
-template <int ND, int NV>
+template <int ND, int NV, bool EXACT>
 __global__ __launch_bounds__(256) void k_passA(PartView p, const float* __restrict__ u, int64_t ldu,
                                                float* __restrict__ G, const BlockDesc2* __restrict__ blocks,
                                                int32_t nblk, int32_t nwg_fast, const int32_t* __restrict__ cells,
                                                int32_t ncells) {
-    __shared__ float lds[WPB * NV * 128];
+    constexpr int BPW = EXACT ? 1 : IBH_BPW;
+    __shared__ float lds[WPB * BPW * NV * 128];
     if ((int32_t)blockIdx.x < nwg_fast) {
         if constexpr (ND == 2) {
             int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            int32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-            if (blk < nblk) passA_block2<NV>(blocks, blk, p.spacing, p.nc, u, ldu, G, lds + wave * NV * 128, lane);
+            int32_t blk = __builtin_amdgcn_readfirstlane((xcd_remap(blockIdx.x, nwg_fast) * WPB + wave) * BPW);
+            if (blk < nblk) {
+                if constexpr (EXACT)
+                    passA_block2<NV>(blocks, blk, p.spacing, p.nc, u, ldu, G, lds + wave * NV * 128, lane);
+                else
+                    blk2::passA<NV, BPW>(blocks, blk, nblk, (uint32_t)p.nc, u, (uint32_t)ldu, G,
+                                         lds + wave * BPW * NV * 128, lane);
+            }
         }
         return;
     }
@@ -422,18 +454,26 @@ __global__ __launch_bounds__(256) void k_passA(PartView p, const float* __restri
     passA_cell<ND, NV>(p, u, ldu, G, c);
 }
 
-template <int ND>
+template <int ND, bool EXACT>
 __global__ __launch_bounds__(256) void k_passB_adv(PartView p, const float* __restrict__ u, const float* __restrict__ C,
                                                    int64_t ldc, const float* __restrict__ G, float* __restrict__ ud,
                                                    const BlockDesc2* __restrict__ blocks, int32_t nblk,
                                                    int32_t nwg_fast, const int32_t* __restrict__ cells,
                                                    int32_t ncells) {
-    __shared__ float lds[WPB * 6 * 128];
+    constexpr int BPW = EXACT ? 1 : IBH_BPW;
+    constexpr int LDSW = EXACT ? 6 * 128 : BPW * BLK2_PASSB_LDS;  // floats per wave
+    __shared__ float lds[WPB * LDSW];
     if ((int32_t)blockIdx.x < nwg_fast) {
         if constexpr (ND == 2) {
             int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            int32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-            if (blk < nblk) passB_adv_block2(blocks, blk, p.nc, u, C, ldc, G, ud, lds + wave * 6 * 128, lane);
+            int32_t blk = __builtin_amdgcn_readfirstlane((xcd_remap(blockIdx.x, nwg_fast) * WPB + wave) * BPW);
+            if (blk < nblk) {
+                if constexpr (EXACT)
+                    passB_adv_block2(blocks, blk, p.nc, u, C, ldc, G, ud, lds + wave * LDSW, lane);
+                else
+                    blk2::passB_adv<BPW>(blocks, blk, nblk, (uint32_t)p.nc, u, C, (uint32_t)ldc, G, ud,
+                                         lds + wave * LDSW, lane);
+            }
         }
         return;
     }
@@ -483,7 +523,8 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     int rc = ensure_G(p, (size_t)(p->nd + 1) * p->nc);
     if (rc) return rc;
     const bool fast = p->bs == 8 && p->nd == 2 && p->nblk > 0 && !(flags & IBH_FORCE_GENERAL);
-    const int32_t nwg_fast = fast ? (p->nblk + WPB - 1) / WPB : 0;
+    const int bpwg = WPB * ((flags & IBH_EXACT) ? 1 : IBH_BPW);  // blocks per workgroup
+    const int32_t nwg_fast = fast ? (p->nblk + bpwg - 1) / bpwg : 0;
     // pass A always covers every cell of the partition (skirt cells feed the faces of image cells)
     const int32_t* cellsA = fast ? p->irr_cells : nullptr;
     const int32_t nA = fast ? p->n_irr : p->nc;
@@ -498,20 +539,29 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     PartView v = view(p);
     dim3 blk(256);
     dim3 gA(nwg_fast + (nA + 255) / 256), gB(nwgB_fast + (nB + 255) / 256);
-    if (p->nd == 2) {
-        if (gA.x && !(flags & IBH_PASS_B_ONLY))
-            hipLaunchKernelGGL((k_passA<2, 1>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2, p->nblk,
-                               nwg_fast, cellsA, nA);
-        if (gB.x && !(flags & IBH_PASS_A_ONLY))
-            hipLaunchKernelGGL((k_passB_adv<2>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2, p->nblk,
-                               nwgB_fast, cellsB, nB);
+    const bool exact = (flags & IBH_EXACT) != 0;
+    const bool doA = gA.x && !(flags & IBH_PASS_B_ONLY), doB = gB.x && !(flags & IBH_PASS_A_ONLY);
+    if (p->nd == 2 && exact) {
+        if (doA)
+            hipLaunchKernelGGL((k_passA<2, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,
+                               p->nblk, nwg_fast, cellsA, nA);
+        if (doB)
+            hipLaunchKernelGGL((k_passB_adv<2, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
+                               p->nblk, nwgB_fast, cellsB, nB);
+    } else if (p->nd == 2) {
+        if (doA)
+            hipLaunchKernelGGL((k_passA<2, 1, false>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,
+                               p->nblk, nwg_fast, cellsA, nA);
+        if (doB)
+            hipLaunchKernelGGL((k_passB_adv<2, false>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
+                               p->nblk, nwgB_fast, cellsB, nB);
     } else {
-        if (gA.x && !(flags & IBH_PASS_B_ONLY))
-            hipLaunchKernelGGL((k_passA<3, 1>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2, p->nblk, 0,
-                               cellsA, nA);
-        if (gB.x && !(flags & IBH_PASS_A_ONLY))
-            hipLaunchKernelGGL((k_passB_adv<3>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2, p->nblk, 0,
-                               cellsB, nB);
+        if (doA)
+            hipLaunchKernelGGL((k_passA<3, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,
+                               p->nblk, 0, cellsA, nA);
+        if (doB)
+            hipLaunchKernelGGL((k_passB_adv<3, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
+                               p->nblk, 0, cellsB, nB);
     }
     IBH_LAUNCH_CHECK();
     return 0;
@@ -534,13 +584,13 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     }
     dim3 gA((p->nc + 255) / 256), gB((nB + 255) / 256);
     if (p->nd == 2) {
-        hipLaunchKernelGGL((k_passA<2, 4>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, (const BlockDesc2*)nullptr, 0, 0,
+        hipLaunchKernelGGL((k_passA<2, 4, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, (const BlockDesc2*)nullptr, 0, 0,
                            (const int32_t*)nullptr, p->nc);
         if (gB.x)
             hipLaunchKernelGGL((k_passB_euler<2>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
                                fluid->gamma, cellsB, nB);
     } else {
-        hipLaunchKernelGGL((k_passA<3, 5>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, (const BlockDesc2*)nullptr, 0, 0,
+        hipLaunchKernelGGL((k_passA<3, 5, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, (const BlockDesc2*)nullptr, 0, 0,
                            (const int32_t*)nullptr, p->nc);
         if (gB.x)
             hipLaunchKernelGGL((k_passB_euler<3>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,

@@ -158,6 +158,7 @@ int ibh_copy_rows(const int32_t* dst_rows, const int32_t* src_rows, int32_t n,
 #define IBH_IMAGE_ONLY 2
 #define IBH_PASS_A_ONLY 4 /* launch only the gradient+sensor kernel (profiling / overlap staging) */
 #define IBH_PASS_B_ONLY 8 /* launch only the flux kernel; the workspace must hold a current pass A */
+#define IBH_EXACT 16      /* block fast path with the literal IEEE arithmetic (bit-comparable with the face-list path) */
 int ibh_residual_advection(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags);
 int ibh_residual_euler_hll(ibh_part*, const float* P, int64_t ldp, float* R, int64_t ldr,
                            const ibh_fluid* fluid, int flags);

@@ -46,7 +46,7 @@ def _parts(domains):
 
 
 @pytest.mark.parametrize("kind", ["smooth", "step"])
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 16])  # tuned block path, face lists, literal block path
 def test_advection_residual(adv_domains, kind, flags):
     for dpart, opart in _parts(adv_domains):
         u = seeded_field(opart.centers, kind=kind)
@@ -65,10 +65,11 @@ def test_advection_residual_rae(rae_domains):
         exp = oracle_advection_residual(opart, u, C)
         fast = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C)))
         gen = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), flags=1))
+        lit = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), flags=16))
         assert rel_inf(gen, exp) <= TOL
         assert rel_inf(fast, exp) <= TOL
-        # the two kernel bodies share their per-face arithmetic
-        assert rel_inf(fast, gen) <= 1e-6
+        # the literal block path and the face-list path share their per-face arithmetic: same bits
+        assert np.array_equal(lit, gen)
         assert dpart.info["full_blocks"] > 0
 
 
