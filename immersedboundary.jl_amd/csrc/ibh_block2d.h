@@ -107,7 +107,42 @@ __device__ __forceinline__ void nbv(const float* tile, const float* halo, int la
 // more memory requests in flight and the grid fits in a single residency round.
 // ------------------------------------------------------------------------------------------
 
-// pass A: gradients of NV variables along x and y + JST sensor of variable 0
+// Gradient along x and y and JST sensor of ONE staged scalar field at this lane's cell
+// (cell_gradient :965 + JST_sensor :1077 in weight form).
+__device__ __forceinline__ void cell_G(const float* tile, const float* halo, int lane, const Lane& L,
+                                       const BlockDesc2& bb, float uc, float& gx, float& gy, float& D) {
+    D = 1e-7f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float rh = __builtin_amdgcn_rcpf(bb.h[d]);
+        const int sL = 2 * d, sR = 2 * d + 1;
+        const int tyL = bb.type[sL], tyR = bb.type[sR];
+        const float qL = L.edge[sL] ? side_q(tyL) : 0.5f;
+        const float qR = L.edge[sR] ? side_q(tyR) : 0.5f;
+        const bool twoL = L.edge[sL] && tyL == SIDE_FINE;
+        const bool twoR = L.edge[sR] && tyR == SIDE_FINE;
+        float l0, l1, r0, r1;
+        nbv(tile, halo, lane, L, sL, l0, l1);
+        nbv(tile, halo, lane, L, sR, r0, r1);
+        const float uLm = twoL ? 0.5f * (l0 + l1) : l0;
+        const float uRm = twoR ? 0.5f * (r0 + r1) : r0;
+        const float fr = uc + qR * (uRm - uc);
+        const float fl = uc + qL * (uLm - uc);
+        const float g = (fr - fl) * rh;
+        if (d == 0) gx = g; else gy = g;
+        const float dr = uRm - uc, dl = uc - uLm;
+        const float ar = twoR ? 0.5f * (fabsf(r0 - uc) + fabsf(r1 - uc)) : fabsf(dr);
+        const float al = twoL ? 0.5f * (fabsf(uc - l0) + fabsf(uc - l1)) : fabsf(dl);
+        const float gg = (dr - dl) * rh;
+        const float ugg = (ar + al) * rh;
+        D = fmaxf(D, (1e-7f + fabsf(gg)) * __builtin_amdgcn_rcpf(1e-7f + ugg));
+    }
+}
+
+// pass A: gradients of NV variables along x and y + JST sensor of variable 0.
+// Only what another cell can ever read is stored: the gradient along d at the two block columns/rows
+// facing dim d, the sensor on the block rim (pass B recomputes the values of its own cells from the
+// staged tile; every cell outside the block that touches this block touches its rim).
 // G layout as in ibh_fused.hip: grad of var v along dim d at G[(d*NV+v)*nc + c], sensor at G[2*NV*nc + c]
 // LDS per wave: BPW * (tile[NV][64] + halo[NV][64])
 template <int NV, int BPW>
@@ -172,7 +207,7 @@ __device__ __forceinline__ void passA(const BlockDesc2* __restrict__ blocks, int
                 // at_faces with weights: face = (1-q)*u_self + q*u_nb
                 const float fr = uc + qR * (uRm - uc);
                 const float fl = uc + qL * (uLm - uc);
-                if (store) stg(G + (size_t)(d * NV + v) * nc, c, (fr - fl) * rh);
+                if (store && (L.edge[sL] || L.edge[sR])) stg(G + (size_t)(d * NV + v) * nc, c, (fr - fl) * rh);
                 if (v == 0) {
                     const float dr = uRm - uc, dl = uc - uLm;
                     const float ar = twoR ? 0.5f * (fabsf(r0 - uc) + fabsf(r1 - uc)) : fabsf(dr);
@@ -183,7 +218,7 @@ __device__ __forceinline__ void passA(const BlockDesc2* __restrict__ blocks, int
                 }
             }
         }
-        if (store) stg(G + (size_t)(2 * NV) * nc, c, D);
+        if (store && (L.edge[0] || L.edge[1] || L.edge[2] || L.edge[3])) stg(G + (size_t)(2 * NV) * nc, c, D);
     }
 }
 
@@ -237,9 +272,7 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
         const int32_t hidx = halo_cell(*b[r], hs, (lane >> 1) & 7, lane & 1);
         const uint32_t c = (uint32_t)b[r]->base + lane;
         sv[r][0] = ldg(u, c);
-        sv[r][1] = ldg(G + (size_t)2 * nc, c);
-        sv[r][2] = ldg(G, c);
-        sv[r][3] = ldg(G + nc, c);
+        sv[r][1] = sv[r][2] = sv[r][3] = 0.0f;  // D, gx, gy of the own cell are recomputed below
         sv[r][4] = ldg(C, c);
         sv[r][5] = ldg(C + ldc, c);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -263,10 +296,22 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
 #pragma unroll
     for (int r = 0; r < BPW; ++r) {
         float* base = lds + r * BLK2_PASSB_LDS;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) base[q * 64 + lane] = sv[r][q];
+        base[lane] = sv[r][0];
+        base[256 + lane] = sv[r][4];
+        base[320 + lane] = sv[r][5];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[384 + q * 64 + lane] = hvv[r][q];
+    }
+    wave_lds_sync();
+    // own-cell gradients + sensor from the staged u tile (same arithmetic as pass A)
+#pragma unroll
+    for (int r = 0; r < BPW; ++r) {
+        float* base = lds + r * BLK2_PASSB_LDS;
+        const Lane L = lane_info(*b[r], lane);
+        cell_G(base, base + 384, lane, L, *b[r], sv[r][0], sv[r][2], sv[r][3], sv[r][1]);
+        base[64 + lane] = sv[r][1];
+        base[128 + lane] = sv[r][2];
+        base[192 + lane] = sv[r][3];
     }
     wave_lds_sync();
 
