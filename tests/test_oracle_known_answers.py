@@ -1,0 +1,178 @@
+"""Pins the oracle (CPU restatement) with every known answer the reference offers for this path.
+
+The reference ships no asserted tests; what it does offer:
+  * the Accumulator docstring example            /root/reference/src/accumulator.jl:26-33
+  * the rae2822 centroid check, analytic (0, 0)   /root/reference/test/rae2822.jl:24-29
+  * analytic invariants of the operators
+"""
+import numpy as np
+import pytest
+
+from oracle import cfd as ocfd
+from oracle import domain as od
+from oracle import nninterp
+from oracle.accumulator import Accumulator
+from oracle.solver import FAS
+
+f32 = np.float32
+
+
+def test_accumulator_docstring_example():
+    acc = Accumulator([[0, 1], [1, 2, 3]], [[-1.0, 2.0], [3.0, 4.0, 5.0]])
+    assert np.array_equal(acc(np.array([1.0, 2.0, 3.0, 4.0])), np.array([3.0, 38.0]))
+
+
+def test_accumulator_nd_and_empty_rows():
+    acc = Accumulator([[0], [], [1, 2]], [[2.0], [], [0.5, 0.5]], first_index=True)
+    v = np.arange(6, dtype=f32).reshape(3, 2)
+    out = acc(v)
+    assert out.shape == (3, 2)
+    assert np.array_equal(out, np.array([[0, 2], [0, 0], [3, 4]], dtype=f32))
+    acc2 = Accumulator([[0, 1]], None)
+    assert acc2(np.array([1.0, 2.0]))[0] == 3.0
+
+
+def test_rae2822_centroid_is_origin(rae_domains):
+    """test/rae2822.jl:24-29: CG = volume_integral(dom, X) / 2500 ~ (0, 0)."""
+    _, do = rae_domains
+    X = np.zeros((len(do), 2), dtype=f32)
+
+    def fill(part, X):
+        X[...] = part.centers
+    do(fill, X)
+    CG = od.volume_integral(do, X) / f32(2500.0)
+    assert np.all(np.abs(CG) < 1e-3)
+    vol = od.volume_integral(do, np.ones(len(do), dtype=f32))
+    assert abs(vol - 2500.0) / 2500.0 < 1e-5
+
+
+def _same_level_interior(part):
+    """cells whose faces are all single, same-level and not mirrored"""
+    ok = np.ones(part.spacing.shape[0], dtype=bool)
+    for dim in range(1, part.ndims + 1):
+        o, n = part.face_owners_neighbors[dim]
+        h = part.spacing[:, dim - 1]
+        bad_face = (h[o] != h[n]) | (o == n)
+        ok[o[bad_face]] = False
+        ok[n[bad_face]] = False
+        for r in (False, True):
+            acc = part.face_accumulators[(dim, r)]
+            for l, (rows, _, _) in acc.stencils.items():
+                if l != 1:
+                    ok[rows] = False
+    return ok
+
+
+def test_operator_invariants(adv_domains):
+    _, do = adv_domains
+    for part in do.partitions.values():
+        x, y = part.centers[:, 0], part.centers[:, 1]
+        const = np.full(x.shape, f32(3.25))
+        for dim in (1, 2):
+            assert np.array_equal(od.cell_gradient(part, const, dim), np.zeros_like(const))
+        lin = (f32(2.0) * x + f32(-3.0) * y).astype(f32)
+        ok = _same_level_interior(part)
+        assert ok.sum() > 100
+        for dim, a in ((1, 2.0), (2, -3.0)):
+            g = od.cell_gradient(part, lin, dim)
+            assert np.allclose(g[ok], a, rtol=2e-4, atol=2e-4)
+            # JST sensor of a linear field on same-level cells = 1e-7 / (1e-7 + 2|a|)
+            nu = od.JST_sensor(part, lin, dim)
+            assert np.allclose(nu[ok], 1e-7 / (1e-7 + 2 * abs(a)), rtol=0, atol=2e-3)
+            # mirror faces give zero face gradient
+            o, n = part.face_owners_neighbors[dim]
+            fg = od.face_gradient(part, lin, dim)
+            assert np.all(fg[o == n] == 0)
+            # MUSCL on a linear field: uL = uR = at_faces(u) on same-level faces between ok cells
+            gu = od.cell_gradient(part, lin, dim)
+            D = od.JST_sensor(part, lin)
+            uL, uR = od.MUSCL(part, lin, gu, dim, D=D, high_order=True)
+            uf = od.at_faces(part, lin, dim)
+            sel = ok[o] & ok[n]
+            assert np.allclose(uL[sel], uf[sel], atol=2e-5) and np.allclose(uR[sel], uf[sel], atol=2e-5)
+
+
+def test_minmod_and_muscl_limiter():
+    a = np.array([1.0, -1.0, 2.0, 0.0], dtype=f32)
+    b = np.array([3.0, 2.0, -5.0, 4.0], dtype=f32)
+    assert np.array_equal(od.minmod(a, b), np.array([1.0, 0.0, 0.0, 0.0], dtype=f32))
+
+
+def test_ls_interpolation_reproduces_linear_fields(adv_domains):
+    """nninterp.jl:31-35: sum(w)=1 and sum(w*dx)=0 by construction."""
+    _, do = adv_domains
+    X = np.zeros((len(do), 2), dtype=f32)
+
+    def fill(part, X):
+        X[...] = part.centers
+    do(fill, X)
+    lin = (f32(1.5) * X[:, 0] - f32(0.5) * X[:, 1] + f32(0.25)).astype(f32)
+    for name, chunks in do.boundaries.items():
+        for b in chunks.values():
+            ia = b.image_interpolator(lin[b.image_domain])
+            images = b.projections + b.normals * b.image_distances[:, None]
+            exact = f32(1.5) * images[:, 0] - f32(0.5) * images[:, 1] + f32(0.25)
+            assert np.allclose(ia, exact, atol=5e-5), name
+
+
+def test_impose_bc_identity_and_dirichlet(adv_domains):
+    _, do = adv_domains
+    u = np.random.default_rng(1).uniform(-1, 1, len(do)).astype(f32)
+    for name in do.boundaries:
+        a = u.copy()
+        captured = {}
+
+        def ident(bdry, ia):
+            captured["ia"] = ia.copy()
+            return ia.copy()
+        od.impose_bc(ident, do, name, a)
+        b = do.boundaries[name][1]
+        assert np.allclose(a[b.ghost_indices], captured["ia"], atol=1e-6)
+        a2 = u.copy()
+        od.impose_bc(lambda bdry, ia: f32(1.0), do, name, a2)
+        eta = b.ghost_distances / b.image_distances
+        assert np.all((eta >= 0) & (eta <= 1.0 + 1e-6))
+        assert np.allclose(a2[b.ghost_indices], eta * captured["ia"] + (1 - eta) * 1.0, atol=1e-6)
+
+
+def test_idw_coarsener_is_child_mean(adv_mesh_coarse):
+    dom = od.Domain(adv_mesh_coarse, hypercube_families=[("outlet", [(1, True), (2, True)])])
+    coarse_doms, prolongators, coarseners = od.multigrid(dom, max_levels=1)
+    assert len(coarse_doms[0]) * 4 == len(dom)
+    u = np.random.default_rng(2).uniform(-1, 1, len(dom)).astype(f32)
+    uc = coarseners[0](u)
+    # block b, coarse cell (I, J) <- fine cells (2I+di, 2J+dj)
+    bs = dom.mesh.block_size
+    fine = u.reshape(-1, bs, bs)  # [block, j, i]
+    mean = fine.reshape(-1, bs // 2, 2, bs // 2, 2).mean(axis=(2, 4)).reshape(-1)
+    assert np.allclose(uc, mean, atol=1e-6)
+    up = prolongators[0](uc)
+    assert up.shape == u.shape
+
+
+def test_hll_flux_consistency():
+    """F(P, P) = physical flux of P; quirk kept: Float64 result (cfd.jl:504-507)."""
+    fl = ocfd.Fluid()
+    P = np.array([[1e5, 288.15, 100.0, 10.0], [9e4, 300.0, -50.0, 5.0]], dtype=f32)
+    for dim in (1, 2):
+        F = ocfd.inviscid_fluxes(fl, P, P, dim)
+        assert F.dtype == np.float64
+        Q = ocfd.primitive2state(fl, P)
+        un = P[:, 1 + dim]
+        phys = Q.astype(np.float64).copy()
+        phys[:, 1] += P[:, 0]
+        phys *= un[:, None]
+        phys[:, 1 + dim] += P[:, 0]
+        assert np.allclose(F, phys, rtol=1e-5)
+    Pb = ocfd.state2primitive(fl, ocfd.primitive2state(fl, P))
+    assert np.allclose(Pb, P, rtol=1e-5)
+
+
+def test_fas_fixed_point_converges():
+    """solver.jl:79-88: Q += clamp(omega,0,1)*r with r = b - A Q converges to A^-1 b."""
+    A = np.array([[2.0, 0.5], [0.5, 1.5]], dtype=f32)
+    b = np.array([1.0, 2.0], dtype=f32)
+    Q = np.zeros(2, dtype=f32)
+    ratio = FAS(lambda l, Q: (b - A @ Q, f32(0.4)), Q, n_iter=200, rtol=f32(1e-6))
+    assert ratio < 1e-4
+    assert np.allclose(A @ Q, b, atol=1e-4)
