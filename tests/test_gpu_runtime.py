@@ -1,0 +1,164 @@
+"""Partition runtime and ghost-cell BC through the GPU backend, against the oracle running the same
+user closures: (dom::Domain)(f, args...) ImmersedBoundary.jl:820-864, impose_bc! :1197-1247, and the
+explicit step of /root/reference/test/advection.jl:30-89 and test/dissipation.jl:52-83."""
+import numpy as np
+import pytest
+import torch
+
+import ibamd
+from conftest import rel_inf, seeded_field
+from oracle import domain as od
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+KW = dict(conv_to_backend=None, conv_from_backend=None)
+
+
+def _gpu_kw():
+    return dict(conv_to_backend=ibamd.hip, conv_from_backend=ibamd.to_host)
+
+
+def test_domain_call_requires_both_converters(adv_domains):
+    dp, _ = adv_domains
+    u = np.zeros(len(dp), dtype=f32)
+    with pytest.raises(AssertionError):
+        dp(lambda part, u: None, u, conv_to_backend=ibamd.hip)
+    with pytest.raises(TypeError):
+        dp(lambda part, u: None, u)  # no CPU path
+
+
+def test_advection_march_matches_oracle(adv_domains):
+    """Three explicit steps of test/advection.jl (operator-granularity closure + BCs), 3 partitions."""
+    dp, do = adv_domains
+    n = len(dp)
+    X = dp.global_centers()
+    u0 = seeded_field(X, kind="step")
+    C = np.ones((n, 2), dtype=f32)
+
+    # ---- oracle
+    def o_dt(part):
+        return f32(0.5) / np.max(np.maximum(
+            od.unsigned_green_gauss(part, od.at_faces(part, np.ones(part.spacing.shape[0], f32), 1), 1),
+            od.unsigned_green_gauss(part, od.at_faces(part, np.ones(part.spacing.shape[0], f32), 2), 2)))
+
+    def o_closure(part, u, ud, Cl):
+        D = od.JST_sensor(part, u)
+        for dim in (1, 2):
+            Cf = od.at_faces(part, np.ascontiguousarray(Cl[:, dim - 1]), dim)
+            gu = od.cell_gradient(part, u, dim)
+            uL, uR = od.MUSCL(part, u, gu, dim, D=D, high_order=True)
+            ud -= od.green_gauss(part, (uL + uR) * Cf / f32(2) + np.abs(Cf) * (uL - uR) / f32(2), dim)
+
+    def o_bcs(u):
+        od.impose_bc(lambda b, ui: f32(1.0), do, "upper", u)
+        od.impose_bc(lambda b, ui: f32(0.0), do, "lower", u)
+        od.impose_bc(lambda b, ui: ui.copy(), do, "outlet", u)
+
+    # ---- GPU backend, same closures written against ibamd
+    def g_dt(part):
+        one = torch.ones(part.nc, dtype=torch.float32, device=part.spacing.device)
+        a = ibamd.unsigned_green_gauss(part, ibamd.at_faces(part, one, 1), 1)
+        b = ibamd.unsigned_green_gauss(part, ibamd.at_faces(part, one, 2), 2)
+        return f32(0.5) / float(torch.maximum(a, b).max())
+
+    def g_closure(part, u, ud, Cl):
+        D = ibamd.JST_sensor(part, u)
+        for dim in (1, 2):
+            Cf = ibamd.at_faces(part, Cl[:, dim - 1].contiguous(), dim)
+            gu = ibamd.cell_gradient(part, u, dim)
+            uL, uR = ibamd.MUSCL(part, u, gu, dim, D=D, high_order=True)
+            ud -= ibamd.green_gauss(part, (uL + uR) * Cf / 2 + torch.abs(Cf) * (uL - uR) / 2, dim)
+
+    def g_bcs(u):
+        ibamd.impose_bc(lambda b, ui: 1.0, dp, "upper", u, **_gpu_kw())
+        ibamd.impose_bc(lambda b, ui: 0.0, dp, "lower", u, **_gpu_kw())
+        ibamd.impose_bc(lambda b, ui: ui.clone(), dp, "outlet", u, **_gpu_kw())
+
+    dt_o = min(do(o_dt)) * f32(0.75)
+    dt_g = min(dp(g_dt, **_gpu_kw())) * f32(0.75)
+    assert abs(dt_o - dt_g) <= 1e-6 * dt_o
+    uo, ug = u0.copy(), u0.copy()
+    for _ in range(3):
+        udo, udg = np.zeros(n, f32), np.zeros(n, f32)
+        do(o_closure, uo, udo, C)
+        dp(g_closure, ug, udg, C, **_gpu_kw())
+        assert rel_inf(udg, udo) <= 1e-5
+        uo += udo * dt_o
+        ug += udg * dt_o
+        o_bcs(uo)
+        g_bcs(ug)
+        assert rel_inf(ug, uo) <= 1e-5
+
+
+def test_dissipation_closure_nd_field(adv_domains):
+    """test/dissipation.jl:69-77: 2-component field, Laplacian via green_gauss(face_gradient)."""
+    dp, do = adv_domains
+    n = len(dp)
+    uv = seeded_field(dp.global_centers(), nv=2)
+
+    def o_closure(part, uv, uvd):
+        for dim in (1, 2):
+            uvd += od.green_gauss(part, od.face_gradient(part, uv, dim), dim)
+
+    def g_closure(part, uv, uvd):
+        for dim in (1, 2):
+            uvd += ibamd.green_gauss(part, ibamd.face_gradient(part, uv, dim), dim)
+
+    a, b = np.zeros((n, 2), f32), np.zeros((n, 2), f32)
+    do(o_closure, uv.copy(), a)
+    dp(g_closure, uv.copy(), b, **_gpu_kw())
+    assert rel_inf(b, a) <= 1e-5
+
+    # BC closures returning arrays (dissipation.jl:30-50) on a device-resident global array
+    uvo = uv.copy()
+    uvg = ibamd.hip(uv)
+
+    def o_bc(bdry, ia):
+        r = np.empty_like(ia)
+        r[:] = np.array([1.0, 0.0], dtype=f32)
+        return r
+
+    def g_bc(bdry, ia):
+        r = torch.empty_like(ia)
+        r[:] = torch.tensor([1.0, 0.0], device=ia.device)
+        return r
+    od.impose_bc(o_bc, do, "upper", uvo)
+    ibamd.impose_bc(g_bc, dp, "upper", uvg)
+    od.impose_bc(lambda bd, ia: ia.copy(), do, "outlet", uvo)
+    ibamd.impose_bc(lambda bd, ia: ia.clone(), dp, "outlet", uvg)
+    assert rel_inf(ibamd.to_host(uvg), uvo) <= 1e-5
+
+
+def test_fused_bc_modes(adv_domains):
+    """ibh_bc_apply: fused interp+blend for the Dirichlet-constant and copy closures."""
+    import ctypes as C
+    from ibamd import backend as B
+    dp, do = adv_domains
+    u = seeded_field(dp.global_centers())
+    for name, mode, const in (("upper", 0, 1.0), ("outlet", 1, 0.0)):
+        uo = u.copy()
+        od.impose_bc((lambda b, ia: f32(const)) if mode == 0 else (lambda b, ia: ia.copy()), do, name, uo)
+        ug = ibamd.hip(u)
+        for k in dp.boundaries[name]:
+            bd = ibamd.to_backend(dp.boundaries[name][k])
+            c = np.array([const], dtype=f32)
+            B._stream()
+            B.call("ibh_bc_apply", bd.handle, B._ptr(ug), 1, ug.shape[0], mode, B._hptr(c))
+        assert rel_inf(ibamd.to_host(ug), uo) <= 1e-6
+
+
+def test_multigrid_transfer_operators(adv_mesh_coarse):
+    """Coarsener / prolongator application = Accumulator SpMV (ImmersedBoundary.jl:1391-1392)."""
+    from oracle import nninterp
+    dom = ibamd.Domain(adv_mesh_coarse, hypercube_families=[("outlet", [(1, True), (2, True)])])
+    coarse_doms, prolongators, coarseners = ibamd.multigrid(dom, max_levels=2)
+    u = seeded_field(dom.global_centers(), nv=3)
+    uc = ibamd.to_backend(coarseners[0])(ibamd.hip(u))
+    bs = dom.mesh.block_size
+    mean = u.reshape(-1, bs // 2, 2, bs // 2, 2, 3).mean(axis=(2, 4)).reshape(-1, 3)
+    assert rel_inf(ibamd.to_host(uc), mean) <= 1e-6
+    up = ibamd.to_backend(prolongators[0])(uc)
+    assert up.shape == (len(dom), 3)
+    # prolongation of a constant is that constant (IDW weights sum to 1)
+    one = torch.ones(len(coarse_doms[0]), dtype=torch.float32, device=uc.device)
+    assert float((ibamd.to_backend(prolongators[0])(one) - 1).abs().max()) <= 1e-6
