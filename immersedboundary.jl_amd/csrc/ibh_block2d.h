@@ -140,9 +140,8 @@ __device__ __forceinline__ void cell_G(const float* tile, const float* halo, int
 }
 
 // pass A: gradients of NV variables along x and y + JST sensor of variable 0.
-// Only what another cell can ever read is stored: the gradient along d at the two block columns/rows
-// facing dim d, the sensor on the block rim (pass B recomputes the values of its own cells from the
-// staged tile; every cell outside the block that touches this block touches its rim).
+// (Measured, profiles/r1_v1: storing only the block rim and recomputing own-cell values in pass B is
+// slower for the scalar residual -- 17.8 vs 15.6 us per sweep -- so everything is stored.)
 // G layout as in ibh_fused.hip: grad of var v along dim d at G[(d*NV+v)*nc + c], sensor at G[2*NV*nc + c]
 // LDS per wave: BPW * (tile[NV][64] + halo[NV][64])
 template <int NV, int BPW>
@@ -207,7 +206,7 @@ __device__ __forceinline__ void passA(const BlockDesc2* __restrict__ blocks, int
                 // at_faces with weights: face = (1-q)*u_self + q*u_nb
                 const float fr = uc + qR * (uRm - uc);
                 const float fl = uc + qL * (uLm - uc);
-                if (store && (L.edge[sL] || L.edge[sR])) stg(G + (size_t)(d * NV + v) * nc, c, (fr - fl) * rh);
+                if (store) stg(G + (size_t)(d * NV + v) * nc, c, (fr - fl) * rh);
                 if (v == 0) {
                     const float dr = uRm - uc, dl = uc - uLm;
                     const float ar = twoR ? 0.5f * (fabsf(r0 - uc) + fabsf(r1 - uc)) : fabsf(dr);
@@ -218,7 +217,7 @@ __device__ __forceinline__ void passA(const BlockDesc2* __restrict__ blocks, int
                 }
             }
         }
-        if (store && (L.edge[0] || L.edge[1] || L.edge[2] || L.edge[3])) stg(G + (size_t)(2 * NV) * nc, c, D);
+        if (store) stg(G + (size_t)(2 * NV) * nc, c, D);
     }
 }
 
@@ -272,7 +271,9 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
         const int32_t hidx = halo_cell(*b[r], hs, (lane >> 1) & 7, lane & 1);
         const uint32_t c = (uint32_t)b[r]->base + lane;
         sv[r][0] = ldg(u, c);
-        sv[r][1] = sv[r][2] = sv[r][3] = 0.0f;  // D, gx, gy of the own cell are recomputed below
+        sv[r][1] = ldg(G + (size_t)2 * nc, c);
+        sv[r][2] = ldg(G, c);
+        sv[r][3] = ldg(G + nc, c);
         sv[r][4] = ldg(C, c);
         sv[r][5] = ldg(C + ldc, c);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -296,22 +297,10 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
 #pragma unroll
     for (int r = 0; r < BPW; ++r) {
         float* base = lds + r * BLK2_PASSB_LDS;
-        base[lane] = sv[r][0];
-        base[256 + lane] = sv[r][4];
-        base[320 + lane] = sv[r][5];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) base[q * 64 + lane] = sv[r][q];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[384 + q * 64 + lane] = hvv[r][q];
-    }
-    wave_lds_sync();
-    // own-cell gradients + sensor from the staged u tile (same arithmetic as pass A)
-#pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        float* base = lds + r * BLK2_PASSB_LDS;
-        const Lane L = lane_info(*b[r], lane);
-        cell_G(base, base + 384, lane, L, *b[r], sv[r][0], sv[r][2], sv[r][3], sv[r][1]);
-        base[64 + lane] = sv[r][1];
-        base[128 + lane] = sv[r][2];
-        base[192 + lane] = sv[r][3];
     }
     wave_lds_sync();
 
@@ -401,6 +390,187 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
         if (L.edge[3] && bb.type[3] == SIDE_FINE) FT = 0.5f * (FT + ex[40 + L.i]);
         const float res = -((FR - FL) * rhx) - ((FT - FB) * rhy);
         if (valid[r] && !L.general) stg(ud, (uint32_t)bb.base + lane, res);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// pass B, Euler: MUSCL(high_order) on P = [p T u v] with the pressure sensor, HLL flux
+// (cfd.jl:459-508, Float32 here -- the reference promotes the last combine to Float64), Green-Gauss.
+// ------------------------------------------------------------------------------------------
+struct Gas {
+    float R, gamma;
+};
+
+__device__ __forceinline__ void euler_side(const float* P, int dn, const Gas& gas, float* Q, float* F, float& un,
+                                           float& a) {
+    const float p = P[0];
+    const float T = fmaxf(P[1], 10.0f);
+    const float k = 0.5f * (P[2] * P[2] + P[3] * P[3]);
+    const float rho = p * __builtin_amdgcn_rcpf(gas.R * T);
+    const float E = rho * (gas.R / (gas.gamma - 1.0f) * T + k);
+    Q[0] = rho;
+    Q[1] = E;
+    Q[2] = rho * P[2];
+    Q[3] = rho * P[3];
+    un = P[2 + dn];
+    a = sqrtf(gas.gamma * gas.R * T);
+    F[0] = Q[0] * un;
+    F[1] = (Q[1] + p) * un;
+    F[2] = Q[2] * un;
+    F[3] = Q[3] * un;
+    F[2 + dn] += p;
+}
+
+// a = left/owner cell, b = right/neighbour; Pa/Pb primitive states, ga/gb their gradients along the face normal
+__device__ __forceinline__ void euler_flux(const float* Pa, const float* Pb, const float* ga, const float* gb, float Da,
+                                           float Db, float dA, float dB, float inv, int dn, const Gas& gas, float* F) {
+    float PL[4], PR[4];
+    const float Df = fmaxf(fmaxf(Da, Db), 1e-7f);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float guf = (Pb[v] - Pa[v]) * inv;
+        const float gu = (2.0f * ga[v] - guf) * dA;
+        const float Du = (2.0f * gb[v] - guf) * dB;
+        const float s = minmod(Du, gu);
+        const float l = Pa[v] + s, r = Pb[v] - s;
+        const float uf = (Pa[v] * dB + Pb[v] * dA) * inv + (ga[v] * dA - gb[v] * dB) * 0.125f;
+        PL[v] = uf + Df * (l - uf);
+        PR[v] = uf + Df * (r - uf);
+    }
+    float QL[4], FL[4], QR[4], FR[4], uL, aL, uR, aR;
+    euler_side(PL, dn, gas, QL, FL, uL, aL);
+    euler_side(PR, dn, gas, QR, FR, uR, aR);
+    const float SR = fminf(uR - aR, 0.0f);
+    const float SL = fmaxf(uL + aL, 0.0f);
+    const float rs = __builtin_amdgcn_rcpf(SL - SR);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) F[v] = (SL * FL[v] - SR * FR[v] + SR * SL * (QR[v] - QL[v])) * rs;
+}
+
+// LDS per wave: tiles P[4], D, gx[4], gy[4] (13 x 64); halos P[4], D, gN[4] (9 x 64); extra flux[4] (4 x 64)
+#define BLK2_EULER_LDS (26 * 64)
+
+__device__ __forceinline__ void passB_euler(const BlockDesc2* __restrict__ blocks, int32_t blk, uint32_t nc,
+                                            const float* __restrict__ P, uint32_t ldp, const float* __restrict__ G,
+                                            float* __restrict__ Rr, uint32_t ldr, Gas gas, float* lds, int lane) {
+    const BlockDesc2& bb = blocks[blk];
+    const Lane L = lane_info(bb, lane);
+    const int hs = lane >> 4;
+    const int32_t hidx = halo_cell(bb, hs, (lane >> 1) & 7, lane & 1);
+    float* tP = lds;              // [4][64]
+    float* tD = lds + 4 * 64;     // [64]
+    float* tG = lds + 5 * 64;     // [2][4][64]
+    float* hP = lds + 13 * 64;    // [4][64]
+    float* hD = lds + 17 * 64;
+    float* hG = lds + 18 * 64;    // [4][64] gradient along the slot's side normal
+    float* ex = lds + 22 * 64;    // [4][64]
+    const uint32_t c = (uint32_t)bb.base + lane;
+    float Pc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        Pc[v] = ldg(P + (size_t)v * ldp, c);
+        tP[v * 64 + lane] = Pc[v];
+    }
+    {
+        const int dn = hs >> 1;
+        const bool ok = hidx >= 0;
+        const uint32_t hi = ok ? (uint32_t)hidx : 0u;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            hP[v * 64 + lane] = ok ? ldg(P + (size_t)v * ldp, hi) : 0.0f;
+            hG[v * 64 + lane] = ok ? ldg(G + (size_t)(dn * 4 + v) * nc, hi) : 0.0f;
+        }
+        hD[lane] = ok ? ldg(G + (size_t)8 * nc, hi) : 0.0f;
+    }
+    wave_lds_sync();
+    // own-cell gradients of the 4 primitives and the pressure sensor
+    float gxc[4], gyc[4], Dc = 1e-7f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float Dv;
+        cell_G(tP + v * 64, hP + v * 64, lane, L, bb, Pc[v], gxc[v], gyc[v], Dv);
+        if (v == 0) Dc = Dv;
+        if (L.general) {  // face-list side: values written by the face-list body of pass A
+            gxc[v] = ldg(G + (size_t)v * nc, c);
+            gyc[v] = ldg(G + (size_t)(4 + v) * nc, c);
+            if (v == 0) Dc = ldg(G + (size_t)8 * nc, c);
+        }
+        tG[v * 64 + lane] = gxc[v];
+        tG[(4 + v) * 64 + lane] = gyc[v];
+    }
+    tD[lane] = Dc;
+    wave_lds_sync();
+
+    const float hx = bb.h[0], hy = bb.h[1];
+    const float rhx = __builtin_amdgcn_rcpf(hx), rhy = __builtin_amdgcn_rcpf(hy);
+    float FR[4], FT[4];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int s = 2 * d + 1;
+        float Pb[4], gb[4], Db, d1;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            nbv(tP + v * 64, hP + v * 64, lane, L, s, Pb[v], d1);
+            nbv(tG + (d * 4 + v) * 64, hG + v * 64, lane, L, s, gb[v], d1);
+        }
+        nbv(tD, hD, lane, L, s, Db, d1);
+        const int ty = bb.type[s];
+        const float rt = L.edge[s] ? side_ratio(ty) : 1.0f;
+        const float q = L.edge[s] ? side_q(ty) : 0.5f;
+        const float h = d ? hy : hx, rh = d ? rhy : rhx;
+        euler_flux(Pc, Pb, d ? gyc : gxc, gb, Dc, Db, 0.5f * h, 0.5f * h * rt, 2.0f * rh * q, d, gas, d ? FT : FR);
+    }
+    {   // extra pass (same role map as the advection kernel)
+        const int g = lane >> 3, t = lane & 7;
+        const int side = (g == 0 || g == 2) ? 0 : (g == 1 || g == 3) ? 2 : (g == 4) ? 1 : 3;
+        const int k = g >= 2 ? 1 : 0;
+        const int ty = bb.type[side & 3];
+        const bool active = g < 2 || (g < 6 && ty == SIDE_FINE);
+        float X[4] = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            const int dn = side >> 1;
+            const int pos = (side == 0) ? 8 * t : (side == 1) ? 7 + 8 * t : (side == 2) ? t : t + 56;
+            const int slot = (side * 8 + t) * 2 + k;
+            float Ps[4], Ph[4], gs[4], gh[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Ps[v] = tP[v * 64 + pos];
+                gs[v] = tG[(dn * 4 + v) * 64 + pos];
+                Ph[v] = hP[v * 64 + slot];
+                gh[v] = hG[v * 64 + slot];
+            }
+            const float Ds = tD[pos], Dh = hD[slot];
+            const float h = dn ? hy : hx, rh = dn ? rhy : rhx;
+            const float rt = side_ratio(ty), q = side_q(ty);
+            const float dS = 0.5f * h, dH = 0.5f * h * rt, inv = 2.0f * rh * q;
+            if ((side & 1) == 0)
+                euler_flux(Ph, Ps, gh, gs, Dh, Ds, dH, dS, inv, dn, gas, X);
+            else
+                euler_flux(Ps, Ph, gs, gh, Ds, Dh, dS, dH, inv, dn, gas, X);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ex[v * 64 + lane] = X[v];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float fr = FR[v], ft = FT[v];
+        float fl = __shfl_up(fr, 1, 64);
+        float fb = __shfl_up(ft, 8, 64);
+        const float* e = ex + v * 64;
+        if (L.edge[0]) {
+            fl = e[L.j];
+            if (bb.type[0] == SIDE_FINE) fl = 0.5f * (fl + e[16 + L.j]);
+        }
+        if (L.edge[2]) {
+            fb = e[8 + L.i];
+            if (bb.type[2] == SIDE_FINE) fb = 0.5f * (fb + e[24 + L.i]);
+        }
+        if (L.edge[1] && bb.type[1] == SIDE_FINE) fr = 0.5f * (fr + e[32 + L.j]);
+        if (L.edge[3] && bb.type[3] == SIDE_FINE) ft = 0.5f * (ft + e[40 + L.i]);
+        const float res = -((fr - fl) * rhx) - ((ft - fb) * rhy);
+        if (!L.general) stg(Rr + (size_t)v * ldr, c, res);
     }
 }
 

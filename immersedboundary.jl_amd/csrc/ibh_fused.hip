@@ -483,6 +483,20 @@ __global__ __launch_bounds__(256) void k_passB_adv(PartView p, const float* __re
     passB_adv_cell<ND>(p, u, C, ldc, G, ud, c);
 }
 
+// Euler pass B: the block body and the face-list body are separate kernels (the Float64 flux combine of
+// the literal face-list body needs ~120 VGPRs and would halve the occupancy of the block body).
+__global__ __launch_bounds__(256) void k_passB_euler_blk(uint32_t nc, const float* __restrict__ P, uint32_t ldp,
+                                                         const float* __restrict__ G, float* __restrict__ R,
+                                                         uint32_t ldr, float Rgas, float gamma,
+                                                         const BlockDesc2* __restrict__ blocks, int32_t nblk,
+                                                         int32_t nwg) {
+    __shared__ float lds[WPB * BLK2_EULER_LDS];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB + wave);
+    if (blk < nblk)
+        blk2::passB_euler(blocks, blk, nc, P, ldp, G, R, ldr, blk2::Gas{Rgas, gamma}, lds + wave * BLK2_EULER_LDS, lane);
+}
+
 template <int ND>
 __global__ __launch_bounds__(256) void k_passB_euler(PartView p, const float* __restrict__ P, int64_t ldp,
                                                      const float* __restrict__ G, float* __restrict__ R, int64_t ldr,
@@ -576,23 +590,37 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     if (rc) return rc;
     PartView v = view(p);
     dim3 blk(256);
-    const int32_t* cellsB = nullptr;
-    int32_t nB = p->nc;
-    if (flags & IBH_IMAGE_ONLY) {
+    // tuned block path: 2-D only and not with IBH_EXACT (the literal arithmetic lives in the face-list body)
+    const bool fast = p->bs == 8 && p->nd == 2 && p->nblk > 0 && !(flags & (IBH_FORCE_GENERAL | IBH_EXACT));
+    const int32_t nwg_fast = fast ? (p->nblk + WPB - 1) / WPB : 0;
+    const int32_t* cellsA = fast ? p->irr_cells : nullptr;
+    const int32_t nA = fast ? p->n_irr : p->nc;
+    const int32_t* cellsB = cellsA;
+    int32_t nB = nA;
+    if ((flags & IBH_IMAGE_ONLY) && !fast) {
         cellsB = p->image_in_domain;
         nB = p->n_image;
     }
-    dim3 gA((p->nc + 255) / 256), gB((nB + 255) / 256);
+    dim3 gA(nwg_fast + (nA + 255) / 256), gB((nB + 255) / 256);
+    const bool doA = gA.x && !(flags & IBH_PASS_B_ONLY), doB = !(flags & IBH_PASS_A_ONLY);
     if (p->nd == 2) {
-        hipLaunchKernelGGL((k_passA<2, 4, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, (const BlockDesc2*)nullptr, 0, 0,
-                           (const int32_t*)nullptr, p->nc);
-        if (gB.x)
+        if (doA && fast)
+            hipLaunchKernelGGL((k_passA<2, 4, false>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->nblk,
+                               nwg_fast, cellsA, nA);
+        else if (doA)
+            hipLaunchKernelGGL((k_passA<2, 4, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->nblk, 0,
+                               cellsA, nA);
+        if (doB && nwg_fast)
+            hipLaunchKernelGGL(k_passB_euler_blk, dim3(nwg_fast), blk, 0, ibh_stream, (uint32_t)p->nc, P, (uint32_t)ldp,
+                               p->G, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks2, p->nblk, nwg_fast);
+        if (doB && gB.x)
             hipLaunchKernelGGL((k_passB_euler<2>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
                                fluid->gamma, cellsB, nB);
     } else {
-        hipLaunchKernelGGL((k_passA<3, 5, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, (const BlockDesc2*)nullptr, 0, 0,
-                           (const int32_t*)nullptr, p->nc);
-        if (gB.x)
+        if (doA)
+            hipLaunchKernelGGL((k_passA<3, 5, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->nblk, 0,
+                               cellsA, nA);
+        if (doB && gB.x)
             hipLaunchKernelGGL((k_passB_euler<3>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
                                fluid->gamma, cellsB, nB);
     }

@@ -83,10 +83,25 @@ def test_block_analysis_classifies_rae_mesh(rae_domains):
     assert tot_blocks >= dp.mesh.nblocks  # every image block is a full block in its own partition
 
 
-def test_euler_residual(adv_domains):
+@pytest.mark.parametrize("flags", [0, 1])  # tuned block path (Float32 HLL combine), literal face-list path
+def test_euler_residual(adv_domains, flags):
     fluid = ocfd.Fluid()
     for dpart, opart in _parts(adv_domains):
         P = euler_field(opart.centers)
         exp = oracle_euler_residual(opart, P, fluid)
-        got = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P)))
+        got = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=flags))
         assert rel_inf(got, exp) <= TOL
+
+
+def test_euler_residual_rae(rae_domains):
+    dp, do = rae_domains
+    fluid = ocfd.Fluid()
+    worst = 0.0
+    for k in dp.partitions:
+        dpart, opart = ibamd.to_backend(dp.partitions[k], ibamd.hip), do.partitions[k]
+        P = euler_field(opart.centers)
+        exp = oracle_euler_residual(opart, P, fluid)
+        for flags in (0, 1):
+            got = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=flags))
+            worst = max(worst, rel_inf(got, exp))
+    assert worst <= TOL
