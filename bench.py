@@ -217,8 +217,19 @@ def main():
     tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
     cells_launch = dpart.nc
     achieved = B_ALG_2D * cells_launch / tB / 1e9
+    # HBM-side traffic of one pass-B launch from the committed PMC passes of this build (separate
+    # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
+    # calibrated against the kernel's known tile loads); null if not profiled.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "current_pmc.json")) as f:
+            pm = json.load(f)
+        if pm.get("workload") == args.workload and not args.general and not args.exact and world == 1:
+            traffic = round((2.0 * pm["passB_fetch_kb"] + pm["passB_write_kb"]) * 1024.0)
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_passB_adv<2>", "kernel_us": round(tB * 1e6, 3), "passA_us": round(tA * 1e6, 3),
                 "alg_bytes_per_cell": B_ALG_2D, "cells_per_launch": cells_launch,
                 "sweep_frac": round(B_ALG_2D * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}

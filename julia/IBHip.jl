@@ -1,0 +1,213 @@
+# IBHip.jl -- the binding a maintainer of ImmersedBoundary.jl would add to run the per-partition
+# residual hot path on MI355X through libibhip.so (C ABI: include/ibhip.h).
+#
+# It plugs into the reference's own hooks and nothing else:
+#   * `conv_to_backend = IBHip.hip`, `conv_from_backend = Array` in `dom(f, args...)` and `impose_bc!`
+#     (/root/reference/src/ImmersedBoundary.jl:823-824, :846-855, :1202-1203);
+#   * `ArrayBackends.to_backend(part, hip)` (src/arraybends.jl:14-77, registered for Partition at
+#     src/ImmersedBoundary.jl:788) -- specialised here to upload ONCE and cache a native handle;
+#   * Julia multiple dispatch on the operators (src/ImmersedBoundary.jl:873-1157): methods for
+#     `HipPartition` + `HipArray` that `ccall` the library.  User closures stay unchanged.
+#
+# No KernelAbstractions, no CUDA.jl/AMDGPU.jl: device memory is owned by the library
+# (ibh_malloc/ibh_free) behind `HipArray`.  There is no Julia runtime in the build container, so this
+# file is written against the reference's sources and the C header but has never been executed; the same
+# ABI is exercised from Python by tests/ (see INTEGRATION.md).
+module IBHip
+
+using ImmersedBoundary
+import ImmersedBoundary: Partition, Boundary, at_owners, at_neighbors, at_faces, green_gauss,
+    unsigned_green_gauss, cell_gradient, face_distance, owner_distance, neighbor_distance, face_gradient, MUSCL
+import ImmersedBoundary.CFD: JST_sensor
+import ImmersedBoundary.ArrayBackends: to_backend
+
+const lib = get(ENV, "IBHIP_LIB", "libibhip")
+
+@inline function check(rc::Cint)
+    rc == 0 || error("libibhip: " * unsafe_string(ccall((:ibh_last_error, lib), Cstring, ())))
+    nothing
+end
+
+init(device::Integer = 0) = check(ccall((:ibh_init, lib), Cint, (Cint,), device))
+
+# ---------------------------------------------------------------------------------------------------
+# device arrays (column-major like Julia's own arrays, so `(ncells, nvars)` maps 1:1 to the ABI's `ld`)
+# ---------------------------------------------------------------------------------------------------
+mutable struct HipArray{T, N} <: AbstractArray{T, N}
+    ptr::Ptr{Cvoid}
+    dims::NTuple{N, Int}
+    function HipArray{T, N}(::UndefInitializer, dims::NTuple{N, Int}) where {T, N}
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ibh_malloc, lib), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, max(prod(dims), 1) * sizeof(T)))
+        a = new{T, N}(p[], dims)
+        finalizer(x -> ccall((:ibh_free, lib), Cint, (Ptr{Cvoid},), x.ptr), a)
+        a
+    end
+end
+HipArray{T}(u::UndefInitializer, dims::Int...) where {T} = HipArray{T, length(dims)}(u, dims)
+Base.size(a::HipArray) = a.dims
+Base.similar(a::HipArray{T}, ::Type{S}, dims::Dims) where {T, S} = HipArray{S, length(dims)}(undef, dims)
+Base.getindex(::HipArray, i...) = error("scalar indexing of a HipArray; copy it back with Array(a)")
+
+"`conv_to_backend`: host array -> device array."
+function hip(a::Array{T, N}) where {T, N}
+    d = HipArray{T, N}(undef, size(a))
+    check(ccall((:ibh_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), d.ptr, a, sizeof(a)))
+    d
+end
+hip(a::AbstractArray) = hip(Array(a))
+hip(a::HipArray) = a
+
+"`conv_from_backend`: device array -> host array."
+function Base.Array(d::HipArray{T, N}) where {T, N}
+    a = Array{T, N}(undef, d.dims)
+    check(ccall((:ibh_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), a, d.ptr, sizeof(a)))
+    a
+end
+
+ld(a::HipArray) = Int64(size(a, 1))
+nv(a::HipArray) = Cint(length(a) ÷ max(size(a, 1), 1))
+
+# ---------------------------------------------------------------------------------------------------
+# Partition on the device: to_backend(part, hip) uploads once (the reference re-uploads per call, :848)
+# ---------------------------------------------------------------------------------------------------
+struct HipPartition{Ti, Tf}
+    handle::Ptr{Cvoid}
+    host::Partition{Ti, Tf}
+    nc::Int
+    nf::Vector{Int}
+    spacing::HipArray{Tf, 2}
+    centers::HipArray{Tf, 2}
+end
+Base.ndims(p::HipPartition) = size(p.centers, 2)
+
+const _cache = IdDict{Any, Any}()
+
+"Bucketed `Accumulator.stencils` (src/accumulator.jl:46-61) -> CSR (offsets, indices), 1-based."
+function csr(acc, n::Int)
+    lens = zeros(Int32, n)
+    for (len, (rows, _, _)) in acc.stencils
+        lens[rows] .= len
+    end
+    off = Int32[1; 1 .+ cumsum(lens)]
+    idx = Vector{Int32}(undef, off[end] - 1)
+    for (len, (rows, st, _)) in acc.stencils
+        for (k, r) in enumerate(rows), j = 1:len
+            idx[off[r] + j - 1] = st[j, k]
+        end
+    end
+    off, idx
+end
+
+function to_backend(part::Partition{Ti, Tf}, ::typeof(hip)) where {Ti, Tf}
+    get!(_cache, part) do
+        nd = ndims(part)
+        nc = size(part.spacing, 1)
+        owners = [Int32.(part.face_owners_neighbors[d][1]) for d = 1:nd]
+        neighs = [Int32.(part.face_owners_neighbors[d][2]) for d = 1:nd]
+        left = [csr(part.face_accumulators[(d, false)], nc) for d = 1:nd]
+        right = [csr(part.face_accumulators[(d, true)], nc) for d = 1:nd]
+        nf = Int32[length(o) for o in owners]
+        ptrs(v) = Ptr{Int32}[pointer(x) for x in v]
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        loff, lidx = first.(left), last.(left)
+        roff, ridx = first.(right), last.(right)
+        domain = Int32.(part.domain)
+        iid = Int32.(part.image_in_domain)
+        GC.@preserve owners neighs loff lidx roff ridx domain iid begin
+            check(ccall((:ibh_partition_create, lib), Cint,
+                (Ptr{Ptr{Cvoid}}, Cint, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Int32},
+                 Ptr{Ptr{Int32}}, Ptr{Ptr{Int32}}, Ptr{Ptr{Int32}}, Ptr{Ptr{Int32}}, Ptr{Ptr{Int32}}, Ptr{Ptr{Int32}},
+                 Int32, Ptr{Int32}, Ptr{Int32}, Cint, Cint),
+                h, nd, nc, Array(part.spacing), Array(part.centers), nf,
+                ptrs(owners), ptrs(neighs), ptrs(loff), ptrs(lidx), ptrs(roff), ptrs(ridx),
+                length(iid), iid, domain, 8 #= mesh.block_size =#, 1 #= Julia indices =#))
+        end
+        hp = HipPartition{Ti, Tf}(h[], part, nc, Int.(nf), hip(Array(part.spacing)), hip(Array(part.centers)))
+        hp
+    end
+end
+
+# ---------------------------------------------------------------------------------------------------
+# operators: same names / arity / return shapes as src/ImmersedBoundary.jl:873-1157
+# ---------------------------------------------------------------------------------------------------
+out_like(u::HipArray{T, N}, n::Int) where {T, N} = HipArray{T, N}(undef, (n, size(u)[2:end]...))
+
+for (jl, c) in ((:at_owners, :ibh_at_owners), (:at_neighbors, :ibh_at_neighbors), (:at_faces, :ibh_at_faces),
+                (:face_gradient, :ibh_face_gradient))
+    @eval function $jl(part::HipPartition, u::HipArray, dim::Int)
+        out = out_like(u, part.nf[dim])
+        check(ccall(($(QuoteNode(c)), lib), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64),
+            part.handle, dim, u.ptr, nv(u), ld(u), out.ptr, ld(out)))
+        out
+    end
+end
+
+function cell_gradient(part::HipPartition, u::HipArray, dim::Int)
+    out = out_like(u, part.nc)
+    check(ccall((:ibh_cell_gradient, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64),
+        part.handle, dim, u.ptr, nv(u), ld(u), out.ptr, ld(out)))
+    out
+end
+cell_gradient(part::HipPartition, u::HipArray) = tuple((cell_gradient(part, u, d) for d = 1:ndims(part))...)
+
+function _gg(part::HipPartition, uf::HipArray, dim::Int, uns::Int)
+    out = out_like(uf, part.nc)
+    check(ccall((:ibh_green_gauss, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Cint),
+        part.handle, dim, uf.ptr, nv(uf), ld(uf), out.ptr, ld(out), uns))
+    out
+end
+green_gauss(part::HipPartition, uf::HipArray, dim::Int) = _gg(part, uf, dim, 0)
+unsigned_green_gauss(part::HipPartition, uf::HipArray, dim::Int) = _gg(part, uf, dim, 1)
+
+for (jl, c) in ((:face_distance, :ibh_face_distance), (:owner_distance, :ibh_owner_distance),
+                (:neighbor_distance, :ibh_neighbor_distance))
+    @eval function $jl(part::HipPartition{Ti, Tf}, dim::Int) where {Ti, Tf}
+        out = HipArray{Tf, 1}(undef, (part.nf[dim],))
+        check(ccall(($(QuoteNode(c)), lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), part.handle, dim, out.ptr))
+        out
+    end
+end
+
+function JST_sensor(part::HipPartition, p::HipArray, dim::Int = 0)
+    out = out_like(p, part.nc)
+    check(ccall((:ibh_jst_sensor, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64),
+        part.handle, dim, p.ptr, nv(p), ld(p), out.ptr, ld(out)))
+    out
+end
+
+function MUSCL(part::HipPartition, u::HipArray, δu::HipArray, dim::Int;
+               D::Union{HipArray, Nothing} = nothing, high_order::Bool = false)
+    uL, uR = out_like(u, part.nf[dim]), out_like(u, part.nf[dim])
+    check(ccall((:ibh_muscl, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+        part.handle, dim, u.ptr, δu.ptr, nv(u), ld(u), isnothing(D) ? C_NULL : D.ptr, high_order, uL.ptr, uR.ptr, ld(uL)))
+    (uL, uR)
+end
+
+# ---------------------------------------------------------------------------------------------------
+# fused residual sweeps (bypass broadcast: one C call = the whole closure of test/advection.jl:67-83)
+# ---------------------------------------------------------------------------------------------------
+"`ud .= -Σ_d green_gauss(upwind MUSCL/JST flux)`: the closure of test/advection.jl:67-83, fused."
+function residual_advection!(ud::HipArray, part::HipPartition, u::HipArray, C::HipArray; flags::Integer = 0)
+    check(ccall((:ibh_residual_advection, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cint),
+        part.handle, u.ptr, C.ptr, ld(C), ud.ptr, flags))
+    ud
+end
+
+struct IbhFluid
+    R::Float32
+    γ::Float32
+end
+
+"`R .= -Σ_d green_gauss(inviscid_fluxes(MUSCL(P)))` with the pressure JST sensor (CFD.inviscid_fluxes, cfd.jl:459)."
+function residual_euler_hll!(R::HipArray, part::HipPartition, P::HipArray, fluid; flags::Integer = 0)
+    f = Ref(IbhFluid(fluid.R, fluid.γ))
+    check(ccall((:ibh_residual_euler_hll, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{IbhFluid}, Cint),
+        part.handle, P.ptr, ld(P), R.ptr, ld(R), f, flags))
+    R
+end
+
+end # module
