@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general", action="store_true", help="force the face-list kernels (no block fast path)")
     ap.add_argument("--exact", action="store_true", help="block path with the literal IEEE arithmetic")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange first, then the whole sweep")
     ap.add_argument("--graph-batch", type=int, default=20,
                     help="sweeps captured per HIP graph (launch-bound loop; 0 = eager launches)")
     args = ap.parse_args()
@@ -115,9 +119,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     msh = build_mesh(args.workload)
     ncells = len(msh)
@@ -133,16 +142,24 @@ def main():
     flags = (ibamd.IBH_FORCE_GENERAL if args.general else 0) | (ibamd.IBH_EXACT if args.exact else 0)
 
     hx = None
+    comm_stream = None
     if world > 1:
-        from ibamd.halo import HaloExchange, HaloPlan
+        from ibamd.halo import HaloExchange, HaloPlan, sweep_overlapped
         hx = HaloExchange(HaloPlan(dom, rank + 1), u.device)
+        overlap = not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
+        comm_stream = torch.cuda.Stream() if overlap else None
 
     def step():
-        if hx is not None:
+        if hx is None:
+            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)
+        elif comm_stream is not None:
+            sweep_overlapped(hx, dpart, u, C, ud, comm_stream, flags=flags)
+        else:
             hx.exchange(u)
-        ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)
+            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -182,10 +199,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=u.device)
+        red_dev = u.device if args.backend == "nccl" else "cpu"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([n_image], dtype=torch.int64, device=u.device)
+        tot = torch.tensor([n_image], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot)
         total_cells = int(tot.item())
     else:
@@ -245,6 +263,10 @@ def main():
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
                    "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else "block-fast-path"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",
+                   "halo": None if hx is None else {"backend": args.backend, "overlap": comm_stream is not None,
+                                                    "send_cells": hx.plan.n_send, "recv_cells": hx.plan.n_recv,
+                                                    "peers": len(hx.plan.peers),
+                                                    "interior_blocks": dpart.info["interior_blocks"]},
                    "block_analysis": dpart.info},
         "roofline": roofline,
     }

@@ -32,6 +32,8 @@ IBH_IMAGE_ONLY = 2
 IBH_PASS_A_ONLY = 4
 IBH_PASS_B_ONLY = 8
 IBH_EXACT = 16
+IBH_PHASE_INTERIOR = 32
+IBH_PHASE_BOUNDARY = 64
 
 _initialised = {}
 
@@ -161,7 +163,7 @@ class DevicePartition:
         info = (C.c_int64 * 8)()
         call("ibh_partition_info", h, info, 8)
         self.info = dict(full_blocks=info[0], irregular_cells=info[1], sides_same=info[2], sides_mirror=info[3],
-                         sides_coarse=info[4], sides_fine=info[5], sides_general=info[6])
+                         sides_coarse=info[4], sides_fine=info[5], sides_general=info[6], interior_blocks=info[7])
 
     @property
     def ndims(self):

@@ -22,7 +22,7 @@ inline bool on_opp_edge(int s, int pos) {
 }  // namespace
 
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks, std::vector<int32_t>& irr,
-                         int64_t* info) {
+                         int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1) {
     const int32_t nc = v.nc;
     const int NPB = 64;
     const float* hx = v.spacing;
@@ -166,6 +166,54 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
     }
     for (int32_t c = 0; c < nc; ++c)
         if (cell_irr[c]) irr.push_back(c);
+
+    // 4. overlap phases: a cell's gradients depend on the skirt if the cell or a face
+    //    neighbour is a skirt cell (not in `image`).  A1 = blocks without such a cell (pass A can run before
+    //    the halo exchange lands); B1 = A1 blocks whose side neighbours are all A1 (pass B as well).
+    //    Block table order: [B1 | A1 only | rest].
+    n_phase1[0] = n_phase1[1] = 0;
+    {
+        std::vector<char> is_image(nc, 0), dep(nc, 0);
+        for (int32_t k = 0; k < n_image; ++k) is_image[image_in_domain[k] - v.index_base] = 1;
+        for (int32_t c = 0; c < nc; ++c) dep[c] = !is_image[c];
+        for (int d = 0; d < v.nd; ++d)
+            for (size_t f = 0; f < v.owners[d].size(); ++f) {
+                int32_t o = v.owners[d][f], n = v.neighbors[d][f];
+                if (!is_image[o]) dep[n] = 1;
+                if (!is_image[n]) dep[o] = 1;
+            }
+        std::unordered_map<int32_t, int> base2a1;
+        std::vector<char> a1(blocks.size(), 0), b1(blocks.size(), 0);
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            bool ok = true;
+            for (int k = 0; k < NPB && ok; ++k) ok = !dep[blocks[b].base + k] && !cell_irr[blocks[b].base + k];
+            a1[b] = ok;
+            base2a1[blocks[b].base] = ok;
+        }
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            bool ok = a1[b];
+            for (int s = 0; s < 4 && ok; ++s) {
+                int ty = blocks[b].type[s];
+                if (ty == SIDE_MIRROR) continue;
+                if (ty == SIDE_GENERAL) { ok = false; break; }
+                int nn = ty == SIDE_FINE ? 2 : 1;
+                for (int k = 0; k < nn && ok; ++k) {
+                    auto it = base2a1.find(blocks[b].nb[s][k]);
+                    ok = it != base2a1.end() && it->second;
+                }
+            }
+            b1[b] = ok;
+        }
+        std::vector<BlockDesc2> ordered;
+        ordered.reserve(blocks.size());
+        for (size_t b = 0; b < blocks.size(); ++b) if (b1[b]) ordered.push_back(blocks[b]);
+        n_phase1[1] = (int32_t)ordered.size();
+        for (size_t b = 0; b < blocks.size(); ++b) if (a1[b] && !b1[b]) ordered.push_back(blocks[b]);
+        n_phase1[0] = (int32_t)ordered.size();
+        for (size_t b = 0; b < blocks.size(); ++b) if (!a1[b]) ordered.push_back(blocks[b]);
+        blocks.swap(ordered);
+    }
+    info[7] = n_phase1[1];
     info[0] = (int64_t)blocks.size();
     info[1] = (int64_t)irr.size();
     for (int k = 0; k < 5; ++k) info[2 + k] = counts[k];

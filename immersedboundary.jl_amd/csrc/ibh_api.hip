@@ -143,7 +143,15 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
     if (domain && block_size > 0 && nd == 2 && block_size == 8) {
         std::vector<BlockDesc2> blocks;
         std::vector<int32_t> irr;
-        ibh_analyze_blocks2(v, blocks, irr, p->info);
+        int32_t nph[2] = {0, 0};
+        if (n_image > 0 && image_in_domain)
+            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph);
+        else {  // no image information: everything is "boundary"
+            std::vector<int32_t> none;
+            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph);
+        }
+        p->nA1 = nph[0];
+        p->nB1 = nph[1];
         p->bs = block_size;
         p->nblk = (int32_t)blocks.size();
         p->n_irr = (int32_t)irr.size();

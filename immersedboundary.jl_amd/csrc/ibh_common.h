@@ -44,6 +44,7 @@ struct ibh_part {
     // block-structured fast path
     int bs = 0;
     int32_t nblk = 0;            // full blocks handled by the fast kernels
+    int32_t nA1 = 0, nB1 = 0;    // blocks [0,nA1): pass A independent of skirt data; [0,nB1): pass B too
     BlockDesc2* blocks2 = nullptr;
     int32_t n_irr = 0;           // cells handled by the general kernels when the fast path is on
     int32_t* irr_cells = nullptr;
@@ -98,7 +99,8 @@ struct HostPartView {
     int bs;
 };
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
-                         std::vector<int32_t>& irr_cells, int64_t* info);
+                         std::vector<int32_t>& irr_cells, int64_t* info, const int32_t* image_in_domain,
+                         int32_t n_image, int32_t* n_phase1);
 
 static inline int ibh_grid(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;

@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void k_passA(PartView p, const float* __restri
                                                float* __restrict__ G, const BlockDesc2* __restrict__ blocks,
                                                int32_t nblk, int32_t nwg_fast, const int32_t* __restrict__ cells,
                                                int32_t ncells) {
+    // `blocks`/`nblk` describe the sub-range of the block table this launch covers
     constexpr int BPW = EXACT ? 1 : IBH_BPW;
     __shared__ float lds[WPB * BPW * NV * 128];
     if ((int32_t)blockIdx.x < nwg_fast) {
@@ -538,37 +539,45 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     if (rc) return rc;
     const bool fast = p->bs == 8 && p->nd == 2 && p->nblk > 0 && !(flags & IBH_FORCE_GENERAL);
     const int bpwg = WPB * ((flags & IBH_EXACT) ? 1 : IBH_BPW);  // blocks per workgroup
-    const int32_t nwg_fast = fast ? (p->nblk + bpwg - 1) / bpwg : 0;
+    // overlap phases: INTERIOR = blocks independent of skirt data, BOUNDARY = the rest + face-list cells
+    const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
+    IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
+    IBH_REQUIRE(!(ph1 || ph2) || fast, "overlap phases need the block path (2-D, block_size 8, domain given)");
+    const int32_t a0 = ph2 ? p->nA1 : 0, a1 = ph1 ? p->nA1 : p->nblk;  // pass A block range
+    const int32_t b0 = ph2 ? p->nB1 : 0, b1 = ph1 ? p->nB1 : p->nblk;  // pass B block range
+    const int32_t nwgA_fast = fast ? (a1 - a0 + bpwg - 1) / bpwg : 0;
+    const int32_t nwgB_fast = fast ? (b1 - b0 + bpwg - 1) / bpwg : 0;
     // pass A always covers every cell of the partition (skirt cells feed the faces of image cells)
     const int32_t* cellsA = fast ? p->irr_cells : nullptr;
-    const int32_t nA = fast ? p->n_irr : p->nc;
+    const int32_t nA = fast ? (ph1 ? 0 : p->n_irr) : p->nc;
     // pass B: every cell, or image cells only
     const int32_t* cellsB = cellsA;
     int32_t nB = nA;
-    int32_t nwgB_fast = nwg_fast;
     if ((flags & IBH_IMAGE_ONLY) && !fast) {
         cellsB = p->image_in_domain;
         nB = p->n_image;
     }
     PartView v = view(p);
     dim3 blk(256);
-    dim3 gA(nwg_fast + (nA + 255) / 256), gB(nwgB_fast + (nB + 255) / 256);
+    dim3 gA(nwgA_fast + (nA + 255) / 256), gB(nwgB_fast + (nB + 255) / 256);
     const bool exact = (flags & IBH_EXACT) != 0;
     const bool doA = gA.x && !(flags & IBH_PASS_B_ONLY), doB = gB.x && !(flags & IBH_PASS_A_ONLY);
+    const BlockDesc2* blkA = p->blocks2 ? p->blocks2 + a0 : nullptr;
+    const BlockDesc2* blkB = p->blocks2 ? p->blocks2 + b0 : nullptr;
     if (p->nd == 2 && exact) {
         if (doA)
-            hipLaunchKernelGGL((k_passA<2, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,
-                               p->nblk, nwg_fast, cellsA, nA);
+            hipLaunchKernelGGL((k_passA<2, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA,
+                               a1 - a0, nwgA_fast, cellsA, nA);
         if (doB)
-            hipLaunchKernelGGL((k_passB_adv<2, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
-                               p->nblk, nwgB_fast, cellsB, nB);
+            hipLaunchKernelGGL((k_passB_adv<2, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB,
+                               b1 - b0, nwgB_fast, cellsB, nB);
     } else if (p->nd == 2) {
         if (doA)
-            hipLaunchKernelGGL((k_passA<2, 1, false>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,
-                               p->nblk, nwg_fast, cellsA, nA);
+            hipLaunchKernelGGL((k_passA<2, 1, false>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA,
+                               a1 - a0, nwgA_fast, cellsA, nA);
         if (doB)
-            hipLaunchKernelGGL((k_passB_adv<2, false>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
-                               p->nblk, nwgB_fast, cellsB, nB);
+            hipLaunchKernelGGL((k_passB_adv<2, false>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB,
+                               b1 - b0, nwgB_fast, cellsB, nB);
     } else {
         if (doA)
             hipLaunchKernelGGL((k_passA<3, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,

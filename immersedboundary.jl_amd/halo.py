@@ -59,14 +59,41 @@ class HaloExchange:
         self.send_idx = {q: torch.from_numpy(v).to(self.device) for q, v in plan.send.items()}
         self.recv_idx = {q: torch.from_numpy(v).to(self.device) for q, v in plan.recv.items()}
         self._bufs = {}
+        # gloo cannot move device buffers point-to-point: stage through pinned host memory (rehearsal only;
+        # the production transport is RCCL, which takes the device buffers directly)
+        self.staged = self.device.type == "cuda" and dist.get_backend(group) == "gloo"
 
     def _buffers(self, nv):
         if nv not in self._bufs:
-            sb = {q: torch.empty((nv, i.numel()), dtype=torch.float32, device=self.device)
-                  for q, i in self.send_idx.items()}
-            rb = {q: torch.empty((nv, i.numel()), dtype=torch.float32, device=self.device)
-                  for q, i in self.recv_idx.items()}
-            self._bufs[nv] = (sb, rb)
+            if nv == 1:
+                # scalar fields: one contiguous buffer per direction, peers are slices -> ONE pack and ONE
+                # unpack kernel per exchange whatever the number of peers
+                sq, rq = sorted(self.send_idx), sorted(self.recv_idx)
+                self.send_all = torch.cat([self.send_idx[q] for q in sq]) if sq else None
+                self.recv_all = torch.cat([self.recv_idx[q] for q in rq]) if rq else None
+                sball = torch.empty((1, sum(self.send_idx[q].numel() for q in sq)), dtype=torch.float32, device=self.device)
+                rball = torch.empty((1, sum(self.recv_idx[q].numel() for q in rq)), dtype=torch.float32, device=self.device)
+                self.sb_all, self.rb_all = sball, rball
+                sb, rb, o = {}, {}, 0
+                for q in sq:
+                    n = self.send_idx[q].numel()
+                    sb[q] = sball[:, o:o + n]
+                    o += n
+                o = 0
+                for q in rq:
+                    n = self.recv_idx[q].numel()
+                    rb[q] = rball[:, o:o + n]
+                    o += n
+            else:
+                sb = {q: torch.empty((nv, i.numel()), dtype=torch.float32, device=self.device)
+                      for q, i in self.send_idx.items()}
+                rb = {q: torch.empty((nv, i.numel()), dtype=torch.float32, device=self.device)
+                      for q, i in self.recv_idx.items()}
+            hs = hr = None
+            if self.staged:
+                hs = {q: torch.empty(b.shape, dtype=b.dtype).pin_memory() for q, b in sb.items()}
+                hr = {q: torch.empty(b.shape, dtype=b.dtype).pin_memory() for q, b in rb.items()}
+            self._bufs[nv] = (sb, rb, hs, hr)
         return self._bufs[nv]
 
     def _pack(self, field, idx, buf):
@@ -92,23 +119,39 @@ class HaloExchange:
     def start(self, field):
         """Pack and post the sends/receives of ``field`` (local ``(nc,)`` or ``(nc, nv)``); returns a handle."""
         nv = 1 if field.ndim == 1 else field.shape[1]
-        sb, rb = self._buffers(nv)
+        sb, rb, hs, hr = self._buffers(nv)
         ops = []
-        for q in self.plan.peers:
-            if q in self.send_idx:
-                self._pack(field, self.send_idx[q], sb[q])
+        if nv == 1:
+            if self.send_all is not None:
+                self._pack(field, self.send_all, self.sb_all)
+        else:
+            for q in self.plan.peers:
+                if q in self.send_idx:
+                    self._pack(field, self.send_idx[q], sb[q])
+        if self.staged:
+            for q in hs:
+                hs[q].copy_(sb[q], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        src, dst = (hs, hr) if self.staged else (sb, rb)
         for q in self.plan.peers:
             if q in self.recv_idx:
-                ops.append(self.dist.P2POp(self.dist.irecv, rb[q], q - 1, self.group))
+                ops.append(self.dist.P2POp(self.dist.irecv, dst[q], q - 1, self.group))
             if q in self.send_idx:
-                ops.append(self.dist.P2POp(self.dist.isend, sb[q], q - 1, self.group))
+                ops.append(self.dist.P2POp(self.dist.isend, src[q], q - 1, self.group))
         reqs = self.dist.batch_isend_irecv(ops) if ops else []
-        return (field, rb, reqs)
+        return (field, rb, hr, reqs, nv)
 
     def finish(self, handle):
-        field, rb, reqs = handle
+        field, rb, hr, reqs, nv = handle
         for r in reqs:
             r.wait()
+        if self.staged:
+            for q in hr:
+                rb[q].copy_(hr[q], non_blocking=True)
+        if nv == 1:
+            if self.recv_all is not None:
+                self._unpack(field, self.recv_all, self.rb_all)
+            return
         for q in self.plan.peers:
             if q in self.recv_idx:
                 self._unpack(field, self.recv_idx[q], rb[q])
@@ -116,3 +159,24 @@ class HaloExchange:
     def exchange(self, field):
         self.finish(self.start(field))
         return field
+
+
+def sweep_overlapped(hx, dpart, u, C, ud, comm_stream, flags=0):
+    """One advection residual sweep with the skirt exchange overlapped with interior compute.
+
+    The exchange (pack, grouped send/recv, unpack) runs on ``comm_stream``; meanwhile the compute stream
+    runs both passes on the blocks that do not depend on skirt cells (``IBH_PHASE_INTERIOR``: the block table
+    is ordered interior-first by the library's analysis); the remaining blocks and the face-list cells run
+    after the exchange has landed (``IBH_PHASE_BOUNDARY``).  Interior blocks never read a skirt cell, so the
+    unpack kernel and the interior kernels touch disjoint rows of ``u``.
+    """
+    import torch
+    from . import backend as B
+    cur = torch.cuda.current_stream()
+    comm_stream.wait_stream(cur)
+    with torch.cuda.stream(comm_stream):
+        hx.finish(hx.start(u))
+    B.residual_advection(dpart, u, C, out=ud, flags=flags | B.IBH_PHASE_INTERIOR)
+    cur.wait_stream(comm_stream)
+    B.residual_advection(dpart, u, C, out=ud, flags=flags | B.IBH_PHASE_BOUNDARY)
+    return ud

@@ -105,3 +105,33 @@ def test_euler_residual_rae(rae_domains):
             got = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=flags))
             worst = max(worst, rel_inf(got, exp))
     assert worst <= TOL
+
+
+@pytest.mark.parametrize("flags", [0, 16])
+def test_overlap_phases_equal_full_sweep(rae_domains, flags):
+    """IBH_PHASE_INTERIOR + IBH_PHASE_BOUNDARY == one full sweep, bit for bit, and the interior phase
+    does not read skirt cells (they are poisoned with NaN while it runs)."""
+    import torch
+    dp, _ = rae_domains
+    n_int = 0
+    for k in dp.partitions:
+        part = dp.partitions[k]
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        n_int += dpart.info["interior_blocks"]
+        u = seeded_field(part.centers)
+        C = np.ones((u.shape[0], 2), dtype=f32)
+        ud_full = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), flags=flags))
+        skirt = np.ones(u.shape[0], dtype=bool)
+        skirt[part.image_in_domain] = False
+        up = u.copy()
+        up[skirt] = np.nan
+        ud = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+        ibamd.residual_advection(dpart, ibamd.hip(up), ibamd.hip(C), out=ud, flags=flags | ibamd.IBH_PHASE_INTERIOR)
+        got1 = ibamd.to_host(ud)
+        done = ~np.isnan(got1)
+        assert np.array_equal(got1[done], ud_full[done])          # interior results final and NaN-free
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud, flags=flags | ibamd.IBH_PHASE_BOUNDARY)
+        got = ibamd.to_host(ud)
+        img = part.image_in_domain
+        assert np.array_equal(got[img], ud_full[img])
+    assert n_int > 0
