@@ -21,4 +21,6 @@ def __getattr__(name):
     backend = importlib.import_module(__name__ + ".backend")
     if hasattr(backend, name):
         return getattr(backend, name)
+    if name == "FAS":
+        return importlib.import_module(__name__ + ".solver").FAS
     raise AttributeError(name)

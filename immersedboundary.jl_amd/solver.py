@@ -1,0 +1,77 @@
+"""Device-resident ``FAS!`` (mirror of /root/reference/src/solver.jl:39-91).
+
+Same signature and semantics as the reference (including its quirks: the recursion guard is
+``length(coarseners) > 1`` so the last supplied level is never visited, and the coarse problem is solved
+before the fine smoothing).  ``Q``, the residuals and the sources are device arrays that never leave the
+GPU; coarseners / prolongators are device Accumulators (``to_backend(acc)``: one SpMV kernel each); the
+fixed-point update and the norm are libibhip kernels.  The only host round-trip per iteration is the
+scalar norm the reference's convergence test needs (solver.jl:84-87).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import backend as B
+
+_eps32 = float(np.finfo(np.float32).eps)
+
+
+def _norm(r):
+    """||r||_2 of a device array (sum of squares accumulated in Float64 on the device)."""
+    r, nv, ld = B._field(r)
+    flat = r if r.ndim == 1 or ld == r.shape[0] else r.T.contiguous().T
+    out = torch.zeros(1, dtype=torch.float64, device=r.device)
+    B._stream()
+    B.call("ibh_sumsq", int(flat.numel()), B._ptr(flat), B._ptr(out))
+    return float(out.item()) ** 0.5
+
+
+def _update(Q, omega, r):
+    """Q += clamp(omega, 0, 1) * r  (solver.jl:82)."""
+    if isinstance(omega, torch.Tensor):
+        Q += torch.clamp(omega, 0.0, 1.0) * r
+        return
+    Qf, _, ldq = B._field(Q)
+    rf, _, ldr = B._field(r)
+    if Qf.data_ptr() != Q.data_ptr() or (Q.ndim == 2 and (ldq != Q.shape[0] or ldr != r.shape[0])):
+        Q += min(max(float(omega), 0.0), 1.0) * r
+        return
+    B._stream()
+    B.call("ibh_axpy_clamped", int(Q.numel()), C.c_float(float(omega)), B._ptr(rf), B._ptr(Q))
+
+
+def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level=0, n_iter=50,
+        rtol=1e-1, atol=1e-7):
+    """``FAS!(f, Q; coarseners, prolongators, perscribed_f, multigrid_level, n_iter, rtol, atol)``.
+
+    ``f(level, Q) -> (r, omega)`` with device arrays; ``Q`` is updated in place.  Returns the residual-norm
+    reduction ratio like the reference.
+    """
+    l = multigrid_level
+    fQ, omega = f(l, Q)
+    source = None
+    if perscribed_f is not None:
+        source = perscribed_f - fQ
+    r = fQ if source is None else fQ + source
+    nr0 = _norm(r)
+    nr = nr0
+    if len(coarseners) > 1:
+        coars, prolong = B.to_backend(coarseners[0]), B.to_backend(prolongators[0])
+        Qc = coars(Q)
+        Qcold = Qc.clone()
+        pfQc = coars(r)
+        FAS(f, Qc, coarseners=coarseners[1:], prolongators=prolongators[1:], perscribed_f=pfQc,
+            multigrid_level=multigrid_level + 1, n_iter=n_iter, atol=atol, rtol=rtol)
+        Q += prolong(Qc - Qcold)
+    for _ in range(n_iter):
+        r, omega = f(l, Q)
+        if source is not None:
+            r = r + source
+        _update(Q, omega, r)
+        nr = _norm(r)
+        if nr < nr0 * rtol + atol:
+            break
+    return nr / (nr0 + _eps32)

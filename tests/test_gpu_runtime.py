@@ -162,3 +162,43 @@ def test_multigrid_transfer_operators(adv_mesh_coarse):
     # prolongation of a constant is that constant (IDW weights sum to 1)
     one = torch.ones(len(coarse_doms[0]), dtype=torch.float32, device=uc.device)
     assert float((ibamd.to_backend(prolongators[0])(one) - 1).abs().max()) <= 1e-6
+
+
+def test_fas_multigrid_matches_oracle(adv_mesh_coarse):
+    """Solver.FAS! (solver.jl:39-91) on a 3-level hierarchy: device-resident loop vs the oracle's loop with
+    the same residual closure (pseudo-time relaxation of the Laplacian, test/dissipation.jl:69-77)."""
+    from oracle.solver import FAS as oFAS
+    fam = [("neumann", [(1, True), (2, True)])]
+    dp = ibamd.Domain(adv_mesh_coarse, hypercube_families=fam, boundaries=False)
+    do = od.Domain(adv_mesh_coarse, hypercube_families=fam)
+    cd_p, prol_p, coar_p = ibamd.multigrid(dp, max_levels=2)
+    cd_o, prol_o, coar_o = od.multigrid(do, max_levels=2)
+    levels_p = [dp] + cd_p
+    levels_o = [do] + cd_o
+    Q0 = seeded_field(dp.global_centers(), nv=2)
+
+    def o_f(l, Q):
+        part = levels_o[l].partitions[1]
+        r = np.zeros_like(Q)
+        for dim in (1, 2):
+            r += od.green_gauss(part, od.face_gradient(part, Q, dim), dim)
+        h = part.spacing[:, 0].min()
+        return r, f32(0.2) * h * h
+
+    dparts = [ibamd.to_backend(d.partitions[1], ibamd.hip) for d in levels_p]
+
+    def g_f(l, Q):
+        part = dparts[l]
+        r = torch.zeros_like(Q)
+        for dim in (1, 2):
+            r += ibamd.green_gauss(part, ibamd.face_gradient(part, Q, dim), dim)
+        h = float(levels_p[l].partitions[1].spacing[:, 0].min())
+        return r, f32(0.2) * f32(h) * f32(h)
+
+    Qo = Q0.copy()
+    ro = oFAS(o_f, Qo, coarseners=coar_o, prolongators=prol_o, n_iter=8, rtol=f32(1e-3))
+    Qg = ibamd.hip(Q0)
+    rg = ibamd.FAS(g_f, Qg, coarseners=coar_p, prolongators=prol_p, n_iter=8, rtol=1e-3)
+    assert rel_inf(ibamd.to_host(Qg), Qo) <= 1e-5
+    assert abs(rg - float(ro)) <= 1e-4 * max(1.0, float(ro))
+    assert not np.array_equal(Qo, Q0)
