@@ -1,0 +1,111 @@
+"""3-D (octree, 8^3 blocks): builder vs literal restatement, and the face-list HIP kernels vs the oracle.
+Small sphere-in-a-box case in the spirit of BASELINE.json configs[3]."""
+import numpy as np
+import pytest
+
+import ibamd
+from conftest import rel_inf
+from ibamd.mesher import Ball, Mesh, Stereolitography
+
+f32 = np.float32
+
+
+def icosphere(radius=0.5, center=(0.0, 0.0, 0.0), subdiv=1):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]])
+    for _ in range(subdiv):
+        nv, nf, cache = list(v), [], {}
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                nv.append((nv[a] + nv[b]) / 2)
+                cache[k] = len(nv) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v, f = np.array(nv), np.array(nf)
+    v = v / np.linalg.norm(v, axis=1, keepdims=True) * radius + np.asarray(center)
+    return Stereolitography(v.T.astype(f32), (f.T + 1).astype(np.int64))
+
+
+@pytest.fixture(scope="module")
+def sphere_mesh():
+    """253 blocks of 4^3 cells on 2 octree levels (16 192 cells), refined towards a ball.  No immersed
+    surface: the reference's per-ghost triangle projection (mesher.jl:778-801 + :544-596) is a cold-path
+    Python loop here and takes minutes in 3-D; hypercube boundaries are built and compared."""
+    return Mesh(f32([-2, -2, -2]), f32([4, 4, 4]), block_size=4,
+                refinement_regions=[(Ball(np.array([0.6, 0.6, 0.6]), 0.1), f32(0.2))])
+
+
+@pytest.fixture(scope="module")
+def sphere_domains(sphere_mesh):
+    from oracle import domain as od
+    kw = dict(hypercube_families=[("farfield", [(1, False), (1, True)])], max_partition_size=8192)
+    return ibamd.Domain(sphere_mesh, **kw), od.Domain(sphere_mesh, **kw)
+
+
+def test_3d_builder_matches_oracle(sphere_domains):
+    dp, do = sphere_domains
+    assert dp.ndims == 3 and len(dp) == 16192 and len(dp.partitions) == 2
+    fd, fo, fn = dp.faces
+    of = np.array(do.faces)
+    assert np.array_equal(of[:, 0], fd) and np.array_equal(of[:, 1], fo) and np.array_equal(of[:, 2], fn)
+    for k in do.partitions:
+        a, b = do.partitions[k], dp.partitions[k]
+        assert np.array_equal(a.domain, b.domain) and np.array_equal(a.image_in_domain, b.image_in_domain)
+        for dim in (1, 2, 3):
+            assert np.array_equal(a.face_owners_neighbors[dim][0], b.face_owners_neighbors[dim][0])
+            assert np.array_equal(a.face_owners_neighbors[dim][1], b.face_owners_neighbors[dim][1])
+            for r in (False, True):
+                ia, _ = a.face_accumulators[(dim, r)].decompose()
+                assert np.array_equal(np.concatenate([x for x in ia if x is not None and len(x)]),
+                                      b.face_accumulators[(dim, r)].idx)
+    for name in do.boundaries:
+        for k in do.boundaries[name]:
+            assert np.array_equal(do.boundaries[name][k].ghost_indices, dp.boundaries[name][k].ghost_indices)
+
+
+@pytest.mark.gpu
+def test_3d_residuals_match_oracle(sphere_domains):
+    from oracle import cfd as ocfd
+    from oracle import domain as od
+    dp, do = sphere_domains
+    rng = np.random.default_rng(5)
+    fluid = ocfd.Fluid()
+    for k in list(dp.partitions)[:2]:
+        opart = do.partitions[k]
+        dpart = ibamd.to_backend(dp.partitions[k], ibamd.hip)
+        n = opart.spacing.shape[0]
+        x = opart.centers
+        u = (np.sin(2 * x[:, 0]) * np.cos(3 * x[:, 1]) + 0.3 * x[:, 2] + 0.1 * rng.uniform(-1, 1, n)).astype(f32)
+        C = np.stack([np.ones(n, f32), f32(0.5) * np.ones(n, f32), f32(-0.25) * np.ones(n, f32)], axis=1)
+        ud = np.zeros(n, f32)
+        D = od.JST_sensor(opart, u)
+        assert rel_inf(ibamd.to_host(ibamd.JST_sensor(dpart, ibamd.hip(u))), D) <= 1e-5
+        for dim in (1, 2, 3):
+            Cf = od.at_faces(opart, np.ascontiguousarray(C[:, dim - 1]), dim)
+            gu = od.cell_gradient(opart, u, dim)
+            assert rel_inf(ibamd.to_host(ibamd.cell_gradient(dpart, ibamd.hip(u), dim)), gu) <= 1e-5
+            uL, uR = od.MUSCL(opart, u, gu, dim, D=D, high_order=True)
+            ud -= od.green_gauss(opart, (uL + uR) * Cf / f32(2) + np.abs(Cf) * (uL - uR) / f32(2), dim)
+        got = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C)))
+        assert rel_inf(got, ud) <= 1e-5
+        P = np.empty((n, 5), dtype=f32)
+        P[:, 0] = 1e5 * (1 + 0.05 * rng.uniform(-1, 1, n))
+        P[:, 1] = 288.15 * (1 + 0.05 * rng.uniform(-1, 1, n))
+        for d in range(3):
+            P[:, 2 + d] = 100.0 * (1 + 0.1 * rng.uniform(-1, 1, n))
+        R = np.zeros_like(P)
+        Dp = od.JST_sensor(opart, np.ascontiguousarray(P[:, 0]))
+        for dim in (1, 2, 3):
+            gP = od.cell_gradient(opart, P, dim)
+            PL, PR = od.MUSCL(opart, P, gP, dim, D=Dp, high_order=True)
+            R -= od.green_gauss(opart, ocfd.inviscid_fluxes(fluid, PL, PR, dim), dim)
+        got = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P)))
+        assert rel_inf(got, R) <= 1e-5
