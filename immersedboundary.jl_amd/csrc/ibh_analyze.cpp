@@ -22,7 +22,8 @@ inline bool on_opp_edge(int s, int pos) {
 }  // namespace
 
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks, std::vector<int32_t>& irr,
-                         int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1) {
+                         int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
+                         std::vector<int32_t>& htab) {
     const int32_t nc = v.nc;
     const int NPB = 64;
     const float* hx = v.spacing;
@@ -84,6 +85,8 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
         b.base = base;
         b.h[0] = hx[base];
         b.h[1] = hy[base];
+        b.rh[0] = 1.0f / b.h[0];
+        b.rh[1] = 1.0f / b.h[1];
         // 3. sides
         for (int s = 0; s < 4; ++s) {
             const int d = s / 2;
@@ -158,6 +161,8 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
             b.nb[s][0] = nb[0];
             b.nb[s][1] = nb[1];
             b.sub[s] = sub < 0 ? 0 : sub;
+            b.q[s] = type == SIDE_COARSE ? (1.0f / 3.0f) : type == SIDE_FINE ? (2.0f / 3.0f) : 0.5f;
+            b.rt[s] = type == SIDE_COARSE ? 2.0f : type == SIDE_FINE ? 0.5f : 1.0f;
             counts[type]++;
             if (type == SIDE_GENERAL)
                 for (int t = 0; t < 8; ++t) cell_irr[base + pos_own(s, t)] = 1;
@@ -212,6 +217,22 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
         n_phase1[0] = (int32_t)ordered.size();
         for (size_t b = 0; b < blocks.size(); ++b) if (!a1[b]) ordered.push_back(blocks[b]);
         blocks.swap(ordered);
+    }
+    // 5. halo cell table in the final block order
+    htab.resize(blocks.size() * 64);
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        const BlockDesc2& b = blocks[bi];
+        for (int s = 0; s < 4; ++s)
+            for (int t = 0; t < 8; ++t)
+                for (int k = 0; k < 2; ++k) {
+                    int32_t cell;
+                    const int ty = b.type[s];
+                    if (ty == SIDE_SAME) cell = b.nb[s][0] + pos_opp(s, t);
+                    else if (ty == SIDE_COARSE) cell = b.nb[s][0] + pos_opp(s, 4 * b.sub[s] + (t >> 1));
+                    else if (ty == SIDE_FINE) cell = b.nb[s][t >> 2] + pos_opp(s, 2 * (t & 3) + k);
+                    else cell = b.base + pos_own(s, t);
+                    htab[bi * 64 + (s * 8 + t) * 2 + k] = cell;
+                }
     }
     info[7] = n_phase1[1];
     info[0] = (int64_t)blocks.size();

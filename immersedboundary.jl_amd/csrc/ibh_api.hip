@@ -144,12 +144,14 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         std::vector<BlockDesc2> blocks;
         std::vector<int32_t> irr;
         int32_t nph[2] = {0, 0};
+        std::vector<int32_t> htab;
         if (n_image > 0 && image_in_domain)
-            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph);
+            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph, htab);
         else {  // no image information: everything is "boundary"
             std::vector<int32_t> none;
-            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph);
+            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph, htab);
         }
+        if ((rc = ibh_upload(&p->htab, htab.data(), htab.size()))) return rc;
         p->nA1 = nph[0];
         p->nB1 = nph[1];
         p->bs = block_size;
@@ -176,6 +178,7 @@ int ibh_partition_destroy(ibh_part* p) {
     }
     hipFree(p->image_in_domain);
     hipFree(p->blocks2);
+    hipFree(p->htab);
     hipFree(p->irr_cells);
     hipFree(p->G);
     delete p;

@@ -2,18 +2,22 @@
 //
 // This is the tuned form of the fast path (the literal IEEE form lives in ibh_fused.hip and is
 // selected with IBH_EXACT).  Differences, all within the 1e-5 norm-wise parity tolerance:
-//   * the divisions of the reference formulas are replaced by per-block reciprocals
-//     (1/hx, 1/hy are wave-uniform) and per-side weight constants: inside a block and across
-//     same-level / 2:1 sides the spacing ratio h_n/h_o is 1, 2 or 1/2, so
-//     at_faces = (1-q)*u_o + q*u_n with q = 1/(1+ratio) in {1/2, 1/3, 2/3} and
-//     1/(d_o+d_n) = 2*q/h;   the sensor ratio uses v_rcp_f32;
-//   * every interior face flux is computed once, by the lane on its left/bottom, and handed
-//     to the neighbour lane with a wavefront shuffle; block-boundary faces that no lane owns
-//     (left and bottom sides, second sub-face on 2:1 fine sides) are computed together in one
-//     extra pass by otherwise idle lanes;
+//   * the divisions of the reference formulas are replaced by per-block reciprocals (1/hx, 1/hy
+//     are wave-uniform, stored in the block descriptor) and per-side weights: inside a block and
+//     across same-level / 2:1 sides the spacing ratio h_n/h_o is 1, 2 or 1/2, so
+//     at_faces = (1-q)*u_o + q*u_n with q = 1/(1+ratio) in {1/2, 1/3, 2/3} and 1/(d_o+d_n) = 2*q/h;
+//     the sensor ratio uses v_rcp_f32;
+//   * every interior face flux is computed once, by the lane on its left/bottom, and handed to the
+//     neighbour lane with a wavefront shuffle; block-boundary faces that no lane owns (left and
+//     bottom sides, second sub-faces) are computed together in one extra pass;
 //   * FMA contraction is allowed in this file.
-// LDS per wave: cell tiles + one halo slot per (side, boundary cell, sub-face), filled by a
-// single gather instruction per field (lane = slot).
+// The body is BRANCH-FREE (profiles/r1_v2: the first version spent ~100 scalar instructions per wave
+// on exec-mask bookkeeping and was bound by instruction issue):
+//   * the halo cell of every slot comes from a precomputed per-block table (one coalesced load);
+//   * every block side has TWO sub-face slots per boundary cell; single-face sides repeat sub-face 0
+//     in slot 1, so "mean over the faces of the side" is always (f0 + f1)/2, exact when f1 == f0;
+//   * interior-vs-halo neighbours are one LDS read with a selected address.
+// LDS per wave and field: tile[64] followed by halo[64] (slot = (side*8 + t)*2 + k).
 #pragma once
 #include "ibh_common.h"
 
@@ -28,49 +32,25 @@ __device__ __forceinline__ void stg(float* __restrict__ p, uint32_t i, float v) 
     *(float*)((char*)p + (size_t)(i << 2)) = v;
 }
 
-// local id of the k-th neighbour cell across side s for boundary cell t, or -1
-__device__ __forceinline__ int32_t halo_cell(const BlockDesc2& b, int s, int t, int k) {
-    int ty = b.type[s];
-    int tt;
-    int32_t base;
-    if (ty == SIDE_SAME) {
-        if (k) return -1;
-        tt = t;
-        base = b.nb[s][0];
-    } else if (ty == SIDE_COARSE) {
-        if (k) return -1;
-        tt = 4 * b.sub[s] + (t >> 1);
-        base = b.nb[s][0];
-    } else if (ty == SIDE_FINE) {
-        tt = 2 * (t & 3) + k;
-        base = b.nb[s][t >> 2];
-    } else if (ty == SIDE_MIRROR) {
-        if (k) return -1;
-        // mirror face: owner == neighbour == the boundary cell itself (ImmersedBoundary.jl:653-660)
-        return b.base + ((s == 0) ? 8 * t : (s == 1) ? 7 + 8 * t : (s == 2) ? t : t + 56);
-    } else {
-        return -1;
-    }
-    int pos = (s == 0) ? 7 + 8 * tt : (s == 1) ? 8 * tt : (s == 2) ? tt + 56 : tt;
-    return base + pos;
-}
-
-// spacing ratio h_nb/h across side type, and q = 1/(1+ratio)
-__device__ __forceinline__ float side_ratio(int ty) { return ty == SIDE_COARSE ? 2.0f : (ty == SIDE_FINE ? 0.5f : 1.0f); }
-__device__ __forceinline__ float side_q(int ty) {
-    return ty == SIDE_COARSE ? (1.0f / 3.0f) : (ty == SIDE_FINE ? (2.0f / 3.0f) : 0.5f);
-}
-
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ float sel4(int s, float a0, float a1, float a2, float a3) {
+    const float lo = (s & 1) ? a1 : a0;
+    const float hi = (s & 1) ? a3 : a2;
+    return (s & 2) ? hi : lo;
+}
+
 struct Lane {
     int i, j;
     bool edge[4];
     bool general;
+    int nidx[4];  // index of the sub-face-0 neighbour in a [tile | halo] LDS field: tile = 0..63, halo = 64..127
+    float q[4];   // 1/(1 + h_nb/h) towards direction s
+    float rt[4];  // h_nb/h
 };
 
 __device__ __forceinline__ Lane lane_info(const BlockDesc2& b, int lane) {
@@ -83,141 +63,87 @@ __device__ __forceinline__ Lane lane_info(const BlockDesc2& b, int lane) {
     L.edge[3] = L.j == 7;
     L.general = false;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) L.general |= L.edge[s] && b.type[s] == SIDE_GENERAL;
+    for (int s = 0; s < 4; ++s) {
+        L.general |= L.edge[s] && b.type[s] == SIDE_GENERAL;
+        const int off = (s == 0) ? -1 : (s == 1) ? 1 : (s == 2) ? -8 : 8;
+        const int t = (s < 2) ? L.j : L.i;
+        L.nidx[s] = L.edge[s] ? 64 + (s * 8 + t) * 2 : lane + off;
+        L.q[s] = L.edge[s] ? b.q[s] : 0.5f;
+        L.rt[s] = L.edge[s] ? b.rt[s] : 1.0f;
+    }
     return L;
 }
 
-// neighbour value(s) of a staged field across direction s
-__device__ __forceinline__ void nbv(const float* tile, const float* halo, int lane, const Lane& L, int s, float& v0,
-                                    float& v1) {
-    if (!L.edge[s]) {
-        const int off = (s == 0) ? -1 : (s == 1) ? 1 : (s == 2) ? -8 : 8;
-        v0 = tile[lane + off];
-        v1 = v0;
-    } else {
-        const int t = (s < 2) ? L.j : L.i;
-        v0 = halo[(s * 8 + t) * 2];
-        v1 = halo[(s * 8 + t) * 2 + 1];
-    }
+// the two sub-face neighbour values across direction s (equal for single faces)
+__device__ __forceinline__ void nb2(const float* f, const Lane& L, int s, float& v0, float& v1) {
+    v0 = f[L.nidx[s]];
+    v1 = f[L.nidx[s] + (L.edge[s] ? 1 : 0)];
 }
-
-// ------------------------------------------------------------------------------------------
-// Both passes process BPW blocks per wavefront: all descriptor loads, then all tile loads and halo
-// gathers of the BPW blocks are issued before anything is consumed, so one wave keeps BPW times
-// more memory requests in flight and the grid fits in a single residency round.
-// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nb1(const float* f, const Lane& L, int s) { return f[L.nidx[s]]; }
 
 // Gradient along x and y and JST sensor of ONE staged scalar field at this lane's cell
 // (cell_gradient :965 + JST_sensor :1077 in weight form).
-__device__ __forceinline__ void cell_G(const float* tile, const float* halo, int lane, const Lane& L,
-                                       const BlockDesc2& bb, float uc, float& gx, float& gy, float& D) {
+__device__ __forceinline__ void cell_G(const float* f, const Lane& L, const BlockDesc2& bb, float uc, float& gx,
+                                       float& gy, float& D) {
     D = 1e-7f;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-        const float rh = __builtin_amdgcn_rcpf(bb.h[d]);
+        const float rh = bb.rh[d];
         const int sL = 2 * d, sR = 2 * d + 1;
-        const int tyL = bb.type[sL], tyR = bb.type[sR];
-        const float qL = L.edge[sL] ? side_q(tyL) : 0.5f;
-        const float qR = L.edge[sR] ? side_q(tyR) : 0.5f;
-        const bool twoL = L.edge[sL] && tyL == SIDE_FINE;
-        const bool twoR = L.edge[sR] && tyR == SIDE_FINE;
         float l0, l1, r0, r1;
-        nbv(tile, halo, lane, L, sL, l0, l1);
-        nbv(tile, halo, lane, L, sR, r0, r1);
-        const float uLm = twoL ? 0.5f * (l0 + l1) : l0;
-        const float uRm = twoR ? 0.5f * (r0 + r1) : r0;
-        const float fr = uc + qR * (uRm - uc);
-        const float fl = uc + qL * (uLm - uc);
+        nb2(f, L, sL, l0, l1);
+        nb2(f, L, sR, r0, r1);
+        const float uLm = 0.5f * (l0 + l1);
+        const float uRm = 0.5f * (r0 + r1);
+        const float fr = uc + L.q[sR] * (uRm - uc);  // at_faces: (1-q)*u_self + q*u_nb
+        const float fl = uc + L.q[sL] * (uLm - uc);
         const float g = (fr - fl) * rh;
         if (d == 0) gx = g; else gy = g;
         const float dr = uRm - uc, dl = uc - uLm;
-        const float ar = twoR ? 0.5f * (fabsf(r0 - uc) + fabsf(r1 - uc)) : fabsf(dr);
-        const float al = twoL ? 0.5f * (fabsf(uc - l0) + fabsf(uc - l1)) : fabsf(dl);
+        const float ar = 0.5f * (fabsf(r0 - uc) + fabsf(r1 - uc));
+        const float al = 0.5f * (fabsf(uc - l0) + fabsf(uc - l1));
         const float gg = (dr - dl) * rh;
         const float ugg = (ar + al) * rh;
         D = fmaxf(D, (1e-7f + fabsf(gg)) * __builtin_amdgcn_rcpf(1e-7f + ugg));
     }
 }
 
-// pass A: gradients of NV variables along x and y + JST sensor of variable 0.
-// (Measured, profiles/r1_v1: storing only the block rim and recomputing own-cell values in pass B is
-// slower for the scalar residual -- 17.8 vs 15.6 us per sweep -- so everything is stored.)
+// ------------------------------------------------------------------------------------------
+// pass A: gradients of NV variables along x and y + JST sensor of variable 0
 // G layout as in ibh_fused.hip: grad of var v along dim d at G[(d*NV+v)*nc + c], sensor at G[2*NV*nc + c]
-// LDS per wave: BPW * (tile[NV][64] + halo[NV][64])
-template <int NV, int BPW>
-__device__ __forceinline__ void passA(const BlockDesc2* __restrict__ blocks, int32_t blk0, int32_t nblk, uint32_t nc,
-                                      const float* __restrict__ u, uint32_t ldu, float* __restrict__ G, float* lds,
-                                      int lane) {
-    const BlockDesc2* b[BPW];
-    bool valid[BPW];
-    float self[BPW][NV], hv[BPW][NV];
+// LDS per wave: NV * 128 floats
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void passA(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                      int32_t blk, uint32_t nc, const float* __restrict__ u, uint32_t ldu,
+                                      float* __restrict__ G, float* lds, int lane) {
+    const BlockDesc2 bb = blocks[blk];  // by value: wave-uniform, lives in SGPRs, no per-lane descriptor loads
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
+    const uint32_t c = (uint32_t)bb.base + lane;
+    float self[NV];
 #pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        valid[r] = blk0 + r < nblk;
-        b[r] = blocks + (valid[r] ? blk0 + r : nblk - 1);
+    for (int v = 0; v < NV; ++v) {
+        self[v] = ldg(u + (size_t)v * ldu, c);
+        const float hv = ldg(u + (size_t)v * ldu, hidx);
+        lds[v * 128 + lane] = self[v];
+        lds[v * 128 + 64 + lane] = hv;
     }
-#pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        const int32_t hidx = halo_cell(*b[r], lane >> 4, (lane >> 1) & 7, lane & 1);
-        const uint32_t c = (uint32_t)b[r]->base + lane;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            self[r][v] = ldg(u + (size_t)v * ldu, c);
-            hv[r][v] = hidx >= 0 ? ldg(u + (size_t)v * ldu, (uint32_t)hidx) : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        float* tile = lds + r * (2 * NV * 64);
-        float* halo = tile + NV * 64;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            tile[v * 64 + lane] = self[r][v];
-            halo[v * 64 + lane] = hv[r][v];
-        }
-    }
+    const Lane L = lane_info(bb, lane);
     wave_lds_sync();
+    float gx[NV], gy[NV], D = 1e-7f;
 #pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        const BlockDesc2& bb = *b[r];
-        const Lane L = lane_info(bb, lane);
-        const float* tile = lds + r * (2 * NV * 64);
-        const float* halo = tile + NV * 64;
-        const uint32_t c = (uint32_t)bb.base + lane;
-        const bool store = valid[r] && !L.general;
-        float D = 1e-7f;
+    for (int v = 0; v < NV; ++v) {
+        float Dv;
+        cell_G(lds + v * 128, L, bb, self[v], gx[v], gy[v], Dv);
+        if (v == 0) D = Dv;
+    }
+    if (!L.general) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const float rh = __builtin_amdgcn_rcpf(bb.h[d]);
-            const int sL = 2 * d, sR = 2 * d + 1;
-            const int tyL = bb.type[sL], tyR = bb.type[sR];
-            const float qL = L.edge[sL] ? side_q(tyL) : 0.5f;
-            const float qR = L.edge[sR] ? side_q(tyR) : 0.5f;
-            const bool twoL = L.edge[sL] && tyL == SIDE_FINE;
-            const bool twoR = L.edge[sR] && tyR == SIDE_FINE;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                float l0, l1, r0, r1;
-                nbv(tile + v * 64, halo + v * 64, lane, L, sL, l0, l1);
-                nbv(tile + v * 64, halo + v * 64, lane, L, sR, r0, r1);
-                const float uc = self[r][v];
-                const float uLm = twoL ? 0.5f * (l0 + l1) : l0;
-                const float uRm = twoR ? 0.5f * (r0 + r1) : r0;
-                // at_faces with weights: face = (1-q)*u_self + q*u_nb
-                const float fr = uc + qR * (uRm - uc);
-                const float fl = uc + qL * (uLm - uc);
-                if (store) stg(G + (size_t)(d * NV + v) * nc, c, (fr - fl) * rh);
-                if (v == 0) {
-                    const float dr = uRm - uc, dl = uc - uLm;
-                    const float ar = twoR ? 0.5f * (fabsf(r0 - uc) + fabsf(r1 - uc)) : fabsf(dr);
-                    const float al = twoL ? 0.5f * (fabsf(uc - l0) + fabsf(uc - l1)) : fabsf(dl);
-                    const float gg = (dr - dl) * rh;
-                    const float ugg = (ar + al) * rh;
-                    D = fmaxf(D, (1e-7f + fabsf(gg)) * __builtin_amdgcn_rcpf(1e-7f + ugg));
-                }
-            }
+        for (int v = 0; v < NV; ++v) {
+            stg(G + (size_t)v * nc, c, gx[v]);
+            stg(G + (size_t)(NV + v) * nc, c, gy[v]);
         }
-        if (store) stg(G + (size_t)(2 * NV) * nc, c, D);
+        stg(G + (size_t)(2 * NV) * nc, c, D);
     }
 }
 
@@ -226,7 +152,7 @@ __device__ __forceinline__ void passA(const BlockDesc2* __restrict__ blocks, int
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float minmod(float a, float b) {
     // min(|a|,|b|)*(sign a + sign b)/2
-    float m = fminf(fabsf(a), fabsf(b));
+    const float m = fminf(fabsf(a), fabsf(b));
     return (a * b > 0.0f) ? copysignf(m, a) : 0.0f;
 }
 
@@ -249,154 +175,116 @@ __device__ __forceinline__ float adv_flux(float ua, float ub, float ga, float gb
     return 0.5f * ((uL + uR) * Cf + fabsf(Cf) * (uL - uR));
 }
 
-// LDS per wave and block: tile[6][64] (u, D, gx, gy, Cx, Cy), halo[4][64] (u, D, gN, CN), extra[64]
-#define BLK2_PASSB_LDS (11 * 64)
-
-template <int BPW>
-__device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks, int32_t blk0, int32_t nblk,
-                                          uint32_t nc, const float* __restrict__ u, const float* __restrict__ C,
-                                          uint32_t ldc, const float* __restrict__ G, float* __restrict__ ud, float* lds,
-                                          int lane) {
-    const BlockDesc2* b[BPW];
-    bool valid[BPW];
-    float sv[BPW][6], hvv[BPW][4];
-    const int hs = lane >> 4;  // side of this lane's halo slot
-#pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        valid[r] = blk0 + r < nblk;
-        b[r] = blocks + (valid[r] ? blk0 + r : nblk - 1);
-    }
-#pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        const int32_t hidx = halo_cell(*b[r], hs, (lane >> 1) & 7, lane & 1);
-        const uint32_t c = (uint32_t)b[r]->base + lane;
-        sv[r][0] = ldg(u, c);
-        sv[r][1] = ldg(G + (size_t)2 * nc, c);
-        sv[r][2] = ldg(G, c);
-        sv[r][3] = ldg(G + nc, c);
-        sv[r][4] = ldg(C, c);
-        sv[r][5] = ldg(C + ldc, c);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#ifdef IBH_ABLATE_NOHALO
-        if (false) {
-#else
-        if (hidx >= 0) {
-#endif
-            const uint32_t hi = (uint32_t)hidx;
-            const int dn = hs >> 1;  // normal dim of the slot's side
-            a0 = ldg(u, hi);
-            a1 = ldg(G + (size_t)2 * nc, hi);
-            a2 = ldg(G + (size_t)dn * nc, hi);
-            a3 = ldg(C + (size_t)dn * ldc, hi);
-        }
-        hvv[r][0] = a0;
-        hvv[r][1] = a1;
-        hvv[r][2] = a2;
-        hvv[r][3] = a3;
-    }
-#pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        float* base = lds + r * BLK2_PASSB_LDS;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) base[q * 64 + lane] = sv[r][q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) base[384 + q * 64 + lane] = hvv[r][q];
-    }
-    wave_lds_sync();
-
-    float FRr[BPW], FTr[BPW];
-#pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        const BlockDesc2& bb = *b[r];
-        const Lane L = lane_info(bb, lane);
-        float* base = lds + r * BLK2_PASSB_LDS;
-        const float *tU = base, *tD = base + 64, *tG = base + 128, *tC = base + 256;
-        const float *hU = base + 384, *hD = base + 448, *hG = base + 512, *hC = base + 576;
-        float* ex = base + 640;
-        const float uc = sv[r][0], Dc = sv[r][1], gxc = sv[r][2], gyc = sv[r][3], cxc = sv[r][4], cyc = sv[r][5];
-        const float hx = bb.h[0], hy = bb.h[1];
-        const float rhx = __builtin_amdgcn_rcpf(hx), rhy = __builtin_amdgcn_rcpf(hy);
-        // ---- main pass: right (x+) and top (y+) face of every cell, sub-face 0 on block sides
-        {
-            float ub, gb, Db, Cb, d1;
-            nbv(tU, hU, lane, L, 1, ub, d1);
-            nbv(tD, hD, lane, L, 1, Db, d1);
-            nbv(tG, hG, lane, L, 1, gb, d1);
-            nbv(tC, hC, lane, L, 1, Cb, d1);
-            const int ty = bb.type[1];
-            const float rt = L.edge[1] ? side_ratio(ty) : 1.0f;
-            const float q = L.edge[1] ? side_q(ty) : 0.5f;
-            FRr[r] = adv_flux(uc, ub, gxc, gb, Dc, Db, cxc, Cb, 0.5f * hx, 0.5f * hx * rt, 2.0f * rhx * q);
-        }
-        {
-            float ub, gb, Db, Cb, d1;
-            nbv(tU, hU, lane, L, 3, ub, d1);
-            nbv(tD, hD, lane, L, 3, Db, d1);
-            nbv(tG + 64, hG, lane, L, 3, gb, d1);
-            nbv(tC + 64, hC, lane, L, 3, Cb, d1);
-            const int ty = bb.type[3];
-            const float rt = L.edge[3] ? side_ratio(ty) : 1.0f;
-            const float q = L.edge[3] ? side_q(ty) : 0.5f;
-            FTr[r] = adv_flux(uc, ub, gyc, gb, Dc, Db, cyc, Cb, 0.5f * hy, 0.5f * hy * rt, 2.0f * rhy * q);
-        }
-        // ---- extra pass: faces no lane owns.  role lane = 8*g + t
-        //   g=0: left side sub-face 0      g=1: bottom side sub-face 0
-        //   g=2: left side sub-face 1      g=3: bottom side sub-face 1     (FINE sides only)
-        //   g=4: right side sub-face 1     g=5: top side sub-face 1        (FINE sides only)
-        {
-            const int g = lane >> 3, t = lane & 7;
-            const int side = (g == 0 || g == 2) ? 0 : (g == 1 || g == 3) ? 2 : (g == 4) ? 1 : 3;
-            const int k = g >= 2 ? 1 : 0;
-            const int ty = bb.type[side & 3];
-            const bool active = g < 2 || (g < 6 && ty == SIDE_FINE);
-            float X = 0.0f;
-            if (active) {
-                const int dn = side >> 1;
-                const int pos = (side == 0) ? 8 * t : (side == 1) ? 7 + 8 * t : (side == 2) ? t : t + 56;
-                const int slot = (side * 8 + t) * 2 + k;
-                const float us = tU[pos], Ds = tD[pos], gs = tG[dn * 64 + pos], Cs = tC[dn * 64 + pos];
-                const float uh = hU[slot], Dh = hD[slot], gh = hG[slot], Ch = hC[slot];
-                const float h = dn ? hy : hx, rh = dn ? rhy : rhx;
-                const float rt = side_ratio(ty), q = side_q(ty);
-                const float dS = 0.5f * h, dH = 0.5f * h * rt, inv = 2.0f * rh * q;
-                if ((side & 1) == 0)  // low side: halo cell is the owner (left), this cell the neighbour
-                    X = adv_flux(uh, us, gh, gs, Dh, Ds, Ch, Cs, dH, dS, inv);
-                else
-                    X = adv_flux(us, uh, gs, gh, Ds, Dh, Cs, Ch, dS, dH, inv);
-            }
-            ex[lane] = X;
-        }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-        const BlockDesc2& bb = *b[r];
-        const Lane L = lane_info(bb, lane);
-        const float* ex = lds + r * BLK2_PASSB_LDS + 640;
-        const float rhx = __builtin_amdgcn_rcpf(bb.h[0]), rhy = __builtin_amdgcn_rcpf(bb.h[1]);
-        float FR = FRr[r], FT = FTr[r];
-        // interior faces: left flux = right flux of lane-1, bottom flux = top flux of lane-8
-        float FL = __shfl_up(FR, 1, 64);
-        float FB = __shfl_up(FT, 8, 64);
-        if (L.edge[0]) {
-            FL = ex[L.j];
-            if (bb.type[0] == SIDE_FINE) FL = 0.5f * (FL + ex[16 + L.j]);
-        }
-        if (L.edge[2]) {
-            FB = ex[8 + L.i];
-            if (bb.type[2] == SIDE_FINE) FB = 0.5f * (FB + ex[24 + L.i]);
-        }
-        if (L.edge[1] && bb.type[1] == SIDE_FINE) FR = 0.5f * (FR + ex[32 + L.j]);
-        if (L.edge[3] && bb.type[3] == SIDE_FINE) FT = 0.5f * (FT + ex[40 + L.i]);
-        const float res = -((FR - FL) * rhx) - ((FT - FB) * rhy);
-        if (valid[r] && !L.general) stg(ud, (uint32_t)bb.base + lane, res);
-    }
+// role of lane r in the extra pass: group g = r>>3, boundary cell t = r&7
+//   g=0: left side sub-face 0   g=1: bottom sub-face 0   g=2: left sub-face 1   g=3: bottom sub-face 1
+//   g=4: right side sub-face 1  g=5: top sub-face 1      (g=6,7 repeat g=4,5; unused)
+struct Role {
+    int side, dn, pos, slot;
+    bool low;
+};
+__device__ __forceinline__ Role role_of(int lane) {
+    Role R;
+    const int g = lane >> 3, t = lane & 7;
+    // side = 2*dn + high;  g odd -> y sides, g >= 4 -> high sides
+    R.dn = g & 1;
+    const int high = (g >> 2) & 1;
+    R.side = 2 * R.dn + high;
+    const int k = g >= 2 ? 1 : 0;
+    R.low = high == 0;
+    // boundary cell t of the side: x sides -> column 0 / 7, row t; y sides -> row 0 / 7, column t
+    const int stride = R.dn ? 1 : 8;
+    const int offs = high * (R.dn ? 56 : 7);
+    R.pos = t * stride + offs;
+    R.slot = 64 + (R.side * 8 + t) * 2 + k;
+    return R;
 }
 
+// LDS per wave: 6 fields x [tile | halo] : U, D, GX, GY, CX, CY (halo of GX/CX meaningful on x sides,
+// of GY/CY on y sides) + extra[64]
+#define BLK2_PASSB_LDS (6 * 128 + 64)
+
+__device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                          int32_t blk, uint32_t nc, const float* __restrict__ u,
+                                          const float* __restrict__ C, uint32_t ldc, const float* __restrict__ G,
+                                          float* __restrict__ ud, float* lds, int lane) {
+    const BlockDesc2 bb = blocks[blk];  // by value: wave-uniform, lives in SGPRs, no per-lane descriptor loads
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
+    const uint32_t c = (uint32_t)bb.base + lane;
+    float* fU = lds;
+    float* fD = lds + 128;
+    float* fGX = lds + 256;
+    float* fGY = lds + 384;
+    float* fCX = lds + 512;
+    float* fCY = lds + 640;
+    float* ex = lds + 768;
+    const float* Gs = G + (size_t)2 * nc;
+    const float uc = ldg(u, c), Dc = ldg(Gs, c), gxc = ldg(G, c), gyc = ldg(G + nc, c);
+    const float cxc = ldg(C, c), cyc = ldg(C + ldc, c);
+    // halo slot of this lane: sides 0,1 need the x-gradient / Cx of the neighbour, sides 2,3 the y ones
+    const int dn = lane >> 5;
+#ifdef IBH_ABLATE_NOHALO
+    const float hu = 0.f, hD = 0.f, hg = 0.f, hc = 0.f;
+#else
+    const float hu = ldg(u, hidx), hD = ldg(Gs, hidx);
+    const float hg = ldg(G + (size_t)dn * nc, hidx);
+    const float hc = ldg(C + (size_t)dn * ldc, hidx);
+#endif
+    fU[lane] = uc;
+    fD[lane] = Dc;
+    fGX[lane] = gxc;
+    fGY[lane] = gyc;
+    fCX[lane] = cxc;
+    fCY[lane] = cyc;
+    fU[64 + lane] = hu;
+    fD[64 + lane] = hD;
+    fGX[64 + lane] = hg;  // slots of sides 2,3 hold gy here; they are only read through fGY below
+    fGY[64 + lane] = hg;
+    fCX[64 + lane] = hc;
+    fCY[64 + lane] = hc;
+    const Lane L = lane_info(bb, lane);
+    wave_lds_sync();
+
+    const float hx = bb.h[0], hy = bb.h[1], rhx = bb.rh[0], rhy = bb.rh[1];
+    // ---- main pass: right (x+) and top (y+) face of every cell, sub-face 0 on block sides
+    float FR = adv_flux(uc, nb1(fU, L, 1), gxc, nb1(fGX, L, 1), Dc, nb1(fD, L, 1), cxc, nb1(fCX, L, 1), 0.5f * hx,
+                        0.5f * hx * L.rt[1], 2.0f * rhx * L.q[1]);
+    float FT = adv_flux(uc, nb1(fU, L, 3), gyc, nb1(fGY, L, 3), Dc, nb1(fD, L, 3), cyc, nb1(fCY, L, 3), 0.5f * hy,
+                        0.5f * hy * L.rt[3], 2.0f * rhy * L.q[3]);
+    // ---- extra pass: faces no lane owns
+    {
+        const Role R = role_of(lane);
+        const float* fG = R.dn ? fGY : fGX;
+        const float* fC = R.dn ? fCY : fCX;
+        const float us = fU[R.pos], Ds = fD[R.pos], gs = fG[R.pos], Cs = fC[R.pos];
+        const float uh = fU[R.slot], Dh = fD[R.slot], gh = fG[R.slot], Ch = fC[R.slot];
+        const float h = R.dn ? hy : hx, rh = R.dn ? rhy : rhx;
+        const float rt = sel4(R.side, bb.rt[0], bb.rt[1], bb.rt[2], bb.rt[3]);
+        const float q = sel4(R.side, bb.q[0], bb.q[1], bb.q[2], bb.q[3]);
+        const float dS = 0.5f * h, dH = 0.5f * h * rt, inv = 2.0f * rh * q;
+        // low side: the halo cell is the owner (left), this cell the neighbour
+        const float X = adv_flux(R.low ? uh : us, R.low ? us : uh, R.low ? gh : gs, R.low ? gs : gh, R.low ? Dh : Ds,
+                                 R.low ? Ds : Dh, R.low ? Ch : Cs, R.low ? Cs : Ch, R.low ? dH : dS, R.low ? dS : dH,
+                                 inv);
+        ex[lane] = X;
+    }
+    // interior faces: left flux = right flux of lane-1, bottom flux = top flux of lane-8
+    const float FLs = __shfl_up(FR, 1, 64);
+    const float FBs = __shfl_up(FT, 8, 64);
+    wave_lds_sync();
+    const float eL = 0.5f * (ex[L.j] + ex[16 + L.j]), eB = 0.5f * (ex[8 + L.i] + ex[24 + L.i]);
+    const float eR = 0.5f * (FR + ex[32 + L.j]), eT = 0.5f * (FT + ex[40 + L.i]);
+    const float FL = L.edge[0] ? eL : FLs;
+    const float FB = L.edge[2] ? eB : FBs;
+    FR = L.edge[1] ? eR : FR;
+    FT = L.edge[3] ? eT : FT;
+    const float res = -((FR - FL) * rhx) - ((FT - FB) * rhy);
+    if (!L.general) stg(ud, c, res);
+}
 
 // ------------------------------------------------------------------------------------------
 // pass B, Euler: MUSCL(high_order) on P = [p T u v] with the pressure sensor, HLL flux
 // (cfd.jl:459-508, Float32 here -- the reference promotes the last combine to Float64), Green-Gauss.
+// Own-cell gradients are recomputed from the staged P tile (8 fewer field loads than reading them back).
 // ------------------------------------------------------------------------------------------
 struct Gas {
     float R, gamma;
@@ -413,13 +301,12 @@ __device__ __forceinline__ void euler_side(const float* P, int dn, const Gas& ga
     Q[1] = E;
     Q[2] = rho * P[2];
     Q[3] = rho * P[3];
-    un = P[2 + dn];
+    un = dn ? P[3] : P[2];
     a = sqrtf(gas.gamma * gas.R * T);
     F[0] = Q[0] * un;
     F[1] = (Q[1] + p) * un;
-    F[2] = Q[2] * un;
-    F[3] = Q[3] * un;
-    F[2 + dn] += p;
+    F[2] = Q[2] * un + (dn ? 0.0f : p);
+    F[3] = Q[3] * un + (dn ? p : 0.0f);
 }
 
 // a = left/owner cell, b = right/neighbour; Pa/Pb primitive states, ga/gb their gradients along the face normal
@@ -448,127 +335,116 @@ __device__ __forceinline__ void euler_flux(const float* Pa, const float* Pb, con
     for (int v = 0; v < 4; ++v) F[v] = (SL * FL[v] - SR * FR[v] + SR * SL * (QR[v] - QL[v])) * rs;
 }
 
-// LDS per wave: tiles P[4], D, gx[4], gy[4] (13 x 64); halos P[4], D, gN[4] (9 x 64); extra flux[4] (4 x 64)
-#define BLK2_EULER_LDS (26 * 64)
+// LDS per wave: P[4], D, GX[4], GY[4] as [tile | halo] fields (13 x 128) + extra flux[4][64]
+#define BLK2_EULER_LDS (13 * 128 + 4 * 64)
 
-__device__ __forceinline__ void passB_euler(const BlockDesc2* __restrict__ blocks, int32_t blk, uint32_t nc,
-                                            const float* __restrict__ P, uint32_t ldp, const float* __restrict__ G,
-                                            float* __restrict__ Rr, uint32_t ldr, Gas gas, float* lds, int lane) {
-    const BlockDesc2& bb = blocks[blk];
-    const Lane L = lane_info(bb, lane);
-    const int hs = lane >> 4;
-    const int32_t hidx = halo_cell(bb, hs, (lane >> 1) & 7, lane & 1);
-    float* tP = lds;              // [4][64]
-    float* tD = lds + 4 * 64;     // [64]
-    float* tG = lds + 5 * 64;     // [2][4][64]
-    float* hP = lds + 13 * 64;    // [4][64]
-    float* hD = lds + 17 * 64;
-    float* hG = lds + 18 * 64;    // [4][64] gradient along the slot's side normal
-    float* ex = lds + 22 * 64;    // [4][64]
+__device__ __forceinline__ void passB_euler(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                            int32_t blk, uint32_t nc, const float* __restrict__ P, uint32_t ldp,
+                                            const float* __restrict__ G, float* __restrict__ Rr, uint32_t ldr, Gas gas,
+                                            float* lds, int lane) {
+    const BlockDesc2 bb = blocks[blk];  // by value: wave-uniform, lives in SGPRs, no per-lane descriptor loads
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
     const uint32_t c = (uint32_t)bb.base + lane;
+    float* fP = lds;             // [4][128]
+    float* fD = lds + 4 * 128;   // [128]
+    float* fGX = lds + 5 * 128;  // [4][128]
+    float* fGY = lds + 9 * 128;  // [4][128]
+    float* ex = lds + 13 * 128;  // [4][64]
+    const int dnl = lane >> 5;
     float Pc[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         Pc[v] = ldg(P + (size_t)v * ldp, c);
-        tP[v * 64 + lane] = Pc[v];
+        fP[v * 128 + lane] = Pc[v];
+        fP[v * 128 + 64 + lane] = ldg(P + (size_t)v * ldp, hidx);
+        const float hg = ldg(G + (size_t)(dnl * 4 + v) * nc, hidx);
+        fGX[v * 128 + 64 + lane] = hg;
+        fGY[v * 128 + 64 + lane] = hg;
     }
-    {
-        const int dn = hs >> 1;
-        const bool ok = hidx >= 0;
-        const uint32_t hi = ok ? (uint32_t)hidx : 0u;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            hP[v * 64 + lane] = ok ? ldg(P + (size_t)v * ldp, hi) : 0.0f;
-            hG[v * 64 + lane] = ok ? ldg(G + (size_t)(dn * 4 + v) * nc, hi) : 0.0f;
-        }
-        hD[lane] = ok ? ldg(G + (size_t)8 * nc, hi) : 0.0f;
-    }
+    fD[64 + lane] = ldg(G + (size_t)8 * nc, hidx);
+    const Lane L = lane_info(bb, lane);
     wave_lds_sync();
     // own-cell gradients of the 4 primitives and the pressure sensor
     float gxc[4], gyc[4], Dc = 1e-7f;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         float Dv;
-        cell_G(tP + v * 64, hP + v * 64, lane, L, bb, Pc[v], gxc[v], gyc[v], Dv);
+        cell_G(fP + v * 128, L, bb, Pc[v], gxc[v], gyc[v], Dv);
         if (v == 0) Dc = Dv;
-        if (L.general) {  // face-list side: values written by the face-list body of pass A
-            gxc[v] = ldg(G + (size_t)v * nc, c);
-            gyc[v] = ldg(G + (size_t)(4 + v) * nc, c);
-            if (v == 0) Dc = ldg(G + (size_t)8 * nc, c);
-        }
-        tG[v * 64 + lane] = gxc[v];
-        tG[(4 + v) * 64 + lane] = gyc[v];
     }
-    tD[lane] = Dc;
-    wave_lds_sync();
-
-    const float hx = bb.h[0], hy = bb.h[1];
-    const float rhx = __builtin_amdgcn_rcpf(hx), rhy = __builtin_amdgcn_rcpf(hy);
-    float FR[4], FT[4];
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        const int s = 2 * d + 1;
-        float Pb[4], gb[4], Db, d1;
+    if (L.general) {  // cells of a face-list side: their values were written by the face-list body of pass A
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            nbv(tP + v * 64, hP + v * 64, lane, L, s, Pb[v], d1);
-            nbv(tG + (d * 4 + v) * 64, hG + v * 64, lane, L, s, gb[v], d1);
+            gxc[v] = ldg(G + (size_t)v * nc, c);
+            gyc[v] = ldg(G + (size_t)(4 + v) * nc, c);
         }
-        nbv(tD, hD, lane, L, s, Db, d1);
-        const int ty = bb.type[s];
-        const float rt = L.edge[s] ? side_ratio(ty) : 1.0f;
-        const float q = L.edge[s] ? side_q(ty) : 0.5f;
-        const float h = d ? hy : hx, rh = d ? rhy : rhx;
-        euler_flux(Pc, Pb, d ? gyc : gxc, gb, Dc, Db, 0.5f * h, 0.5f * h * rt, 2.0f * rh * q, d, gas, d ? FT : FR);
+        Dc = ldg(G + (size_t)8 * nc, c);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        fGX[v * 128 + lane] = gxc[v];
+        fGY[v * 128 + lane] = gyc[v];
+    }
+    fD[lane] = Dc;
+    wave_lds_sync();
+
+    const float hx = bb.h[0], hy = bb.h[1], rhx = bb.rh[0], rhy = bb.rh[1];
+    float FR[4], FT[4];
+    {
+        float Pb[4], gb[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            Pb[v] = nb1(fP + v * 128, L, 1);
+            gb[v] = nb1(fGX + v * 128, L, 1);
+        }
+        euler_flux(Pc, Pb, gxc, gb, Dc, nb1(fD, L, 1), 0.5f * hx, 0.5f * hx * L.rt[1], 2.0f * rhx * L.q[1], 0, gas, FR);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            Pb[v] = nb1(fP + v * 128, L, 3);
+            gb[v] = nb1(fGY + v * 128, L, 3);
+        }
+        euler_flux(Pc, Pb, gyc, gb, Dc, nb1(fD, L, 3), 0.5f * hy, 0.5f * hy * L.rt[3], 2.0f * rhy * L.q[3], 1, gas, FT);
     }
     {   // extra pass (same role map as the advection kernel)
-        const int g = lane >> 3, t = lane & 7;
-        const int side = (g == 0 || g == 2) ? 0 : (g == 1 || g == 3) ? 2 : (g == 4) ? 1 : 3;
-        const int k = g >= 2 ? 1 : 0;
-        const int ty = bb.type[side & 3];
-        const bool active = g < 2 || (g < 6 && ty == SIDE_FINE);
-        float X[4] = {0.f, 0.f, 0.f, 0.f};
-        if (active) {
-            const int dn = side >> 1;
-            const int pos = (side == 0) ? 8 * t : (side == 1) ? 7 + 8 * t : (side == 2) ? t : t + 56;
-            const int slot = (side * 8 + t) * 2 + k;
-            float Ps[4], Ph[4], gs[4], gh[4];
+        const Role R = role_of(lane);
+        const float* fG = R.dn ? fGY : fGX;
+        float Pa[4], Pb[4], ga[4], gb[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                Ps[v] = tP[v * 64 + pos];
-                gs[v] = tG[(dn * 4 + v) * 64 + pos];
-                Ph[v] = hP[v * 64 + slot];
-                gh[v] = hG[v * 64 + slot];
-            }
-            const float Ds = tD[pos], Dh = hD[slot];
-            const float h = dn ? hy : hx, rh = dn ? rhy : rhx;
-            const float rt = side_ratio(ty), q = side_q(ty);
-            const float dS = 0.5f * h, dH = 0.5f * h * rt, inv = 2.0f * rh * q;
-            if ((side & 1) == 0)
-                euler_flux(Ph, Ps, gh, gs, Dh, Ds, dH, dS, inv, dn, gas, X);
-            else
-                euler_flux(Ps, Ph, gs, gh, Ds, Dh, dS, dH, inv, dn, gas, X);
+        for (int v = 0; v < 4; ++v) {
+            const float ps = fP[v * 128 + R.pos], ph = fP[v * 128 + R.slot];
+            const float gs = fG[v * 128 + R.pos], gh = fG[v * 128 + R.slot];
+            Pa[v] = R.low ? ph : ps;
+            Pb[v] = R.low ? ps : ph;
+            ga[v] = R.low ? gh : gs;
+            gb[v] = R.low ? gs : gh;
         }
+        const float Ds = fD[R.pos], Dh = fD[R.slot];
+        const float h = R.dn ? hy : hx, rh = R.dn ? rhy : rhx;
+        const float rt = sel4(R.side, bb.rt[0], bb.rt[1], bb.rt[2], bb.rt[3]);
+        const float q = sel4(R.side, bb.q[0], bb.q[1], bb.q[2], bb.q[3]);
+        const float dS = 0.5f * h, dH = 0.5f * h * rt, inv = 2.0f * rh * q;
+        float X[4];
+        euler_flux(Pa, Pb, ga, gb, R.low ? Dh : Ds, R.low ? Ds : Dh, R.low ? dH : dS, R.low ? dS : dH, inv, R.dn, gas,
+                   X);
 #pragma unroll
         for (int v = 0; v < 4; ++v) ex[v * 64 + lane] = X[v];
+    }
+    float FLs[4], FBs[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        FLs[v] = __shfl_up(FR[v], 1, 64);
+        FBs[v] = __shfl_up(FT[v], 8, 64);
     }
     wave_lds_sync();
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        float fr = FR[v], ft = FT[v];
-        float fl = __shfl_up(fr, 1, 64);
-        float fb = __shfl_up(ft, 8, 64);
         const float* e = ex + v * 64;
-        if (L.edge[0]) {
-            fl = e[L.j];
-            if (bb.type[0] == SIDE_FINE) fl = 0.5f * (fl + e[16 + L.j]);
-        }
-        if (L.edge[2]) {
-            fb = e[8 + L.i];
-            if (bb.type[2] == SIDE_FINE) fb = 0.5f * (fb + e[24 + L.i]);
-        }
-        if (L.edge[1] && bb.type[1] == SIDE_FINE) fr = 0.5f * (fr + e[32 + L.j]);
-        if (L.edge[3] && bb.type[3] == SIDE_FINE) ft = 0.5f * (ft + e[40 + L.i]);
+        const float eL = 0.5f * (e[L.j] + e[16 + L.j]), eB = 0.5f * (e[8 + L.i] + e[24 + L.i]);
+        const float eR = 0.5f * (FR[v] + e[32 + L.j]), eT = 0.5f * (FT[v] + e[40 + L.i]);
+        const float fl = L.edge[0] ? eL : FLs[v];
+        const float fb = L.edge[2] ? eB : FBs[v];
+        const float fr = L.edge[1] ? eR : FR[v];
+        const float ft = L.edge[3] ? eT : FT[v];
         const float res = -((fr - fl) * rhx) - ((ft - fb) * rhy);
         if (!L.general) stg(Rr + (size_t)v * ldr, c, res);
     }

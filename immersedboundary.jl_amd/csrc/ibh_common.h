@@ -24,7 +24,14 @@ struct BlockDesc2 {  // 2-D
     int32_t nb[4][2];
     int32_t sub[4];
     float h[2];
+    float rh[2];   // 1/h
+    float q[4];    // per side: 1/(1 + h_nb/h) = 1/2 (same, mirror), 1/3 (coarse), 2/3 (fine)
+    float rt[4];   // per side: h_nb/h = 1, 2, 1/2
 };
+// Per block: 64 halo slots, slot = (side*8 + t)*2 + k -> local id of the k-th neighbour cell across `side`
+// of boundary cell t.  Always a valid cell: single-face sides repeat sub-face 0 in slot k=1 (so that
+// averaging the two sub-faces is exact), MIRROR sides name the boundary cell itself, GENERAL sides too
+// (their lanes are handled by the face-list body and never stored).
 
 struct DimData {
     int32_t nf = 0;
@@ -46,6 +53,7 @@ struct ibh_part {
     int32_t nblk = 0;            // full blocks handled by the fast kernels
     int32_t nA1 = 0, nB1 = 0;    // blocks [0,nA1): pass A independent of skirt data; [0,nB1): pass B too
     BlockDesc2* blocks2 = nullptr;
+    int32_t* htab = nullptr;     // [nblk][64] halo cell table, same order as blocks2
     int32_t n_irr = 0;           // cells handled by the general kernels when the fast path is on
     int32_t* irr_cells = nullptr;
     int64_t info[8] = {0};
@@ -100,7 +108,7 @@ struct HostPartView {
 };
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
                          std::vector<int32_t>& irr_cells, int64_t* info, const int32_t* image_in_domain,
-                         int32_t n_image, int32_t* n_phase1);
+                         int32_t n_image, int32_t* n_phase1, std::vector<int32_t>& htab);
 
 static inline int ibh_grid(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;

@@ -213,31 +213,6 @@ __device__ __forceinline__ int32_t xcd_remap(int32_t wg, int32_t nwg) {
 #define IBH_BPW 1  // blocks per wave in the tuned block path (2-4 measured: no gain, see profiles/r1_v1)
 #endif
 
-// Local id of the k-th neighbour cell across side s for boundary cell t, or -1 (mirror/general/none).
-__device__ __forceinline__ int32_t halo_cell(const BlockDesc2& b, int s, int t, int k) {
-    int ty = b.type[s];
-    // position of the opposite edge inside the neighbour block
-    // s=0 (x-): neighbour column 7; s=1 (x+): column 0; s=2 (y-): row 7; s=3 (y+): row 0
-    int tt;
-    int32_t base;
-    if (ty == SIDE_SAME) {
-        if (k) return -1;
-        tt = t;
-        base = b.nb[s][0];
-    } else if (ty == SIDE_COARSE) {
-        if (k) return -1;
-        tt = 4 * b.sub[s] + (t >> 1);
-        base = b.nb[s][0];
-    } else if (ty == SIDE_FINE) {
-        tt = 2 * (t & 3) + k;
-        base = b.nb[s][t >> 2];
-    } else {
-        return -1;
-    }
-    int pos = (s == 0) ? 7 + 8 * tt : (s == 1) ? 8 * tt : (s == 2) ? tt + 56 : tt;
-    return base + pos;
-}
-
 struct Nb {  // data of one neighbour direction for one lane
     float v0, v1;  // neighbour value(s)
     float hn;      // neighbour spacing along the face normal
@@ -273,28 +248,23 @@ __device__ __forceinline__ float stage_field(const float* __restrict__ f, const 
     return self;
 }
 
-__device__ __forceinline__ void lane_halo_role(const BlockDesc2& b, int lane, int32_t& hc_idx, int32_t& mirror_idx,
-                                               float& hn_slot) {
-    // lane -> halo slot (s, t, k): slot index = (s*8 + t)*2 + k
-    int k = lane & 1, t = (lane >> 1) & 7, s = lane >> 4;
-    hc_idx = halo_cell(b, s, t, k);
+// lane -> halo slot (s, t, k) = lane; its cell comes from the per-block table built by ibh_analyze.cpp
+// (single-face sides repeat sub-face 0 in slot k=1, MIRROR sides name the boundary cell itself).
+__device__ __forceinline__ void lane_halo_role(const int32_t* __restrict__ htab, int32_t blk, int lane,
+                                               int32_t& hc_idx, int32_t& mirror_idx) {
+    hc_idx = htab[(size_t)blk * 64 + lane];
     mirror_idx = -1;
-    if (b.type[s] == SIDE_MIRROR && k == 0) {
-        int own = (s == 0) ? 8 * t : (s == 1) ? 7 + 8 * t : (s == 2) ? t : t + 56;
-        mirror_idx = b.base + own;
-    }
-    (void)hn_slot;
 }
 
 template <int NV>
-__device__ __forceinline__ void passA_block2(const BlockDesc2* __restrict__ blocks, int32_t blk, const float* spacing,
+__device__ __forceinline__ void passA_block2(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                             int32_t blk, const float* spacing,
                                              int64_t nc, const float* __restrict__ u, int64_t ldu, float* __restrict__ G,
                                              float* lds, int lane) {
     const BlockDesc2& b = blocks[blk];
     const int i = lane & 7, j = lane >> 3;
     int32_t hc_idx, mirror_idx;
-    float dummy;
-    lane_halo_role(b, lane, hc_idx, mirror_idx, dummy);
+    lane_halo_role(htab, blk, lane, hc_idx, mirror_idx);
     float* tile = lds;         // [NV][64]
     float* halo = lds + NV * 64;  // [NV][64]
     float self[NV];
@@ -360,15 +330,15 @@ __device__ __forceinline__ void passA_block2(const BlockDesc2* __restrict__ bloc
     (void)spacing;
 }
 
-__device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ blocks, int32_t blk, int64_t nc,
+__device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ blocks,
+                                                 const int32_t* __restrict__ htab, int32_t blk, int64_t nc,
                                                  const float* __restrict__ u, const float* __restrict__ C, int64_t ldc,
                                                  const float* __restrict__ G, float* __restrict__ ud, float* lds,
                                                  int lane) {
     const BlockDesc2& b = blocks[blk];
     const int i = lane & 7, j = lane >> 3;
     int32_t hc_idx, mirror_idx;
-    float dummy;
-    lane_halo_role(b, lane, hc_idx, mirror_idx, dummy);
+    lane_halo_role(htab, blk, lane, hc_idx, mirror_idx);
     // fields: 0:u 1:D 2:gx 3:gy 4:Cx 5:Cy   (halo of gx/Cx only meaningful on x sides, gy/Cy on y sides;
     // every slot is gathered anyway: one instruction per field)
     float* tile = lds;
@@ -430,21 +400,19 @@ namespace {
 template <int ND, int NV, bool EXACT>
 __global__ __launch_bounds__(256) void k_passA(PartView p, const float* __restrict__ u, int64_t ldu,
                                                float* __restrict__ G, const BlockDesc2* __restrict__ blocks,
-                                               int32_t nblk, int32_t nwg_fast, const int32_t* __restrict__ cells,
-                                               int32_t ncells) {
-    // `blocks`/`nblk` describe the sub-range of the block table this launch covers
-    constexpr int BPW = EXACT ? 1 : IBH_BPW;
-    __shared__ float lds[WPB * BPW * NV * 128];
+                                               const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg_fast,
+                                               const int32_t* __restrict__ cells, int32_t ncells) {
+    // `blocks`/`htab`/`nblk` describe the sub-range of the block table this launch covers
+    __shared__ float lds[WPB * NV * 128];
     if ((int32_t)blockIdx.x < nwg_fast) {
         if constexpr (ND == 2) {
             int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            int32_t blk = __builtin_amdgcn_readfirstlane((xcd_remap(blockIdx.x, nwg_fast) * WPB + wave) * BPW);
+            int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg_fast) * WPB + wave);
             if (blk < nblk) {
                 if constexpr (EXACT)
-                    passA_block2<NV>(blocks, blk, p.spacing, p.nc, u, ldu, G, lds + wave * NV * 128, lane);
+                    passA_block2<NV>(blocks, htab, blk, p.spacing, p.nc, u, ldu, G, lds + wave * NV * 128, lane);
                 else
-                    blk2::passA<NV, BPW>(blocks, blk, nblk, (uint32_t)p.nc, u, (uint32_t)ldu, G,
-                                         lds + wave * BPW * NV * 128, lane);
+                    blk2::passA<NV>(blocks, htab, blk, (uint32_t)p.nc, u, (uint32_t)ldu, G, lds + wave * NV * 128, lane);
             }
         }
         return;
@@ -458,22 +426,21 @@ __global__ __launch_bounds__(256) void k_passA(PartView p, const float* __restri
 template <int ND, bool EXACT>
 __global__ __launch_bounds__(256) void k_passB_adv(PartView p, const float* __restrict__ u, const float* __restrict__ C,
                                                    int64_t ldc, const float* __restrict__ G, float* __restrict__ ud,
-                                                   const BlockDesc2* __restrict__ blocks, int32_t nblk,
-                                                   int32_t nwg_fast, const int32_t* __restrict__ cells,
-                                                   int32_t ncells) {
-    constexpr int BPW = EXACT ? 1 : IBH_BPW;
-    constexpr int LDSW = EXACT ? 6 * 128 : BPW * BLK2_PASSB_LDS;  // floats per wave
+                                                   const BlockDesc2* __restrict__ blocks,
+                                                   const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg_fast,
+                                                   const int32_t* __restrict__ cells, int32_t ncells) {
+    constexpr int LDSW = EXACT ? 6 * 128 : BLK2_PASSB_LDS;  // floats per wave
     __shared__ float lds[WPB * LDSW];
     if ((int32_t)blockIdx.x < nwg_fast) {
         if constexpr (ND == 2) {
             int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            int32_t blk = __builtin_amdgcn_readfirstlane((xcd_remap(blockIdx.x, nwg_fast) * WPB + wave) * BPW);
+            int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg_fast) * WPB + wave);
             if (blk < nblk) {
                 if constexpr (EXACT)
-                    passB_adv_block2(blocks, blk, p.nc, u, C, ldc, G, ud, lds + wave * LDSW, lane);
+                    passB_adv_block2(blocks, htab, blk, p.nc, u, C, ldc, G, ud, lds + wave * LDSW, lane);
                 else
-                    blk2::passB_adv<BPW>(blocks, blk, nblk, (uint32_t)p.nc, u, C, (uint32_t)ldc, G, ud,
-                                         lds + wave * LDSW, lane);
+                    blk2::passB_adv(blocks, htab, blk, (uint32_t)p.nc, u, C, (uint32_t)ldc, G, ud, lds + wave * LDSW,
+                                    lane);
             }
         }
         return;
@@ -489,13 +456,14 @@ __global__ __launch_bounds__(256) void k_passB_adv(PartView p, const float* __re
 __global__ __launch_bounds__(256) void k_passB_euler_blk(uint32_t nc, const float* __restrict__ P, uint32_t ldp,
                                                          const float* __restrict__ G, float* __restrict__ R,
                                                          uint32_t ldr, float Rgas, float gamma,
-                                                         const BlockDesc2* __restrict__ blocks, int32_t nblk,
-                                                         int32_t nwg) {
+                                                         const BlockDesc2* __restrict__ blocks,
+                                                         const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg) {
     __shared__ float lds[WPB * BLK2_EULER_LDS];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB + wave);
     if (blk < nblk)
-        blk2::passB_euler(blocks, blk, nc, P, ldp, G, R, ldr, blk2::Gas{Rgas, gamma}, lds + wave * BLK2_EULER_LDS, lane);
+        blk2::passB_euler(blocks, htab, blk, nc, P, ldp, G, R, ldr, blk2::Gas{Rgas, gamma}, lds + wave * BLK2_EULER_LDS,
+                          lane);
 }
 
 template <int ND>
@@ -538,7 +506,7 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     int rc = ensure_G(p, (size_t)(p->nd + 1) * p->nc);
     if (rc) return rc;
     const bool fast = p->bs == 8 && p->nd == 2 && p->nblk > 0 && !(flags & IBH_FORCE_GENERAL);
-    const int bpwg = WPB * ((flags & IBH_EXACT) ? 1 : IBH_BPW);  // blocks per workgroup
+    const int bpwg = WPB;  // blocks per workgroup
     // overlap phases: INTERIOR = blocks independent of skirt data, BOUNDARY = the rest + face-list cells
     const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
     IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
@@ -564,27 +532,29 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     const bool doA = gA.x && !(flags & IBH_PASS_B_ONLY), doB = gB.x && !(flags & IBH_PASS_A_ONLY);
     const BlockDesc2* blkA = p->blocks2 ? p->blocks2 + a0 : nullptr;
     const BlockDesc2* blkB = p->blocks2 ? p->blocks2 + b0 : nullptr;
+    const int32_t* htA = p->htab ? p->htab + (size_t)a0 * 64 : nullptr;
+    const int32_t* htB = p->htab ? p->htab + (size_t)b0 * 64 : nullptr;
     if (p->nd == 2 && exact) {
         if (doA)
-            hipLaunchKernelGGL((k_passA<2, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA,
+            hipLaunchKernelGGL((k_passA<2, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA, htA,
                                a1 - a0, nwgA_fast, cellsA, nA);
         if (doB)
-            hipLaunchKernelGGL((k_passB_adv<2, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB,
+            hipLaunchKernelGGL((k_passB_adv<2, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB, htB,
                                b1 - b0, nwgB_fast, cellsB, nB);
     } else if (p->nd == 2) {
         if (doA)
-            hipLaunchKernelGGL((k_passA<2, 1, false>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA,
+            hipLaunchKernelGGL((k_passA<2, 1, false>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA, htA,
                                a1 - a0, nwgA_fast, cellsA, nA);
         if (doB)
-            hipLaunchKernelGGL((k_passB_adv<2, false>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB,
+            hipLaunchKernelGGL((k_passB_adv<2, false>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB, htB,
                                b1 - b0, nwgB_fast, cellsB, nB);
     } else {
         if (doA)
             hipLaunchKernelGGL((k_passA<3, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,
-                               p->nblk, 0, cellsA, nA);
+                               p->htab, p->nblk, 0, cellsA, nA);
         if (doB)
             hipLaunchKernelGGL((k_passB_adv<3, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
-                               p->nblk, 0, cellsB, nB);
+                               p->htab, p->nblk, 0, cellsB, nB);
     }
     IBH_LAUNCH_CHECK();
     return 0;
@@ -614,21 +584,21 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     const bool doA = gA.x && !(flags & IBH_PASS_B_ONLY), doB = !(flags & IBH_PASS_A_ONLY);
     if (p->nd == 2) {
         if (doA && fast)
-            hipLaunchKernelGGL((k_passA<2, 4, false>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->nblk,
-                               nwg_fast, cellsA, nA);
+            hipLaunchKernelGGL((k_passA<2, 4, false>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
+                               p->nblk, nwg_fast, cellsA, nA);
         else if (doA)
-            hipLaunchKernelGGL((k_passA<2, 4, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->nblk, 0,
-                               cellsA, nA);
+            hipLaunchKernelGGL((k_passA<2, 4, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
+                               p->nblk, 0, cellsA, nA);
         if (doB && nwg_fast)
             hipLaunchKernelGGL(k_passB_euler_blk, dim3(nwg_fast), blk, 0, ibh_stream, (uint32_t)p->nc, P, (uint32_t)ldp,
-                               p->G, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks2, p->nblk, nwg_fast);
+                               p->G, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks2, p->htab, p->nblk, nwg_fast);
         if (doB && gB.x)
             hipLaunchKernelGGL((k_passB_euler<2>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
                                fluid->gamma, cellsB, nB);
     } else {
         if (doA)
-            hipLaunchKernelGGL((k_passA<3, 5, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->nblk, 0,
-                               cellsA, nA);
+            hipLaunchKernelGGL((k_passA<3, 5, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
+                               p->nblk, 0, cellsA, nA);
         if (doB && gB.x)
             hipLaunchKernelGGL((k_passB_euler<3>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
                                fluid->gamma, cellsB, nB);
