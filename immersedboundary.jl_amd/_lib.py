@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _here = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_here, "libibhip.so")
+LIB_PATH = os.environ.get("IBHIP_LIB") or os.path.join(_here, "libibhip.so")  # IBHIP_LIB: A/B builds
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
