@@ -194,7 +194,9 @@ __device__ __forceinline__ void passB_euler_cell(const PartView& p, const float*
 // block fast path, 2-D, 8x8 blocks.  LDS per wave and per field: tile[64] + halo[4][8][2].
 // halo slot (s, t, k): side s, boundary cell t along the side, k-th face (k = 1 only on FINE sides)
 // ------------------------------------------------------------------------------------------
-#define WPB 4  // waves per 256-thread workgroup
+#ifndef WPB
+#define WPB 4  // waves (= blocks) per workgroup of 64*WPB threads
+#endif
 
 // XCD-aware workgroup remap (cdna_hip_programming.md T1): workgroups are dealt round-robin over the
 // 8 XCDs, each with its own non-coherent L2.  Give every XCD one CONTIGUOUS chunk of the block list
@@ -398,7 +400,7 @@ namespace {
 // otherwise the tuned block path of ibh_block2d.h.
 // ------------------------------------------------------------------------------------------
 template <int ND, int NV, bool EXACT>
-__global__ __launch_bounds__(256) void k_passA(PartView p, const float* __restrict__ u, int64_t ldu,
+__global__ __launch_bounds__(64 * WPB) void k_passA(PartView p, const float* __restrict__ u, int64_t ldu,
                                                float* __restrict__ G, const BlockDesc2* __restrict__ blocks,
                                                const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg_fast,
                                                const int32_t* __restrict__ cells, int32_t ncells) {
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256) void k_passA(PartView p, const float* __restri
 }
 
 template <int ND, bool EXACT>
-__global__ __launch_bounds__(256) void k_passB_adv(PartView p, const float* __restrict__ u, const float* __restrict__ C,
+__global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float* __restrict__ u, const float* __restrict__ C,
                                                    int64_t ldc, const float* __restrict__ G, float* __restrict__ ud,
                                                    const BlockDesc2* __restrict__ blocks,
                                                    const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg_fast,
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256) void k_passB_adv(PartView p, const float* __re
 
 // Euler pass B: the block body and the face-list body are separate kernels (the Float64 flux combine of
 // the literal face-list body needs ~120 VGPRs and would halve the occupancy of the block body).
-__global__ __launch_bounds__(256) void k_passB_euler_blk(uint32_t nc, const float* __restrict__ P, uint32_t ldp,
+__global__ __launch_bounds__(64 * WPB) void k_passB_euler_blk(uint32_t nc, const float* __restrict__ P, uint32_t ldp,
                                                          const float* __restrict__ G, float* __restrict__ R,
                                                          uint32_t ldr, float Rgas, float gamma,
                                                          const BlockDesc2* __restrict__ blocks,
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256) void k_passB_euler_blk(uint32_t nc, const floa
 }
 
 template <int ND>
-__global__ __launch_bounds__(256) void k_passB_euler(PartView p, const float* __restrict__ P, int64_t ldp,
+__global__ __launch_bounds__(64 * WPB) void k_passB_euler(PartView p, const float* __restrict__ P, int64_t ldp,
                                                      const float* __restrict__ G, float* __restrict__ R, int64_t ldr,
                                                      float Rgas, float gamma, const int32_t* __restrict__ cells,
                                                      int32_t ncells) {
@@ -526,8 +528,8 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         nB = p->n_image;
     }
     PartView v = view(p);
-    dim3 blk(256);
-    dim3 gA(nwgA_fast + (nA + 255) / 256), gB(nwgB_fast + (nB + 255) / 256);
+    dim3 blk(64 * WPB);
+    dim3 gA(nwgA_fast + (nA + 64 * WPB - 1) / (64 * WPB)), gB(nwgB_fast + (nB + 64 * WPB - 1) / (64 * WPB));
     const bool exact = (flags & IBH_EXACT) != 0;
     const bool doA = gA.x && !(flags & IBH_PASS_B_ONLY), doB = gB.x && !(flags & IBH_PASS_A_ONLY);
     const BlockDesc2* blkA = p->blocks2 ? p->blocks2 + a0 : nullptr;
@@ -568,7 +570,7 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     int rc = ensure_G(p, (size_t)(p->nd * nv + 1) * p->nc);
     if (rc) return rc;
     PartView v = view(p);
-    dim3 blk(256);
+    dim3 blk(64 * WPB);
     // tuned block path: 2-D only and not with IBH_EXACT (the literal arithmetic lives in the face-list body)
     const bool fast = p->bs == 8 && p->nd == 2 && p->nblk > 0 && !(flags & (IBH_FORCE_GENERAL | IBH_EXACT));
     const int32_t nwg_fast = fast ? (p->nblk + WPB - 1) / WPB : 0;
@@ -580,7 +582,7 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
         cellsB = p->image_in_domain;
         nB = p->n_image;
     }
-    dim3 gA(nwg_fast + (nA + 255) / 256), gB((nB + 255) / 256);
+    dim3 gA(nwg_fast + (nA + 64 * WPB - 1) / (64 * WPB)), gB((nB + 64 * WPB - 1) / (64 * WPB));
     const bool doA = gA.x && !(flags & IBH_PASS_B_ONLY), doB = !(flags & IBH_PASS_A_ONLY);
     if (p->nd == 2) {
         if (doA && fast)
