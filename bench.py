@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="rae2822_0.87M", choices=sorted(WORKLOADS))
+    ap.add_argument("--residual", default="advection", choices=["advection", "euler"],
+                    help="advection = R1 (headline, 16 B/cell); euler = R2 HLL residual (32 B/cell), secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general", action="store_true", help="force the face-list kernels (no block fast path)")
     ap.add_argument("--exact", action="store_true", help="block path with the literal IEEE arithmetic")
@@ -139,6 +141,19 @@ def main():
     dpart = ibamd.to_backend(part, ibamd.hip)
     u, C = ibamd.hip(u_h), ibamd.hip(C_h)
     ud = torch.zeros(dpart.nc, dtype=torch.float32, device=u.device)
+    euler = args.residual == "euler"
+    if euler:
+        if world > 1:
+            raise SystemExit("--residual euler is a single-GPU secondary measurement")
+        rng = np.random.default_rng(12345)
+        n = part.centers.shape[0]
+        P_h = np.empty((n, 4), dtype=np.float32)   # P = [p T u v], SURVEY.md 8d
+        P_h[:, 0] = 1e5 * (1 + 0.05 * rng.uniform(-1, 1, n))
+        P_h[:, 1] = 288.15 * (1 + 0.05 * rng.uniform(-1, 1, n))
+        P_h[:, 2] = 100.0 * (1 + 0.1 * rng.uniform(-1, 1, n))
+        P_h[:, 3] = 100.0 * (1 + 0.1 * rng.uniform(-1, 1, n))
+        P = ibamd.hip(P_h)
+        Rres = torch.zeros((4, dpart.nc), dtype=torch.float32, device=P.device).T
     flags = (ibamd.IBH_FORCE_GENERAL if args.general else 0) | (ibamd.IBH_EXACT if args.exact else 0)
 
     hx = None
@@ -149,9 +164,15 @@ def main():
         overlap = not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
         comm_stream = torch.cuda.Stream() if overlap else None
 
+    def sweep(extra=0):
+        if euler:
+            ibamd.residual_euler_hll(dpart, P, out=Rres, flags=flags | extra)
+        else:
+            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags | extra)
+
     def step():
         if hx is None:
-            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)
+            sweep()
         elif comm_stream is not None:
             sweep_overlapped(hx, dpart, u, C, ud, comm_stream, flags=flags)
         else:
@@ -215,12 +236,12 @@ def main():
     def time_pass(f, reps):
         # `reps` launches of one kernel captured in a graph, timed with events on the launch stream
         with torch.cuda.stream(side):
-            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)  # valid workspace
+            sweep()  # valid workspace
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 for _ in range(reps):
-                    ibamd.residual_advection(dpart, u, C, out=ud, flags=flags | f)
+                    sweep(f)
             g.replay()
             torch.cuda.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -234,7 +255,8 @@ def main():
     tB = time_pass(ibamd.IBH_PASS_B_ONLY, reps)
     tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
     cells_launch = dpart.nc
-    achieved = B_ALG_2D * cells_launch / tB / 1e9
+    b_alg = 32.0 if euler else B_ALG_2D  # R2 = 2 * 4 * (nd + 2) B/cell in 2-D
+    achieved = b_alg * cells_launch / tB / 1e9
     # HBM-side traffic of one pass-B launch from the committed PMC passes of this build (separate
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
     # calibrated against the kernel's known tile loads); null if not profiled.
@@ -242,24 +264,25 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "current_pmc.json")) as f:
             pm = json.load(f)
-        if pm.get("workload") == args.workload and not args.general and not args.exact and world == 1:
+        if pm.get("workload") == args.workload and not args.general and not args.exact and world == 1 and not euler:
             traffic = round((2.0 * pm["passB_fetch_kb"] + pm["passB_write_kb"]) * 1024.0)
     except (OSError, KeyError, ValueError):
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_passB_adv<2>", "kernel_us": round(tB * 1e6, 3), "passA_us": round(tA * 1e6, 3),
-                "alg_bytes_per_cell": B_ALG_2D, "cells_per_launch": cells_launch,
-                "sweep_frac": round(B_ALG_2D * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+                "kernel": "k_passB_euler_blk" if euler else "k_passB_adv<2,false>",
+                "kernel_us": round(tB * 1e6, 3), "passA_us": round(tA * 1e6, 3),
+                "alg_bytes_per_cell": b_alg, "cells_per_launch": cells_launch,
+                "sweep_frac": round(b_alg * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
 
     out = {
-        "metric": "Mcells*iters/s residual sweep (advection-JST-MUSCL), 2D RAE2822",
+        "metric": "Mcells*iters/s residual sweep (%s), 2D RAE2822" % ("Euler HLL-JST-MUSCL" if euler else "advection-JST-MUSCL"),
         "value": round(value, 2), "unit": "Mcells*iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: 2D RAE2822 block quadtree, {ncells} cells, "
                                f"{msh.nblocks} 8x8 blocks, {world} partition(s), skirt depth 2, "
-                               f"R1 advection-JST-MUSCL residual, fields resident in HBM",
+                               f"{'R2 Euler HLL' if euler else 'R1 advection'}-JST-MUSCL residual, fields resident in HBM",
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
                    "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else "block-fast-path"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",
@@ -270,7 +293,7 @@ def main():
                    "block_analysis": dpart.info},
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler:
         v, n, secs = cpu_baseline(part, u_h, C_h)
         out["cpu_baseline"] = {"value": round(v, 3), "unit": "Mcells*iters/s", "cores": 1, "kind": "port",
                                "sample": f"{n} sweeps of the same {u_h.shape[0]}-cell partition in {secs:.1f} s, "
