@@ -21,7 +21,8 @@ class IbhError(RuntimeError):
 
 
 class ibh_fluid(C.Structure):
-    _fields_ = [("R", C.c_float), ("gamma", C.c_float)]
+    _fields_ = [("R", C.c_float), ("gamma", C.c_float), ("mu_ref", C.c_float), ("Tref", C.c_float),
+                ("S", C.c_float), ("nk", C.c_int32), ("k", C.c_float * 4)]
 
 
 _SIGS = {
@@ -63,6 +64,16 @@ _SIGS = {
     "ibh_copy_rows": [c_vp, c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_residual_advection": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
     "ibh_residual_euler_hll": [c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(ibh_fluid), c_int],
+    "ibh_cfd_speed_of_sound": [C.POINTER(ibh_fluid), c_i64, c_vp, c_vp],
+    "ibh_cfd_dynamic_viscosity": [C.POINTER(ibh_fluid), c_i64, c_vp, c_vp],
+    "ibh_cfd_heat_conductivity": [C.POINTER(ibh_fluid), c_i64, c_vp, c_vp],
+    "ibh_cfd_primitive2state": [C.POINTER(ibh_fluid), c_int, c_i64, c_vp, c_i64, c_vp, c_i64],
+    "ibh_cfd_state2primitive": [C.POINTER(ibh_fluid), c_int, c_i64, c_vp, c_i64, c_vp, c_i64],
+    "ibh_cfd_inviscid_fluxes_hll": [C.POINTER(ibh_fluid), c_int, c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64],
+    "ibh_cfd_inviscid_fluxes_sensor": [C.POINTER(ibh_fluid), c_int, c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                       c_vp, c_i64],
+    "ibh_cfd_viscous_fluxes": [C.POINTER(ibh_fluid), c_int, c_int, c_i64, c_vp, c_i64, C.POINTER(c_vp), c_i64, c_vp,
+                               C.c_float, c_vp, c_i64],
     "ibh_axpy_clamped": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_axpy": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_sumsq": [c_i64, c_vp, c_vp],

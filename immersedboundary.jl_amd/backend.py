@@ -418,15 +418,17 @@ def residual_advection(part, u, C_, out=None, flags=0):
     return ud
 
 
-def residual_euler_hll(part, P, fluid_R=283.0, fluid_gamma=1.4, out=None, flags=0):
+def residual_euler_hll(part, P, fluid_R=283.0, fluid_gamma=1.4, out=None, flags=0, fluid=None):
     """Fused Euler residual R2: JST(p) + cell_gradient + MUSCL(high_order) + HLL + green_gauss."""
     part = _part(part)
+    if fluid is not None:
+        fluid_R, fluid_gamma = fluid.R, fluid.gamma
     P, nv, ldp = _field(P, part.nc)
     if nv != part.nd + 2:
         raise ValueError("P must be (nc, nd+2) = [p T u v (w)]")
     R = out if out is not None else torch.zeros((nv, part.nc), dtype=torch.float32, device=P.device).T
     R, _, ldr = _field(R, part.nc)
-    fl = _lib.ibh_fluid(float(fluid_R), float(fluid_gamma))
+    fl = _lib.ibh_fluid(float(fluid_R), float(fluid_gamma), 0.0, 1.0, 0.0, 0)
     _stream()
     call("ibh_residual_euler_hll", part.handle, _ptr(P), ldp, _ptr(R), ldr, C.byref(fl), flags)
     return R

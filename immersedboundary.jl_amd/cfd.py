@@ -1,0 +1,132 @@
+"""``CFD`` pointwise physics on device arrays (mirror of /root/reference/src/cfd.jl for the functions residual
+closures call): ``Fluid``, ``speed_of_sound``, ``dynamic_viscosity``, ``heat_conductivity``,
+``primitive2state``, ``state2primitive``, ``inviscid_fluxes`` (HLL and sensor/Rusanov methods),
+``viscous_fluxes``.  Same names and argument order; ``dim`` is the 1-based Cartesian direction (the
+matrix-normal form of the reference is a curvilinear extension outside this hot path).
+Arithmetic runs in libibhip kernels (csrc/ibh_cfd.hip); device arrays only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import backend as B
+
+
+class Fluid:
+    """cfd.jl:14-53 (defaults = air, Float32)."""
+
+    def __init__(self, R=283.0, gamma=1.4, k=(0.00646, 6.468e-5), mu_ref=1.716e-5, Tref=273.15, S=110.4):
+        self.R, self.gamma = float(R), float(gamma)
+        self.k = [float(k)] if np.isscalar(k) else [float(x) for x in k]
+        if len(self.k) > 4:
+            raise ValueError("at most 4 heat-conductivity coefficients are supported")
+        self.mu_ref, self.Tref, self.S = float(mu_ref), float(Tref), float(S)
+
+    def _c(self):
+        kk = (C.c_float * 4)(*(self.k + [0.0] * (4 - len(self.k))))
+        return _lib.ibh_fluid(self.R, self.gamma, self.mu_ref, self.Tref, self.S, len(self.k), kk)
+
+
+def _pointwise(name, fld, T):
+    T, nv, _ = B._field(T)
+    flat = T if T.ndim == 1 else T.T.contiguous().T
+    out = B._like(flat, flat.shape[0])
+    f = fld._c()
+    B._stream()
+    B.call(name, C.byref(f), int(flat.numel()), B._ptr(flat), B._ptr(out))
+    return out
+
+
+def speed_of_sound(fld, T):
+    """cfd.jl:62-64"""
+    return _pointwise("ibh_cfd_speed_of_sound", fld, T)
+
+
+def dynamic_viscosity(fld, T):
+    """cfd.jl:71-77"""
+    return _pointwise("ibh_cfd_dynamic_viscosity", fld, T)
+
+
+def heat_conductivity(fld, T):
+    """cfd.jl:84-90"""
+    return _pointwise("ibh_cfd_heat_conductivity", fld, T)
+
+
+def _nd(P):
+    nd = P.shape[1] - 2
+    if P.ndim != 2 or nd not in (2, 3):
+        raise ValueError("expected (n, nd+2) with nd = 2 or 3")
+    return nd
+
+
+def primitive2state(fluid, P):
+    """cfd.jl:106-123"""
+    P, _, ldp = B._field(P)
+    nd = _nd(P)
+    Q = B._like(P, P.shape[0])
+    f = fluid._c()
+    B._stream()
+    B.call("ibh_cfd_primitive2state", C.byref(f), nd, P.shape[0], B._ptr(P), ldp, B._ptr(Q), P.shape[0])
+    return Q
+
+
+def state2primitive(fluid, Q):
+    """cfd.jl:137-151"""
+    Q, _, ldq = B._field(Q)
+    nd = _nd(Q)
+    P = B._like(Q, Q.shape[0])
+    f = fluid._c()
+    B._stream()
+    B.call("ibh_cfd_state2primitive", C.byref(f), nd, Q.shape[0], B._ptr(Q), ldq, B._ptr(P), Q.shape[0])
+    return P
+
+
+def inviscid_fluxes(fluid, PL, PR, *args):
+    """``inviscid_fluxes(fluid, PL, PR, dim)`` (HLL, cfd.jl:459-508) or
+    ``inviscid_fluxes(fluid, PL, PR, nuL, nuR, dim)`` (sensor/Rusanov, cfd.jl:516-554)."""
+    PL, _, ld = B._field(PL)
+    PR, _, ld2 = B._field(PR)
+    if ld2 != ld:
+        PR = PR.T.contiguous().T
+        PL = PL.T.contiguous().T
+        ld = PL.shape[0]
+    nd = _nd(PL)
+    n = PL.shape[0]
+    F = B._like(PL, n)
+    f = fluid._c()
+    B._stream()
+    if len(args) == 1:
+        B.call("ibh_cfd_inviscid_fluxes_hll", C.byref(f), nd, int(args[0]), n, B._ptr(PL), B._ptr(PR), ld, B._ptr(F), n)
+    elif len(args) == 3:
+        nuL, _, _ = B._field(args[0], n)
+        nuR, _, _ = B._field(args[1], n)
+        B.call("ibh_cfd_inviscid_fluxes_sensor", C.byref(f), nd, int(args[2]), n, B._ptr(PL), B._ptr(PR), ld,
+               B._ptr(nuL), B._ptr(nuR), B._ptr(F), n)
+    else:
+        raise TypeError("inviscid_fluxes(fluid, PL, PR, dim) or inviscid_fluxes(fluid, PL, PR, nuL, nuR, dim)")
+    return F
+
+
+def viscous_fluxes(fluid, P, Pgrad, dim, mu_t=0.0):
+    """cfd.jl:664-736 (Cartesian ``dim``); ``Pgrad`` = tuple of the gradients of P along each axis."""
+    P, _, ldp = B._field(P)
+    nd = _nd(P)
+    n = P.shape[0]
+    grads = [B._field(g, n)[0].T.contiguous().T for g in Pgrad]
+    if len(grads) != nd:
+        raise ValueError("Pgrad needs one array per dimension")
+    ptrs = (B.c_vp * nd)(*[g.data_ptr() for g in grads])
+    F = B._like(P, n)
+    f = fluid._c()
+    mt_arr, mt_const = None, 0.0
+    if hasattr(mu_t, "data_ptr"):
+        mt_arr, _, _ = B._field(mu_t, n)
+    else:
+        mt_const = float(mu_t)
+    B._stream()
+    B.call("ibh_cfd_viscous_fluxes", C.byref(f), nd, int(dim), n, B._ptr(P), ldp, ptrs, n, B._ptr(mt_arr),
+           C.c_float(mt_const), B._ptr(F), n)
+    return F

@@ -1,0 +1,248 @@
+// libibhip: CFD pointwise physics (cfd.jl) as standalone kernels, one thread per row, literal
+// Float32 arithmetic in the reference's evaluation order (-ffp-contract=off).  These exist so that
+// operator-granularity closures (`CFD.inviscid_fluxes(fluid, PL, PR, dim)` etc.) run on device arrays;
+// the fused sweeps of ibh_fused.hip inline the same formulas (ibh_flux.h).
+#include "ibh_common.h"
+#include "ibh_flux.h"
+
+#define CFD_BLOCK 256
+
+namespace {
+
+__device__ __forceinline__ float sutherland(const ibh_fluid& f, float T) {
+    T = fmaxf(T, 10.0f);
+    // mu_ref * ((T/Tref)^(2/3)) * (Tref + S) / (T + S)     (cfd.jl:75, exponent as in the reference)
+    return f.mu_ref * powf(T / f.Tref, 2.0f / 3.0f) * (f.Tref + f.S) / (T + f.S);
+}
+
+__device__ __forceinline__ float conductivity(const ibh_fluid& f, float T) {
+    float k = 0.0f * T;
+    float Tp = 1.0f;
+    for (int i = 0; i < f.nk; ++i) {
+        k = k + f.k[i] * (i == 0 ? 1.0f : Tp);
+        Tp = (i == 0) ? T : Tp * T;
+    }
+    return k;
+}
+
+__global__ void k_pointwise(ibh_fluid f, int mode, int64_t n, const float* __restrict__ T, float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float t = T[i];
+        out[i] = mode == 0 ? sqrtf(f.gamma * f.R * fmaxf(t, 10.0f)) : mode == 1 ? sutherland(f, t) : conductivity(f, t);
+    }
+}
+
+template <int ND>
+__global__ void k_p2s(ibh_fluid f, int64_t n, const float* __restrict__ P, int64_t ldp, float* __restrict__ Q,
+                      int64_t ldq) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float p = P[i], T = fmaxf(P[i + ldp], 10.0f);
+        float k = P[i + 2 * ldp] * P[i + 2 * ldp];
+#pragma unroll
+        for (int j = 1; j < ND; ++j) k = k + P[i + (2 + j) * ldp] * P[i + (2 + j) * ldp];
+        k = k / 2.0f;
+        float rho = p / (f.R * T);
+        Q[i] = rho;
+        Q[i + ldq] = rho * (f.R / (f.gamma - 1.0f) * T + k);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) Q[i + (2 + j) * ldq] = rho * P[i + (2 + j) * ldp];
+    }
+}
+
+template <int ND>
+__global__ void k_s2p(ibh_fluid f, int64_t n, const float* __restrict__ Q, int64_t ldq, float* __restrict__ P,
+                      int64_t ldp) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float rho = Q[i], E = Q[i + ldq];
+        float u[ND];
+        float k = 0.f;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            u[j] = Q[i + (2 + j) * ldq] / rho;
+            k = (j == 0) ? u[j] * u[j] : k + u[j] * u[j];
+        }
+        k = k / 2.0f;
+        float p = (f.gamma - 1.0f) * (E - rho * k);
+        P[i] = p;
+        P[i + ldp] = fmaxf(p / (rho * f.R), 10.0f);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) P[i + (2 + j) * ldp] = u[j];
+    }
+}
+
+template <int ND>
+__global__ void k_hll(ibh_fluid f, int dim0, int64_t n, const float* __restrict__ PL, const float* __restrict__ PR,
+                      int64_t ld, float* __restrict__ F, int64_t ldf) {
+    constexpr int NV = ND + 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float l[NV], r[NV];
+        double Fd[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            l[v] = PL[i + v * ld];
+            r[v] = PR[i + v * ld];
+        }
+        ibhf::hll_flux<ND>(l, r, dim0, f.R, f.gamma, Fd);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) F[i + v * ldf] = (float)Fd[v];
+    }
+}
+
+template <int ND>
+__global__ void k_sensor_flux(ibh_fluid f, int dim0, int64_t n, const float* __restrict__ PL,
+                              const float* __restrict__ PR, int64_t ld, const float* __restrict__ nuL,
+                              const float* __restrict__ nuR, float* __restrict__ F, int64_t ldf) {
+    constexpr int NV = ND + 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float l[NV], r[NV], UL[NV], UR[NV], dummyF[NV], un, a;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            l[v] = PL[i + v * ld];
+            r[v] = PR[i + v * ld];
+        }
+        // UcL/UcR = primitive2state with the pressure added to the energy (cfd.jl:521-525)
+        ibhf::side_state<ND>(l, dim0, f.R, f.gamma, UL, dummyF, un, a);
+        ibhf::side_state<ND>(r, dim0, f.R, f.gamma, UR, dummyF, un, a);
+        UL[1] = UL[1] + l[0];
+        UR[1] = UR[1] + r[0];
+        float Pm[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) Pm[v] = (l[v] + r[v]) / 2.0f;
+        float u = Pm[2 + dim0];
+        float am = sqrtf(f.gamma * f.R * fmaxf(Pm[1], 10.0f));
+        float nu = fmaxf(nuL[i], nuR[i]);
+        float diss = nu * (am + fabsf(u)) / 2.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float Fv = (UL[v] + UR[v]) * u / 2.0f;
+            if (v == 2 + dim0) Fv = Fv + Pm[0];
+            F[i + v * ldf] = Fv + (UL[v] - UR[v]) * diss;
+        }
+    }
+}
+
+template <int ND>
+struct GradPtrs {
+    const float* g[ND];
+};
+
+template <int ND>
+__global__ void k_viscous(ibh_fluid f, int dim0, int64_t n, const float* __restrict__ P, int64_t ldp, GradPtrs<ND> G,
+                          int64_t ldg, const float* __restrict__ mu_t, float mu_t_const, float* __restrict__ F,
+                          int64_t ldf) {
+    constexpr int NV = ND + 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float T = P[i + ldp];
+        float mu = sutherland(f, T) + (mu_t ? mu_t[i] : mu_t_const);
+        float k = conductivity(f, T);
+        // vel_grad(a, b) = d u_a / d x_b = Pgrad[b][:, 2 + a]   (cfd.jl:677)
+        float vg[ND][ND];
+        float divu = 0.f;
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+            for (int b = 0; b < ND; ++b) vg[a][b] = G.g[b][i + (2 + a) * ldg];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) divu = (a == 0) ? 0.f + vg[0][0] : divu + vg[a][a];
+        float tau[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+            tau[j] = ((vg[dim0][j] + vg[j][dim0]) - (dim0 == j ? 2.0f / 3.0f : 0.0f) * divu) * mu;
+        float Fe = 0.0f + G.g[dim0][i + ldg] * k;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) Fe = Fe + tau[j] * P[i + (2 + j) * ldp];
+        F[i] = 0.0f;
+        F[i + ldf] = Fe;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) F[i + (2 + j) * ldf] = 0.0f + tau[j];
+        (void)NV;
+    }
+}
+
+inline dim3 grid1(int64_t n) { int g = ibh_grid(n, CFD_BLOCK); return dim3(g > 4096 ? 4096 : g); }
+
+}  // namespace
+
+#define CHECK_ND(nd, dim) IBH_REQUIRE(((nd) == 2 || (nd) == 3) && (dim) >= 1 && (dim) <= (nd), "bad nd/dim")
+
+extern "C" {
+
+static int pointwise(const ibh_fluid* f, int mode, int64_t n, const float* T, float* out) {
+    IBH_REQUIRE(f && T && out, "ibh_cfd: null argument");
+    IBH_REQUIRE(f->nk >= 0 && f->nk <= 4, "ibh_cfd: nk out of range");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_pointwise, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, mode, n, T, out);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_cfd_speed_of_sound(const ibh_fluid* f, int64_t n, const float* T, float* a) { return pointwise(f, 0, n, T, a); }
+int ibh_cfd_dynamic_viscosity(const ibh_fluid* f, int64_t n, const float* T, float* mu) { return pointwise(f, 1, n, T, mu); }
+int ibh_cfd_heat_conductivity(const ibh_fluid* f, int64_t n, const float* T, float* k) { return pointwise(f, 2, n, T, k); }
+
+int ibh_cfd_primitive2state(const ibh_fluid* f, int nd, int64_t n, const float* P, int64_t ldp, float* Q, int64_t ldq) {
+    IBH_REQUIRE(f && P && Q, "ibh_cfd_primitive2state: null argument");
+    CHECK_ND(nd, 1);
+    if (n <= 0) return 0;
+    if (nd == 2) hipLaunchKernelGGL(k_p2s<2>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, n, P, ldp, Q, ldq);
+    else hipLaunchKernelGGL(k_p2s<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, n, P, ldp, Q, ldq);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_cfd_state2primitive(const ibh_fluid* f, int nd, int64_t n, const float* Q, int64_t ldq, float* P, int64_t ldp) {
+    IBH_REQUIRE(f && P && Q, "ibh_cfd_state2primitive: null argument");
+    CHECK_ND(nd, 1);
+    if (n <= 0) return 0;
+    if (nd == 2) hipLaunchKernelGGL(k_s2p<2>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, n, Q, ldq, P, ldp);
+    else hipLaunchKernelGGL(k_s2p<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, n, Q, ldq, P, ldp);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_cfd_inviscid_fluxes_hll(const ibh_fluid* f, int nd, int dim, int64_t n, const float* PL, const float* PR,
+                                int64_t ld, float* F, int64_t ldf) {
+    IBH_REQUIRE(f && PL && PR && F, "ibh_cfd_inviscid_fluxes_hll: null argument");
+    CHECK_ND(nd, dim);
+    if (n <= 0) return 0;
+    if (nd == 2) hipLaunchKernelGGL(k_hll<2>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, dim - 1, n, PL, PR, ld, F, ldf);
+    else hipLaunchKernelGGL(k_hll<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, dim - 1, n, PL, PR, ld, F, ldf);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_cfd_inviscid_fluxes_sensor(const ibh_fluid* f, int nd, int dim, int64_t n, const float* PL, const float* PR,
+                                   int64_t ld, const float* nuL, const float* nuR, float* F, int64_t ldf) {
+    IBH_REQUIRE(f && PL && PR && nuL && nuR && F, "ibh_cfd_inviscid_fluxes_sensor: null argument");
+    CHECK_ND(nd, dim);
+    if (n <= 0) return 0;
+    if (nd == 2)
+        hipLaunchKernelGGL(k_sensor_flux<2>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, dim - 1, n, PL, PR, ld, nuL,
+                           nuR, F, ldf);
+    else
+        hipLaunchKernelGGL(k_sensor_flux<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, dim - 1, n, PL, PR, ld, nuL,
+                           nuR, F, ldf);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_cfd_viscous_fluxes(const ibh_fluid* f, int nd, int dim, int64_t n, const float* P, int64_t ldp,
+                           const float* const* Pgrad, int64_t ldg, const float* mu_t, float mu_t_const, float* F,
+                           int64_t ldf) {
+    IBH_REQUIRE(f && P && Pgrad && F, "ibh_cfd_viscous_fluxes: null argument");
+    IBH_REQUIRE(f->nk >= 0 && f->nk <= 4, "ibh_cfd: nk out of range");
+    CHECK_ND(nd, dim);
+    if (n <= 0) return 0;
+    if (nd == 2) {
+        GradPtrs<2> g{{Pgrad[0], Pgrad[1]}};
+        hipLaunchKernelGGL(k_viscous<2>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, dim - 1, n, P, ldp, g, ldg, mu_t,
+                           mu_t_const, F, ldf);
+    } else {
+        GradPtrs<3> g{{Pgrad[0], Pgrad[1], Pgrad[2]}};
+        hipLaunchKernelGGL(k_viscous<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, dim - 1, n, P, ldp, g, ldg, mu_t,
+                           mu_t_const, F, ldf);
+    }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -39,10 +39,17 @@ typedef struct ibh_part ibh_part; /* device-resident Partition  (ImmersedBoundar
 typedef struct ibh_acc ibh_acc;   /* device-resident Accumulator (accumulator.jl:12-16)        */
 typedef struct ibh_bc ibh_bc;     /* device-resident Boundary    (ImmersedBoundary.jl:406-414) */
 
-/* Ideal-gas constants used by the fused Euler residual (cfd.jl:14-53). */
+/* `Fluid` (cfd.jl:14-53).  The fused Euler residual uses R and gamma only; the transport
+ * properties feed ibh_cfd_viscous_fluxes / dynamic_viscosity / heat_conductivity:
+ * Sutherland's law with the reference's exponent 2/3 (cfd.jl:71-77) and k(T) = sum k[i]*T^i (:84-90). */
 typedef struct ibh_fluid {
     float R;
     float gamma;
+    float mu_ref;
+    float Tref;
+    float S;
+    int32_t nk;   /* number of heat-conductivity coefficients, <= 4 */
+    float k[4];
 } ibh_fluid;
 
 /* ---- runtime ---------------------------------------------------------- */
@@ -165,6 +172,28 @@ int ibh_copy_rows(const int32_t* dst_rows, const int32_t* src_rows, int32_t n,
 int ibh_residual_advection(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags);
 int ibh_residual_euler_hll(ibh_part*, const float* P, int64_t ldp, float* R, int64_t ldr,
                            const ibh_fluid* fluid, int flags);
+
+/* ---- CFD pointwise physics that residual closures call (cfd.jl), rows of P are [p T u v (w)],
+ * rows of Q are [rho E rho*u rho*v (rho*w)]; all arrays (n, nd+2) column-major, `dim` 1-based. ---- */
+int ibh_cfd_speed_of_sound(const ibh_fluid*, int64_t n, const float* T, float* a);          /* cfd.jl:62-64  */
+int ibh_cfd_dynamic_viscosity(const ibh_fluid*, int64_t n, const float* T, float* mu);      /* cfd.jl:71-77  */
+int ibh_cfd_heat_conductivity(const ibh_fluid*, int64_t n, const float* T, float* k);       /* cfd.jl:84-90  */
+int ibh_cfd_primitive2state(const ibh_fluid*, int nd, int64_t n, const float* P, int64_t ldp,
+                            float* Q, int64_t ldq);                                          /* cfd.jl:106-123 */
+int ibh_cfd_state2primitive(const ibh_fluid*, int nd, int64_t n, const float* Q, int64_t ldq,
+                            float* P, int64_t ldp);                                          /* cfd.jl:137-151 */
+/* HLL flux (cfd.jl:459-508).  The reference evaluates the last combine in Float64 (its `0.0`
+ * literals) and returns Float64; here the combine is Float64 too and the result is rounded to Float32. */
+int ibh_cfd_inviscid_fluxes_hll(const ibh_fluid*, int nd, int dim, int64_t n, const float* PL, const float* PR,
+                                int64_t ld, float* F, int64_t ldf);
+/* central flux + Rusanov dissipation scaled by sensors nuL/nuR (n) (cfd.jl:516-554) */
+int ibh_cfd_inviscid_fluxes_sensor(const ibh_fluid*, int nd, int dim, int64_t n, const float* PL, const float* PR,
+                                   int64_t ld, const float* nuL, const float* nuR, float* F, int64_t ldf);
+/* viscous flux along Cartesian `dim` (cfd.jl:664-736): `Pgrad` = HOST array of nd DEVICE pointers, the
+ * gradient of P along each axis, each (n, nd+2) with leading dimension ldg; mu_t per row or NULL (+ constant). */
+int ibh_cfd_viscous_fluxes(const ibh_fluid*, int nd, int dim, int64_t n, const float* P, int64_t ldp,
+                           const float* const* Pgrad, int64_t ldg, const float* mu_t, float mu_t_const,
+                           float* F, int64_t ldf);
 
 /* ---- small device-resident vector ops for the FAS loop (solver.jl:79-88) ---------- */
 /* q += clamp(omega,0,1) * r ; omega scalar */

@@ -1,0 +1,69 @@
+"""CFD pointwise physics on the GPU vs the oracle (cfd.jl:62-151, 459-554, 664-736)."""
+import numpy as np
+import pytest
+
+import ibamd
+from conftest import rel_inf
+from ibamd import cfd as gcfd
+from oracle import cfd as ocfd
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _P(n, nd, seed=0):
+    rng = np.random.default_rng(seed)
+    P = np.empty((n, nd + 2), dtype=f32)
+    P[:, 0] = 1e5 * (1 + 0.2 * rng.uniform(-1, 1, n))
+    P[:, 1] = 288.15 * (1 + 0.2 * rng.uniform(-1, 1, n))
+    P[:5, 1] = 5.0  # below the 10 K clamp
+    for d in range(nd):
+        P[:, 2 + d] = 300.0 * rng.uniform(-1, 1, n)  # sub- and supersonic, both signs
+    return P
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_state_conversions_and_properties(nd):
+    of, gf = ocfd.Fluid(), gcfd.Fluid()
+    P = _P(4097, nd)
+    Q = ocfd.primitive2state(of, P)
+    assert rel_inf(ibamd.to_host(gcfd.primitive2state(gf, ibamd.hip(P))), Q) <= 1e-6
+    assert rel_inf(ibamd.to_host(gcfd.state2primitive(gf, ibamd.hip(Q))), ocfd.state2primitive(of, Q)) <= 1e-6
+    T = np.ascontiguousarray(P[:, 1])
+    assert rel_inf(ibamd.to_host(gcfd.speed_of_sound(gf, ibamd.hip(T))), ocfd.speed_of_sound(of, T)) <= 1e-6
+    assert rel_inf(ibamd.to_host(gcfd.dynamic_viscosity(gf, ibamd.hip(T))), ocfd.dynamic_viscosity(of, T)) <= 1e-5
+    assert rel_inf(ibamd.to_host(gcfd.heat_conductivity(gf, ibamd.hip(T))), ocfd.heat_conductivity(of, T)) <= 1e-6
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_inviscid_fluxes(nd):
+    of, gf = ocfd.Fluid(), gcfd.Fluid()
+    PL, PR = _P(3000, nd, 1), _P(3000, nd, 2)
+    rng = np.random.default_rng(3)
+    nuL, nuR = rng.uniform(0, 1, 3000).astype(f32), rng.uniform(0, 1, 3000).astype(f32)
+    for dim in range(1, nd + 1):
+        exp = ocfd.inviscid_fluxes(of, PL, PR, dim)
+        got = ibamd.to_host(gcfd.inviscid_fluxes(gf, ibamd.hip(PL), ibamd.hip(PR), dim))
+        ok = np.isfinite(exp).all(axis=1)  # SL = SR = 0 gives 0/0 in the reference too
+        assert ok.mean() > 0.95
+        assert rel_inf(got[ok], exp[ok]) <= 1e-6
+        exp = ocfd.inviscid_fluxes_sensor(of, PL, PR, nuL, nuR, dim)
+        got = ibamd.to_host(gcfd.inviscid_fluxes(gf, ibamd.hip(PL), ibamd.hip(PR), ibamd.hip(nuL), ibamd.hip(nuR), dim))
+        assert rel_inf(got, exp) <= 1e-6
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_viscous_fluxes(nd):
+    of, gf = ocfd.Fluid(), gcfd.Fluid()
+    P = _P(2000, nd, 4)
+    rng = np.random.default_rng(5)
+    Pgrad = tuple((rng.uniform(-1, 1, P.shape) * 1e3).astype(f32) for _ in range(nd))
+    mu_t = rng.uniform(0, 1e-4, 2000).astype(f32)
+    for dim in range(1, nd + 1):
+        exp = ocfd.viscous_fluxes(of, P, Pgrad, dim, mu_t=mu_t)
+        got = ibamd.to_host(gcfd.viscous_fluxes(gf, ibamd.hip(P), tuple(ibamd.hip(g) for g in Pgrad), dim,
+                                                mu_t=ibamd.hip(mu_t)))
+        assert rel_inf(got, exp) <= 1e-5
+        exp0 = ocfd.viscous_fluxes(of, P, Pgrad, dim)
+        got0 = ibamd.to_host(gcfd.viscous_fluxes(gf, ibamd.hip(P), tuple(ibamd.hip(g) for g in Pgrad), dim))
+        assert rel_inf(got0, exp0) <= 1e-5
