@@ -1,0 +1,130 @@
+"""Edge cases through the C ABI: empty and ragged inputs, strided / non-column-major fields, wide fields,
+error reporting instead of crashes, partitions without block information, index_base = 1 (Julia callers)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import ibamd
+from conftest import rel_inf, seeded_field
+from ibamd import _lib
+from ibamd import backend as B
+from oracle import domain as od
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def test_empty_accumulator_rows_and_zero_sized():
+    acc = ibamd.Accumulator([[], [0, 2], []], [[], [0.25, 0.75], []], n_input=3)
+    out = ibamd.to_host(ibamd.to_backend(acc)(ibamd.hip(np.array([4.0, 5.0, 8.0], dtype=f32))))
+    assert np.array_equal(out, np.array([0.0, 7.0, 0.0], dtype=f32))      # zero-length bucket -> 0 (accumulator.jl:83)
+    empty = ibamd.Accumulator([], [], n_input=3)
+    assert ibamd.to_backend(empty)(ibamd.hip(np.zeros(3, f32))).shape[0] == 0
+
+
+def test_unweighted_accumulator():
+    acc = ibamd.Accumulator([[0, 1, 2], [2]], None, n_input=3)
+    out = ibamd.to_host(ibamd.to_backend(acc)(ibamd.hip(np.array([[1, 10], [2, 20], [3, 30]], dtype=f32))))
+    assert np.array_equal(out, np.array([[6, 60], [3, 30]], dtype=f32))
+
+
+def test_row_major_and_strided_fields_are_accepted(adv_domains):
+    dp, do = adv_domains
+    part, opart = dp.partitions[2], do.partitions[2]
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    u = seeded_field(opart.centers, nv=3)
+    exp = od.cell_gradient(opart, u, 1)
+    rowmajor = torch.from_numpy(u).cuda()                       # (n, 3) C-order: stride (3, 1)
+    assert rel_inf(ibamd.to_host(ibamd.cell_gradient(dpart, rowmajor, 1)), exp) <= 1e-6
+    wide = ibamd.hip(np.concatenate([u, u], axis=1))[:, 1:4]    # column slice of a wider column-major array
+    exp2 = od.cell_gradient(opart, np.ascontiguousarray(np.concatenate([u, u], axis=1)[:, 1:4]), 1)
+    assert rel_inf(ibamd.to_host(ibamd.cell_gradient(dpart, wide, 1)), exp2) <= 1e-6
+    with pytest.raises(ValueError):
+        ibamd.cell_gradient(dpart, rowmajor[:-1], 1)           # wrong number of rows
+    with pytest.raises(TypeError):
+        ibamd.cell_gradient(dpart, rowmajor.double(), 1)       # Float32 only
+    with pytest.raises(_lib.IbhError):
+        ibamd.cell_gradient(dpart, ibamd.hip(u), 3)            # dim out of range -> error code, not a crash
+
+
+def test_wide_field(adv_domains):
+    dp, do = adv_domains
+    part, opart = dp.partitions[1], do.partitions[1]
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    u = seeded_field(opart.centers, nv=17)
+    assert rel_inf(ibamd.to_host(ibamd.at_faces(dpart, ibamd.hip(u), 2)), od.at_faces(opart, u, 2)) <= 1e-6
+
+
+def _raw_create(part, block_size, index_base, with_domain=True):
+    nd, nc = 2, part.spacing.shape[0]
+    keep = []
+
+    def parr(arrs):
+        arrs = [np.ascontiguousarray(a + index_base, dtype=np.int32) for a in arrs]
+        keep.append(arrs)
+        return (B.c_vp * nd)(*[a.ctypes.data for a in arrs])
+    fon, fa = part.face_owners_neighbors, part.face_accumulators
+    owners, neigh = parr([fon[d][0] for d in (1, 2)]), parr([fon[d][1] for d in (1, 2)])
+    loff, lidx = parr([fa[(d, False)].off for d in (1, 2)]), parr([fa[(d, False)].idx for d in (1, 2)])
+    roff, ridx = parr([fa[(d, True)].off for d in (1, 2)]), parr([fa[(d, True)].idx for d in (1, 2)])
+    nf = np.array([fon[1][0].size, fon[2][0].size], dtype=np.int32)
+    sp = np.asfortranarray(part.spacing)
+    iid = np.ascontiguousarray(part.image_in_domain + index_base, dtype=np.int32)
+    dom = np.ascontiguousarray(part.domain + index_base, dtype=np.int32)
+    h = B.c_vp()
+    B._dev()
+    B.call("ibh_partition_create", C.byref(h), nd, nc, sp.ctypes.data_as(B.c_vp), B.c_vp(None), nf.ctypes.data_as(B.c_vp),
+           owners, neigh, loff, lidx, roff, ridx, int(iid.size), B._hptr(iid),
+           B._hptr(dom) if with_domain else B.c_vp(None), block_size, index_base)
+    return h
+
+
+def test_one_based_indices_and_no_block_info(adv_domains):
+    """Julia callers pass 1-based arrays; a partition created without `domain` has no block path."""
+    dp, do = adv_domains
+    part, opart = dp.partitions[2], do.partitions[2]
+    u = seeded_field(opart.centers)
+    Cc = np.ones((u.shape[0], 2), dtype=f32)
+    ref = ibamd.to_host(ibamd.residual_advection(ibamd.to_backend(part, ibamd.hip), ibamd.hip(u), ibamd.hip(Cc), flags=1))
+    ud, Cd = ibamd.hip(u), ibamd.hip(Cc)
+    for base, with_dom in ((1, True), (0, False)):
+        h = _raw_create(part, 8, base, with_dom)
+        info = (C.c_int64 * 8)()
+        B.call("ibh_partition_info", h, info, 8)
+        assert (info[0] > 0) == with_dom
+        out = torch.zeros(u.shape[0], dtype=torch.float32, device="cuda")
+        B._stream()
+        B.call("ibh_residual_advection", h, B._ptr(ud), B._ptr(Cd), u.shape[0], B._ptr(out), 16 if with_dom else 0)
+        assert np.array_equal(ibamd.to_host(out), ref)       # literal block path / face lists: same bits
+        with pytest.raises(_lib.IbhError):
+            B.call("ibh_residual_advection", h, B._ptr(ud), B._ptr(Cd), u.shape[0], B._ptr(out), 32 | 64)
+        B.call("ibh_partition_destroy", h)
+
+
+def test_bad_indices_are_rejected(adv_domains):
+    dp, _ = adv_domains
+    part = dp.partitions[1]
+    bad = ibamd.Accumulator(csr=(np.array([0, 1], np.int32), np.array([7], np.int32), np.array([1.0], f32)), n_input=3)
+    with pytest.raises(_lib.IbhError):
+        ibamd.to_backend(bad)
+    lib = _lib.load()
+    assert lib.ibh_accumulate(None, None, 1, 1, None, 1) != 0 and b"null" in lib.ibh_last_error()
+
+
+def test_image_only_flag(adv_domains):
+    dp, do = adv_domains
+    part = dp.partitions[2]
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    u = seeded_field(part.centers)
+    Cc = np.ones((u.shape[0], 2), dtype=f32)
+    full = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(Cc), flags=1))
+    out = torch.full((u.shape[0],), 123.0, dtype=torch.float32, device="cuda")
+    ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(Cc), out=out, flags=1 | 2)
+    got = ibamd.to_host(out)
+    img = part.image_in_domain
+    assert np.array_equal(got[img], full[img])
+    skirt = np.ones(u.shape[0], bool)
+    skirt[img] = False
+    assert np.all(got[skirt] == 123.0)                         # skirt rows untouched (ImmersedBoundary.jl:857-859)
