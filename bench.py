@@ -106,6 +106,10 @@ def main():
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange first, then the whole sweep")
+    ap.add_argument("--halo", default="auto", choices=["auto", "rccl", "xgmi"],
+                    help="N > 1 skirt exchange: rccl = grouped send/recv (eager launches); xgmi = direct peer writes "
+                         "into IPC-mapped buffers + device flags, captured in HIP graphs; auto = xgmi if it "
+                         "reproduces the rccl exchange bit for bit at start-up, else rccl")
     ap.add_argument("--graph-batch", type=int, default=20,
                     help="sweeps captured per HIP graph (launch-bound loop; 0 = eager launches)")
     args = ap.parse_args()
@@ -158,9 +162,27 @@ def main():
 
     hx = None
     comm_stream = None
+    halo_kind = None
     if world > 1:
-        from ibamd.halo import HaloExchange, HaloPlan, sweep_overlapped
-        hx = HaloExchange(HaloPlan(dom, rank + 1), u.device)
+        from ibamd.halo import HaloExchange, HaloPlan, XgmiHalo, sweep_overlapped, verify_exchangers
+        plan = HaloPlan(dom, rank + 1)
+        hx = HaloExchange(plan, u.device)
+        halo_kind = "rccl" if args.backend == "nccl" else "gloo-staged"
+        if args.halo in ("auto", "xgmi"):
+            try:
+                xg = XgmiHalo(plan, dom, u.device, nv=1)
+                good = verify_exchangers(xg, hx, dpart.nc, 1, rounds=3) and xg.healthy()
+                if good:
+                    hx, halo_kind = xg, "xgmi-direct"
+                elif args.halo == "xgmi":
+                    raise SystemExit("xgmi halo exchange failed verification against the reference exchange")
+                else:
+                    xg.close()
+            except RuntimeError as e:
+                if args.halo == "xgmi":
+                    raise
+                if rank == 0:
+                    print(f"[bench] xgmi halo exchange unavailable ({e}); using {halo_kind}", file=sys.stderr)
         overlap = not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
         comm_stream = torch.cuda.Stream() if overlap else None
 
@@ -187,15 +209,20 @@ def main():
 
     # The sweep is ~10 us of GPU work: a Python/ctypes launch per step would be host-bound, so on one GPU
     # the step loop is captured into HIP graphs of `graph_batch` sweeps each (every sweep still runs in full).
-    batch = args.graph_batch if (world == 1 and args.graph_batch > 0) else 0
+    # (N > 1: only with the xgmi exchange, which is kernels only; RCCL calls are launched eagerly.)
+    graphable = world == 1 or halo_kind == "xgmi-direct"
+    batch = args.graph_batch if (graphable and args.graph_batch > 0) else 0
+    batch -= batch % 2  # the xgmi exchange alternates two receive buffers: capture whole pairs
     graph = None
     side = torch.cuda.Stream()
     if batch:
         batch = min(batch, args.steps)
         with torch.cuda.stream(side):
-            for _ in range(3):
+            for _ in range(4):
                 step()
             torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
                 for _ in range(batch):
@@ -210,7 +237,7 @@ def main():
         with torch.cuda.stream(side):
             for _ in range(nsteps // batch):
                 graph.replay()
-            for _ in range(nsteps % batch):
+            for _ in range(nsteps % batch):  # (even remainders only when the xgmi exchange is in the graph)
                 step()
 
     run(args.warmup)
@@ -286,7 +313,8 @@ def main():
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
                    "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else "block-fast-path"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",
-                   "halo": None if hx is None else {"backend": args.backend, "overlap": comm_stream is not None,
+                   "halo": None if hx is None else {"backend": args.backend, "exchange": halo_kind,
+                                                    "overlap": comm_stream is not None,
                                                     "send_cells": hx.plan.n_send, "recv_cells": hx.plan.n_recv,
                                                     "peers": len(hx.plan.peers),
                                                     "interior_blocks": dpart.info["interior_blocks"]},

@@ -74,6 +74,13 @@ _SIGS = {
                                        c_vp, c_i64],
     "ibh_cfd_viscous_fluxes": [C.POINTER(ibh_fluid), c_int, c_int, c_i64, c_vp, c_i64, C.POINTER(c_vp), c_i64, c_vp,
                                C.c_float, c_vp, c_i64],
+    "ibh_ipc_alloc": [C.POINTER(c_vp), C.c_size_t, c_int],
+    "ibh_ipc_free": [c_vp],
+    "ibh_ipc_export": [c_vp, c_vp],
+    "ibh_ipc_import": [c_vp, C.POINTER(c_vp)],
+    "ibh_ipc_close": [c_vp],
+    "ibh_flag_signal": [c_vp, c_vp, c_int],
+    "ibh_flag_wait": [c_vp, c_vp, c_int, C.c_uint32, c_vp],
     "ibh_axpy_clamped": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_axpy": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_sumsq": [c_i64, c_vp, c_vp],

@@ -195,6 +195,27 @@ int ibh_cfd_viscous_fluxes(const ibh_fluid*, int nd, int dim, int64_t n, const f
                            const float* const* Pgrad, int64_t ldg, const float* mu_t, float mu_t_const,
                            float* F, int64_t ldf);
 
+/* ---- direct peer halo exchange over xGMI ("or direct peer ... IPC writes") -------
+ * Building blocks; the orchestration (who writes where) is host-side (halo.py / the Julia shim):
+ *   - receive buffers and flag words are allocated fine-grained (coherent across devices), exported as
+ *     64-byte HIP IPC handles, and mapped by the peers;
+ *   - per sweep the sender packs with ibh_gather_rows straight INTO the peer's mapped receive buffer, then
+ *     ibh_flag_signal bumps a sequence number in the peer's flag word (system-scope release);
+ *   - the receiver runs ibh_flag_wait (bounded spin, never hangs: on timeout bit 0 of *status is set and
+ *     the host falls back to the RCCL path) and unpacks with ibh_scatter_rows.
+ * Everything is an ordinary kernel on the caller's stream, so whole sweeps incl. the exchange can be
+ * captured in a HIP graph. */
+int ibh_ipc_alloc(void** dptr, size_t bytes, int fine_grained);
+int ibh_ipc_free(void* dptr);
+int ibh_ipc_export(void* dptr, void* handle64);        /* hipIpcGetMemHandle: writes 64 bytes            */
+int ibh_ipc_import(const void* handle64, void** dptr); /* hipIpcOpenMemHandle (lazy peer access)         */
+int ibh_ipc_close(void* dptr);
+/* seq = ++(*counter); *slots[q] = seq for q < n.  `counter` local device memory, `slots` DEVICE array of n
+ * device pointers (into the peers' flag arrays). */
+int ibh_flag_signal(uint32_t* counter, uint32_t* const* slots, int n);
+/* exp = ++(*counter); wait until *slots[q] >= exp for every q < n, at most max_spins polls each. */
+int ibh_flag_wait(uint32_t* counter, const uint32_t* const* slots, int n, uint32_t max_spins, uint32_t* status);
+
 /* ---- small device-resident vector ops for the FAS loop (solver.jl:79-88) ---------- */
 /* q += clamp(omega,0,1) * r ; omega scalar */
 int ibh_axpy_clamped(int64_t n, float omega, const float* r, float* q);
