@@ -151,9 +151,8 @@ __device__ __forceinline__ void passA(const BlockDesc2* __restrict__ blocks, con
 // pass B, advection: MUSCL(high_order) + upwind flux + Green-Gauss (test/advection.jl:67-83)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float minmod(float a, float b) {
-    // min(|a|,|b|)*(sign a + sign b)/2
-    const float m = fminf(fabsf(a), fabsf(b));
-    return (a * b > 0.0f) ? copysignf(m, a) : 0.0f;
+    // min(|a|,|b|)*(sign a + sign b)/2  ==  median(a, b, 0): one v_med3_f32
+    return __builtin_amdgcn_fmed3f(a, b, 0.0f);
 }
 
 // flux at the face between cell a (left/owner, half width dA) and b (right/neighbour, dB); inv = 1/(dA+dB)
@@ -245,38 +244,43 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
     wave_lds_sync();
 
     const float hx = bb.h[0], hy = bb.h[1], rhx = bb.rh[0], rhy = bb.rh[1];
+    // per-side half-widths of the neighbour and 1/(dA+dB), wave-uniform (scalar registers)
+    const float dBs[4] = {0.5f * hx * bb.rt[0], 0.5f * hx * bb.rt[1], 0.5f * hy * bb.rt[2], 0.5f * hy * bb.rt[3]};
+    const float invs[4] = {2.0f * rhx * bb.q[0], 2.0f * rhx * bb.q[1], 2.0f * rhy * bb.q[2], 2.0f * rhy * bb.q[3]};
     // ---- main pass: right (x+) and top (y+) face of every cell, sub-face 0 on block sides
     float FR = adv_flux(uc, nb1(fU, L, 1), gxc, nb1(fGX, L, 1), Dc, nb1(fD, L, 1), cxc, nb1(fCX, L, 1), 0.5f * hx,
-                        0.5f * hx * L.rt[1], 2.0f * rhx * L.q[1]);
+                        L.edge[1] ? dBs[1] : 0.5f * hx, L.edge[1] ? invs[1] : rhx);
     float FT = adv_flux(uc, nb1(fU, L, 3), gyc, nb1(fGY, L, 3), Dc, nb1(fD, L, 3), cyc, nb1(fCY, L, 3), 0.5f * hy,
-                        0.5f * hy * L.rt[3], 2.0f * rhy * L.q[3]);
-    // ---- extra pass: faces no lane owns
+                        L.edge[3] ? dBs[3] : 0.5f * hy, L.edge[3] ? invs[3] : rhy);
+    // ---- extra pass, low sides only (the halo cell is the owner, this cell the neighbour): role lane r < 32,
+    //   g = r>>3:  0: left sub-face 0   1: bottom sub-face 0   2: left sub-face 1   3: bottom sub-face 1
     {
-        const Role R = role_of(lane);
-        const float* fG = R.dn ? fGY : fGX;
-        const float* fC = R.dn ? fCY : fCX;
-        const float us = fU[R.pos], Ds = fD[R.pos], gs = fG[R.pos], Cs = fC[R.pos];
-        const float uh = fU[R.slot], Dh = fD[R.slot], gh = fG[R.slot], Ch = fC[R.slot];
-        const float h = R.dn ? hy : hx, rh = R.dn ? rhy : rhx;
-        const float rt = sel4(R.side, bb.rt[0], bb.rt[1], bb.rt[2], bb.rt[3]);
-        const float q = sel4(R.side, bb.q[0], bb.q[1], bb.q[2], bb.q[3]);
-        const float dS = 0.5f * h, dH = 0.5f * h * rt, inv = 2.0f * rh * q;
-        // low side: the halo cell is the owner (left), this cell the neighbour
-        const float X = adv_flux(R.low ? uh : us, R.low ? us : uh, R.low ? gh : gs, R.low ? gs : gh, R.low ? Dh : Ds,
-                                 R.low ? Ds : Dh, R.low ? Ch : Cs, R.low ? Cs : Ch, R.low ? dH : dS, R.low ? dS : dH,
-                                 inv);
-        ex[lane] = X;
+        const int g = (lane >> 3) & 3, t = lane & 7;
+        const int dn = g & 1, k = g >> 1;
+        const int pos = dn ? t : 8 * t;
+        const int slot = 64 + (dn * 16 + t) * 2 + k;  // side = 2*dn
+        const float* fG = dn ? fGY : fGX;
+        const float* fC = dn ? fCY : fCX;
+        ex[lane] = adv_flux(fU[slot], fU[pos], fG[slot], fG[pos], fD[slot], fD[pos], fC[slot], fC[pos],
+                            dn ? dBs[2] : dBs[0], dn ? 0.5f * hy : 0.5f * hx, dn ? invs[2] : invs[0]);
     }
+    // ---- second sub-faces of the HIGH sides exist only next to finer blocks (~5 % of the sides): wave-uniform
+    float FR1 = FR, FT1 = FT;
+    if (bb.type[1] == SIDE_FINE)
+        FR1 = adv_flux(uc, fU[L.nidx[1] + 1], gxc, fGX[L.nidx[1] + 1], Dc, fD[L.nidx[1] + 1], cxc, fCX[L.nidx[1] + 1],
+                       0.5f * hx, dBs[1], invs[1]);
+    if (bb.type[3] == SIDE_FINE)
+        FT1 = adv_flux(uc, fU[L.nidx[3] + 1], gyc, fGY[L.nidx[3] + 1], Dc, fD[L.nidx[3] + 1], cyc, fCY[L.nidx[3] + 1],
+                       0.5f * hy, dBs[3], invs[3]);
     // interior faces: left flux = right flux of lane-1, bottom flux = top flux of lane-8
     const float FLs = __shfl_up(FR, 1, 64);
     const float FBs = __shfl_up(FT, 8, 64);
     wave_lds_sync();
     const float eL = 0.5f * (ex[L.j] + ex[16 + L.j]), eB = 0.5f * (ex[8 + L.i] + ex[24 + L.i]);
-    const float eR = 0.5f * (FR + ex[32 + L.j]), eT = 0.5f * (FT + ex[40 + L.i]);
     const float FL = L.edge[0] ? eL : FLs;
     const float FB = L.edge[2] ? eB : FBs;
-    FR = L.edge[1] ? eR : FR;
-    FT = L.edge[3] ? eT : FT;
+    FR = L.edge[1] ? 0.5f * (FR + FR1) : FR;
+    FT = L.edge[3] ? 0.5f * (FT + FT1) : FT;
     const float res = -((FR - FL) * rhx) - ((FT - FB) * rhy);
     if (!L.general) stg(ud, c, res);
 }
