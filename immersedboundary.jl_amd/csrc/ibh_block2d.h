@@ -207,7 +207,6 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
                                           const float* __restrict__ C, uint32_t ldc, const float* __restrict__ G,
                                           float* __restrict__ ud, float* lds, int lane) {
     const BlockDesc2 bb = blocks[blk];  // by value: wave-uniform, lives in SGPRs, no per-lane descriptor loads
-    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
     const uint32_t c = (uint32_t)bb.base + lane;
     float* fU = lds;
     float* fD = lds + 128;
@@ -217,8 +216,12 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
     float* fCY = lds + 640;
     float* ex = lds + 768;
     const float* Gs = G + (size_t)2 * nc;
+    // issue order: halo table (needs nothing), own-cell loads (need the descriptor), and only then the
+    // gathers that wait for the table -- the scheduling barrier keeps them from being hoisted in between
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
     const float uc = ldg(u, c), Dc = ldg(Gs, c), gxc = ldg(G, c), gyc = ldg(G + nc, c);
     const float cxc = ldg(C, c), cyc = ldg(C + ldc, c);
+    __builtin_amdgcn_sched_barrier(0);
     // halo slot of this lane: sides 0,1 need the x-gradient / Cx of the neighbour, sides 2,3 the y ones
     const int dn = lane >> 5;
 #ifdef IBH_ABLATE_NOHALO
