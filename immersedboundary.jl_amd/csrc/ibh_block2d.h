@@ -309,7 +309,7 @@ __device__ __forceinline__ void euler_side(const float* P, int dn, const Gas& ga
     Q[2] = rho * P[2];
     Q[3] = rho * P[3];
     un = dn ? P[3] : P[2];
-    a = sqrtf(gas.gamma * gas.R * T);
+    a = __builtin_amdgcn_sqrtf(gas.gamma * gas.R * T);  // v_sqrt_f32 (1 ulp); the literal path keeps IEEE sqrtf
     F[0] = Q[0] * un;
     F[1] = (Q[1] + p) * un;
     F[2] = Q[2] * un + (dn ? 0.0f : p);
@@ -396,7 +396,9 @@ __device__ __forceinline__ void passB_euler(const BlockDesc2* __restrict__ block
     wave_lds_sync();
 
     const float hx = bb.h[0], hy = bb.h[1], rhx = bb.rh[0], rhy = bb.rh[1];
-    float FR[4], FT[4];
+    const float dBs[4] = {0.5f * hx * bb.rt[0], 0.5f * hx * bb.rt[1], 0.5f * hy * bb.rt[2], 0.5f * hy * bb.rt[3]};
+    const float invs[4] = {2.0f * rhx * bb.q[0], 2.0f * rhx * bb.q[1], 2.0f * rhy * bb.q[2], 2.0f * rhy * bb.q[3]};
+    float FR[4], FT[4], FR1[4], FT1[4];
     {
         float Pb[4], gb[4];
 #pragma unroll
@@ -404,37 +406,59 @@ __device__ __forceinline__ void passB_euler(const BlockDesc2* __restrict__ block
             Pb[v] = nb1(fP + v * 128, L, 1);
             gb[v] = nb1(fGX + v * 128, L, 1);
         }
-        euler_flux(Pc, Pb, gxc, gb, Dc, nb1(fD, L, 1), 0.5f * hx, 0.5f * hx * L.rt[1], 2.0f * rhx * L.q[1], 0, gas, FR);
+        euler_flux(Pc, Pb, gxc, gb, Dc, nb1(fD, L, 1), 0.5f * hx, L.edge[1] ? dBs[1] : 0.5f * hx,
+                   L.edge[1] ? invs[1] : rhx, 0, gas, FR);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             Pb[v] = nb1(fP + v * 128, L, 3);
             gb[v] = nb1(fGY + v * 128, L, 3);
         }
-        euler_flux(Pc, Pb, gyc, gb, Dc, nb1(fD, L, 3), 0.5f * hy, 0.5f * hy * L.rt[3], 2.0f * rhy * L.q[3], 1, gas, FT);
+        euler_flux(Pc, Pb, gyc, gb, Dc, nb1(fD, L, 3), 0.5f * hy, L.edge[3] ? dBs[3] : 0.5f * hy,
+                   L.edge[3] ? invs[3] : rhy, 1, gas, FT);
     }
-    {   // extra pass (same role map as the advection kernel)
-        const Role R = role_of(lane);
-        const float* fG = R.dn ? fGY : fGX;
-        float Pa[4], Pb[4], ga[4], gb[4];
+    {   // extra pass, low sides only (halo cell = owner): role lane r < 32, g = r>>3:
+        //   0: left sub-face 0   1: bottom sub-face 0   2: left sub-face 1   3: bottom sub-face 1
+        const int g = (lane >> 3) & 3, t = lane & 7;
+        const int dn = g & 1, k = g >> 1;
+        const int pos = dn ? t : 8 * t;
+        const int slot = 64 + (dn * 16 + t) * 2 + k;
+        const float* fG = dn ? fGY : fGX;
+        float Pa[4], Pb[4], ga[4], gb[4], X[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const float ps = fP[v * 128 + R.pos], ph = fP[v * 128 + R.slot];
-            const float gs = fG[v * 128 + R.pos], gh = fG[v * 128 + R.slot];
-            Pa[v] = R.low ? ph : ps;
-            Pb[v] = R.low ? ps : ph;
-            ga[v] = R.low ? gh : gs;
-            gb[v] = R.low ? gs : gh;
+            Pa[v] = fP[v * 128 + slot];
+            Pb[v] = fP[v * 128 + pos];
+            ga[v] = fG[v * 128 + slot];
+            gb[v] = fG[v * 128 + pos];
         }
-        const float Ds = fD[R.pos], Dh = fD[R.slot];
-        const float h = R.dn ? hy : hx, rh = R.dn ? rhy : rhx;
-        const float rt = sel4(R.side, bb.rt[0], bb.rt[1], bb.rt[2], bb.rt[3]);
-        const float q = sel4(R.side, bb.q[0], bb.q[1], bb.q[2], bb.q[3]);
-        const float dS = 0.5f * h, dH = 0.5f * h * rt, inv = 2.0f * rh * q;
-        float X[4];
-        euler_flux(Pa, Pb, ga, gb, R.low ? Dh : Ds, R.low ? Ds : Dh, R.low ? dH : dS, R.low ? dS : dH, inv, R.dn, gas,
-                   X);
+        euler_flux(Pa, Pb, ga, gb, fD[slot], fD[pos], dn ? dBs[2] : dBs[0], dn ? 0.5f * hy : 0.5f * hx,
+                   dn ? invs[2] : invs[0], dn, gas, X);
 #pragma unroll
         for (int v = 0; v < 4; ++v) ex[v * 64 + lane] = X[v];
+    }
+    // second sub-faces of the HIGH sides exist only next to finer blocks: wave-uniform branches
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        FR1[v] = FR[v];
+        FT1[v] = FT[v];
+    }
+    if (bb.type[1] == SIDE_FINE) {
+        float Pb[4], gb[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            Pb[v] = fP[v * 128 + L.nidx[1] + 1];
+            gb[v] = fGX[v * 128 + L.nidx[1] + 1];
+        }
+        euler_flux(Pc, Pb, gxc, gb, Dc, fD[L.nidx[1] + 1], 0.5f * hx, dBs[1], invs[1], 0, gas, FR1);
+    }
+    if (bb.type[3] == SIDE_FINE) {
+        float Pb[4], gb[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            Pb[v] = fP[v * 128 + L.nidx[3] + 1];
+            gb[v] = fGY[v * 128 + L.nidx[3] + 1];
+        }
+        euler_flux(Pc, Pb, gyc, gb, Dc, fD[L.nidx[3] + 1], 0.5f * hy, dBs[3], invs[3], 1, gas, FT1);
     }
     float FLs[4], FBs[4];
 #pragma unroll
@@ -447,11 +471,10 @@ __device__ __forceinline__ void passB_euler(const BlockDesc2* __restrict__ block
     for (int v = 0; v < 4; ++v) {
         const float* e = ex + v * 64;
         const float eL = 0.5f * (e[L.j] + e[16 + L.j]), eB = 0.5f * (e[8 + L.i] + e[24 + L.i]);
-        const float eR = 0.5f * (FR[v] + e[32 + L.j]), eT = 0.5f * (FT[v] + e[40 + L.i]);
         const float fl = L.edge[0] ? eL : FLs[v];
         const float fb = L.edge[2] ? eB : FBs[v];
-        const float fr = L.edge[1] ? eR : FR[v];
-        const float ft = L.edge[3] ? eT : FT[v];
+        const float fr = L.edge[1] ? 0.5f * (FR[v] + FR1[v]) : FR[v];
+        const float ft = L.edge[3] ? 0.5f * (FT[v] + FT1[v]) : FT[v];
         const float res = -((fr - fl) * rhx) - ((ft - fb) * rhy);
         if (!L.general) stg(Rr + (size_t)v * ldr, c, res);
     }
