@@ -1,0 +1,205 @@
+// libibhip: 3-D counterpart of ibh_analyze.cpp -- recovers the 8x8x8 block structure of a Partition from
+// part.domain + the face lists and classifies every block side, verified face by face against what the
+// reference registered.  Cell numbering inside a block: local = i + 8*j + 64*k (mesher.jl:1064-1112).
+#include <unordered_map>
+
+#include "ibh_common.h"
+
+namespace {
+
+constexpr int NPB = 512;
+const int STR[3] = {1, 8, 64};
+
+// tangential dims of dim d, increasing
+inline void tang(int d, int& a, int& b) {
+    a = d == 0 ? 1 : 0;
+    b = d == 2 ? 1 : 2;
+}
+inline int pos3(int d, int n, int t1, int t2) {
+    int a, b;
+    tang(d, a, b);
+    return n * STR[d] + t1 * STR[a] + t2 * STR[b];
+}
+inline int coord(int pos, int d) { return (pos / STR[d]) % 8; }
+
+}  // namespace
+
+void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr,
+                         int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
+                         std::vector<int32_t>& htab) {
+    const int32_t nc = v.nc;
+    const float* hh[3] = {v.spacing, v.spacing + nc, v.spacing + 2 * (size_t)nc};
+    auto gid = [&](int32_t c) { return (int64_t)v.domain[c] - v.index_base; };
+
+    std::unordered_map<int64_t, int32_t> blockbase;
+    std::vector<int32_t> bases;
+    std::vector<char> in_full(nc, 0);
+    for (int32_t c = 0; c + NPB <= nc;) {
+        int64_t g = gid(c);
+        bool ok = (g % NPB == 0) && gid(c + NPB - 1) == g + NPB - 1;
+        if (ok)
+            for (int k = 1; k < NPB && ok; ++k)
+                ok = gid(c + k) == g + k && hh[0][c + k] == hh[0][c] && hh[1][c + k] == hh[1][c] &&
+                     hh[2][c + k] == hh[2][c];
+        if (ok) {
+            blockbase[g / NPB] = c;
+            bases.push_back(c);
+            for (int k = 0; k < NPB; ++k) in_full[c + k] = 1;
+            c += NPB;
+        } else {
+            ++c;
+        }
+    }
+    auto single = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& idx, int32_t c) -> int32_t {
+        return (off[c + 1] - off[c] == 1) ? idx[off[c]] : -1;
+    };
+    std::vector<char> cell_irr(nc, 0);
+    for (int32_t c = 0; c < nc; ++c) cell_irr[c] = !in_full[c];
+    int64_t counts[5] = {0, 0, 0, 0, 0};
+
+    for (int32_t base : bases) {
+        bool good = true;
+        for (int pos = 0; pos < NPB && good; ++pos) {
+            const int32_t c = base + pos;
+            for (int d = 0; d < 3 && good; ++d) {
+                const int x = coord(pos, d);
+                if (x < 7) {
+                    int32_t f = single(v.roff[d], v.ridx[d], c);
+                    good = f >= 0 && v.owners[d][f] == c && v.neighbors[d][f] == c + STR[d];
+                }
+                if (good && x > 0) {
+                    int32_t f = single(v.loff[d], v.lidx[d], c);
+                    good = f >= 0 && v.owners[d][f] == c - STR[d] && v.neighbors[d][f] == c;
+                }
+            }
+        }
+        if (!good) {
+            for (int k = 0; k < NPB; ++k) cell_irr[base + k] = 1;
+            continue;
+        }
+        BlockDesc3 b;
+        b.base = base;
+        for (int d = 0; d < 3; ++d) {
+            b.h[d] = hh[d][base];
+            b.rh[d] = 1.0f / b.h[d];
+        }
+        for (int s = 0; s < 6; ++s) {
+            const int d = s / 2;
+            const bool low = (s % 2) == 0;
+            const float hc = hh[d][base];
+            const std::vector<int32_t>& off = low ? v.loff[d] : v.roff[d];
+            const std::vector<int32_t>& idx = low ? v.lidx[d] : v.ridx[d];
+            int type = -1, sub = -1;
+            int32_t nb = -1;
+            bool ok = true;
+            for (int t = 0; t < 64 && ok; ++t) {
+                const int t1 = t % 8, t2 = t / 8;
+                const int32_t c = base + pos3(d, low ? 0 : 7, t1, t2);
+                if (off[c + 1] - off[c] != 1) { ok = false; break; }
+                const int32_t f = idx[off[c]];
+                const int32_t me = low ? v.neighbors[d][f] : v.owners[d][f];
+                const int32_t o = low ? v.owners[d][f] : v.neighbors[d][f];
+                if (me != c) { ok = false; break; }
+                int ty;
+                if (o == c) {
+                    ty = SIDE_MIRROR;
+                } else {
+                    if (!in_full[o]) { ok = false; break; }
+                    const int64_t g = gid(o);
+                    const int32_t ob = blockbase[g / NPB];
+                    const int pos = (int)(g % NPB);
+                    if (coord(pos, d) != (low ? 7 : 0)) { ok = false; break; }
+                    int a, bb2;
+                    tang(d, a, bb2);
+                    const int o1 = coord(pos, a), o2 = coord(pos, bb2);
+                    if (hh[d][o] == hc) {
+                        ty = SIDE_SAME;
+                        if (o1 != t1 || o2 != t2) { ok = false; break; }
+                        if (t == 0) nb = ob; else if (nb != ob) { ok = false; break; }
+                    } else if (hh[d][o] == hc * 2.0f) {
+                        ty = SIDE_COARSE;
+                        const int q1 = o1 - t1 / 2, q2 = o2 - t2 / 2;
+                        if ((q1 != 0 && q1 != 4) || (q2 != 0 && q2 != 4)) { ok = false; break; }
+                        const int q = q1 / 4 + 2 * (q2 / 4);
+                        if (t == 0) { nb = ob; sub = q; } else if (nb != ob || sub != q) { ok = false; break; }
+                    } else { ok = false; break; }
+                }
+                if (t == 0) type = ty; else if (type != ty) { ok = false; break; }
+            }
+            if (!ok) type = SIDE_GENERAL;
+            b.type[s] = type;
+            b.nb[s] = nb;
+            b.sub[s] = sub < 0 ? 0 : sub;
+            b.q[s] = type == SIDE_COARSE ? (1.0f / 3.0f) : 0.5f;
+            b.rt[s] = type == SIDE_COARSE ? 2.0f : 1.0f;
+            counts[type]++;
+            if (type == SIDE_GENERAL)
+                for (int t = 0; t < 64; ++t) cell_irr[base + pos3(d, low ? 0 : 7, t % 8, t / 8)] = 1;
+        }
+        blocks.push_back(b);
+    }
+    for (int32_t c = 0; c < nc; ++c)
+        if (cell_irr[c]) irr.push_back(c);
+
+    // overlap phases, as in 2-D
+    n_phase1[0] = n_phase1[1] = 0;
+    {
+        std::vector<char> is_image(nc, 0), dep(nc, 0);
+        for (int32_t k = 0; k < n_image; ++k) is_image[image_in_domain[k] - v.index_base] = 1;
+        for (int32_t c = 0; c < nc; ++c) dep[c] = !is_image[c];
+        for (int d = 0; d < v.nd; ++d)
+            for (size_t f = 0; f < v.owners[d].size(); ++f) {
+                int32_t o = v.owners[d][f], n = v.neighbors[d][f];
+                if (!is_image[o]) dep[n] = 1;
+                if (!is_image[n]) dep[o] = 1;
+            }
+        std::unordered_map<int32_t, int> base2a1;
+        std::vector<char> a1(blocks.size(), 0), b1(blocks.size(), 0);
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            bool ok = true;
+            for (int k = 0; k < NPB && ok; ++k) ok = !dep[blocks[b].base + k] && !cell_irr[blocks[b].base + k];
+            a1[b] = ok;
+            base2a1[blocks[b].base] = ok;
+        }
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            bool ok = a1[b];
+            for (int s = 0; s < 6 && ok; ++s) {
+                const int ty = blocks[b].type[s];
+                if (ty == SIDE_MIRROR) continue;
+                if (ty == SIDE_GENERAL) { ok = false; break; }
+                auto it = base2a1.find(blocks[b].nb[s]);
+                ok = it != base2a1.end() && it->second;
+            }
+            b1[b] = ok;
+        }
+        std::vector<BlockDesc3> ordered;
+        ordered.reserve(blocks.size());
+        for (size_t b = 0; b < blocks.size(); ++b) if (b1[b]) ordered.push_back(blocks[b]);
+        n_phase1[1] = (int32_t)ordered.size();
+        for (size_t b = 0; b < blocks.size(); ++b) if (a1[b] && !b1[b]) ordered.push_back(blocks[b]);
+        n_phase1[0] = (int32_t)ordered.size();
+        for (size_t b = 0; b < blocks.size(); ++b) if (!a1[b]) ordered.push_back(blocks[b]);
+        blocks.swap(ordered);
+    }
+    htab.resize(blocks.size() * 384);
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        const BlockDesc3& b = blocks[bi];
+        for (int s = 0; s < 6; ++s) {
+            const int d = s / 2;
+            const bool low = (s % 2) == 0;
+            for (int t = 0; t < 64; ++t) {
+                const int t1 = t % 8, t2 = t / 8;
+                int32_t cell;
+                if (b.type[s] == SIDE_SAME) cell = b.nb[s] + pos3(d, low ? 7 : 0, t1, t2);
+                else if (b.type[s] == SIDE_COARSE)
+                    cell = b.nb[s] + pos3(d, low ? 7 : 0, 4 * (b.sub[s] & 1) + t1 / 2, 4 * (b.sub[s] >> 1) + t2 / 2);
+                else cell = b.base + pos3(d, low ? 0 : 7, t1, t2);
+                htab[bi * 384 + s * 64 + t] = cell;
+            }
+        }
+    }
+    info[0] = (int64_t)blocks.size();
+    info[1] = (int64_t)irr.size();
+    for (int k = 0; k < 5; ++k) info[2 + k] = counts[k];
+    info[7] = n_phase1[1];
+}

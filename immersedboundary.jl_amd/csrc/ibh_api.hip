@@ -22,6 +22,7 @@ int ibh_upload(T** dptr, const T* host, size_t n) {
 template int ibh_upload<int32_t>(int32_t**, const int32_t*, size_t);
 template int ibh_upload<float>(float**, const float*, size_t);
 template int ibh_upload<BlockDesc2>(BlockDesc2**, const BlockDesc2*, size_t);
+template int ibh_upload<BlockDesc3>(BlockDesc3**, const BlockDesc3*, size_t);
 
 extern "C" {
 
@@ -159,6 +160,22 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         p->n_irr = (int32_t)irr.size();
         if ((rc = ibh_upload(&p->blocks2, blocks.data(), blocks.size()))) return rc;
         if ((rc = ibh_upload(&p->irr_cells, irr.data(), irr.size()))) return rc;
+    } else if (domain && block_size == 8 && nd == 3) {
+        std::vector<BlockDesc3> blocks;
+        std::vector<int32_t> irr, htab;
+        int32_t nph[2] = {0, 0};
+        std::vector<int32_t> none;
+        const bool have_img = n_image > 0 && image_in_domain;
+        ibh_analyze_blocks3(v, blocks, irr, p->info, have_img ? image_in_domain : none.data(), have_img ? n_image : 0,
+                            nph, htab);
+        p->nA1 = nph[0];
+        p->nB1 = nph[1];
+        p->bs = block_size;
+        p->nblk = (int32_t)blocks.size();
+        p->n_irr = (int32_t)irr.size();
+        if ((rc = ibh_upload(&p->blocks3, blocks.data(), blocks.size()))) return rc;
+        if ((rc = ibh_upload(&p->htab3, htab.data(), htab.size()))) return rc;
+        if ((rc = ibh_upload(&p->irr_cells, irr.data(), irr.size()))) return rc;
     } else {
         p->info[0] = 0;
         p->info[1] = nc;
@@ -179,6 +196,8 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->image_in_domain);
     hipFree(p->blocks2);
     hipFree(p->htab);
+    hipFree(p->blocks3);
+    hipFree(p->htab3);
     hipFree(p->irr_cells);
     hipFree(p->G);
     delete p;

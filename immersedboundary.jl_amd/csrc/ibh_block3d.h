@@ -1,0 +1,185 @@
+// Block fast path, 3-D, 8x8x8 blocks: one 512-thread workgroup (8 wavefronts) per block, thread = cell
+// (x fastest: tid = i + 8j + 64k).  Same scheme as the 2-D path (ibh_block2d.h): branch-free, per-block
+// halo-cell table, reciprocal arithmetic, every face flux computed once (the +x/+y/+z faces by their owner
+// thread, the low-side block faces by 192 otherwise idle threads) and exchanged through LDS.
+// Sides: SAME / MIRROR / 2:1 COARSE; sides facing finer blocks are GENERAL (face-list body), so every
+// boundary cell has exactly one face.  LDS field layout: [tile 512 | halo 384], halo slot = side*64 + t.
+#pragma once
+#include "ibh_block2d.h"
+
+namespace blk3 {
+
+#pragma clang fp contract(fast)
+
+using blk2::adv_flux;
+using blk2::ldg;
+using blk2::stg;
+
+struct Lane3 {
+    int i, j, k;
+    bool edge[6];
+    bool general;
+    int nidx[6];  // index of the neighbour across direction s in a [tile | halo] field
+    float q[6];
+};
+
+__device__ __forceinline__ Lane3 lane_info(const BlockDesc3& b, int tid) {
+    Lane3 L;
+    L.i = tid & 7;
+    L.j = (tid >> 3) & 7;
+    L.k = tid >> 6;
+    L.edge[0] = L.i == 0;
+    L.edge[1] = L.i == 7;
+    L.edge[2] = L.j == 0;
+    L.edge[3] = L.j == 7;
+    L.edge[4] = L.k == 0;
+    L.edge[5] = L.k == 7;
+    const int t[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
+    const int off[6] = {-1, 1, -8, 8, -64, 64};
+    L.general = false;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        L.general |= L.edge[s] && b.type[s] == SIDE_GENERAL;
+        L.nidx[s] = L.edge[s] ? 512 + s * 64 + t[s >> 1] : tid + off[s];
+        L.q[s] = L.edge[s] ? b.q[s] : 0.5f;
+    }
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------
+// pass A (scalar field): gradients along x, y, z + JST sensor.  LDS: 896 floats.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void passA(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                      int32_t blk, uint32_t nc, const float* __restrict__ u, float* __restrict__ G,
+                                      float* lds, int tid) {
+    const BlockDesc3 bb = blocks[blk];
+    const uint32_t c = (uint32_t)bb.base + tid;
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
+    const float uc = ldg(u, c);
+    const float hv = ldg(u, hidx);
+    lds[tid] = uc;
+    if (tid < 384) lds[512 + tid] = hv;
+    const Lane3 L = lane_info(bb, tid);
+    __syncthreads();
+    float g[3], D = 1e-7f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float rh = bb.rh[d];
+        const float l = lds[L.nidx[2 * d]], r = lds[L.nidx[2 * d + 1]];
+        const float fr = uc + L.q[2 * d + 1] * (r - uc);  // at_faces: (1-q)*u_self + q*u_nb
+        const float fl = uc + L.q[2 * d] * (l - uc);
+        g[d] = (fr - fl) * rh;
+        const float dr = r - uc, dl = uc - l;
+        const float gg = (dr - dl) * rh;
+        const float ugg = (fabsf(dr) + fabsf(dl)) * rh;
+        D = fmaxf(D, (1e-7f + fabsf(gg)) * __builtin_amdgcn_rcpf(1e-7f + ugg));
+    }
+    if (!L.general) {
+        stg(G, c, g[0]);
+        stg(G + nc, c, g[1]);
+        stg(G + (size_t)2 * nc, c, g[2]);
+        stg(G + (size_t)3 * nc, c, D);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass B, advection.  LDS (floats): fU 896 | fD 896 | tG 3x512 | hG 384 | tC 3x512 | hC 384 | ex 192 | F 3x512
+// ------------------------------------------------------------------------------------------
+#define BLK3_PASSB_LDS (896 * 2 + 1536 + 384 + 1536 + 384 + 192 + 1536)
+
+__device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                          int32_t blk, uint32_t nc, const float* __restrict__ u,
+                                          const float* __restrict__ C, uint32_t ldc, const float* __restrict__ G,
+                                          float* __restrict__ ud, float* lds, int tid) {
+    const BlockDesc3 bb = blocks[blk];
+    const uint32_t c = (uint32_t)bb.base + tid;
+    float* fU = lds;
+    float* fD = lds + 896;
+    float* tG = lds + 1792;          // [3][512]
+    float* hG = lds + 1792 + 1536;   // [384]
+    float* tC = hG + 384;            // [3][512]
+    float* hC = tC + 1536;           // [384]
+    float* ex = hC + 384;            // [192]
+    float* FF = ex + 192;            // [3][512]
+    const float* Gs = G + (size_t)3 * nc;
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
+    const float uc = ldg(u, c), Dc = ldg(Gs, c);
+    float gc[3], cc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        gc[d] = ldg(G + (size_t)d * nc, c);
+        cc[d] = ldg(C + (size_t)d * ldc, c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int dnh = tid >> 7;  // normal dim of this thread's halo slot (side = tid >> 6)
+    const float hu = ldg(u, hidx), hD = ldg(Gs, hidx);
+    const float hg = ldg(G + (size_t)(dnh < 3 ? dnh : 0) * nc, hidx);
+    const float hc = ldg(C + (size_t)(dnh < 3 ? dnh : 0) * ldc, hidx);
+    fU[tid] = uc;
+    fD[tid] = Dc;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        tG[d * 512 + tid] = gc[d];
+        tC[d * 512 + tid] = cc[d];
+    }
+    if (tid < 384) {
+        fU[512 + tid] = hu;
+        fD[512 + tid] = hD;
+        hG[tid] = hg;
+        hC[tid] = hc;
+    }
+    const Lane3 L = lane_info(bb, tid);
+    __syncthreads();
+
+    float dBs[6], invs[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        dBs[s] = 0.5f * bb.h[s >> 1] * bb.rt[s];
+        invs[s] = 2.0f * bb.rh[s >> 1] * bb.q[s];
+    }
+    // ---- main pass: the +x, +y, +z face of every cell
+    float F[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int s = 2 * d + 1;
+        const bool e = L.edge[s];
+        const int ni = L.nidx[s];
+        const float gb = e ? hG[ni - 512] : tG[d * 512 + ni];
+        const float Cb = e ? hC[ni - 512] : tC[d * 512 + ni];
+        const float hd = 0.5f * bb.h[d];
+        F[d] = adv_flux(uc, fU[ni], gc[d], gb, Dc, fD[ni], cc[d], Cb, hd, e ? dBs[s] : hd, e ? invs[s] : bb.rh[d]);
+    }
+    // ---- extra pass: the 3 x 64 low-side block faces (halo cell = owner), threads 0..191
+    {
+        const int r = tid < 192 ? tid : 0;
+        const int dn = r >> 6, t = r & 63;
+        const int t1 = t & 7, t2 = t >> 3;
+        const int pos = dn == 0 ? 8 * t1 + 64 * t2 : dn == 1 ? t1 + 64 * t2 : t;
+        const int slot = dn * 128 + t;  // side 2*dn
+        const float hd = 0.5f * (dn == 0 ? bb.h[0] : dn == 1 ? bb.h[1] : bb.h[2]);
+        const float dB = dn == 0 ? dBs[0] : dn == 1 ? dBs[2] : dBs[4];
+        const float inv = dn == 0 ? invs[0] : dn == 1 ? invs[2] : invs[4];
+        const float X = adv_flux(fU[512 + slot], fU[pos], hG[slot], tG[dn * 512 + pos], fD[512 + slot], fD[pos], hC[slot],
+                                 tC[dn * 512 + pos], dB, hd, inv);
+        if (tid < 192) ex[tid] = X;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) FF[d * 512 + tid] = F[d];
+    __syncthreads();
+    // low-side fluxes: from the extra pass on block sides, from the neighbour thread inside the block
+    // (ex and FF are contiguous: ex at FF - 192)
+    const int tt[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
+    const int offm[3] = {1, 8, 64};
+    float res = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int idx = L.edge[2 * d] ? (d * 64 + tt[d]) - 192 : d * 512 + tid - offm[d];
+        const float Flow = FF[idx];
+        res = res - (F[d] - Flow) * bb.rh[d];
+    }
+    if (!L.general) stg(ud, c, res);
+}
+
+#pragma clang fp contract(off)
+
+}  // namespace blk3

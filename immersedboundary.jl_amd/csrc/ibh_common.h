@@ -33,6 +33,21 @@ struct BlockDesc2 {  // 2-D
 // averaging the two sub-faces is exact), MIRROR sides name the boundary cell itself, GENERAL sides too
 // (their lanes are handled by the face-list body and never stored).
 
+// 3-D: one full 8x8x8 block (512 consecutive local ids).  side s = 2*d + (0 low / 1 high); boundary cell of a
+// side indexed t = t1 + 8*t2 over the two tangential dims in increasing order.  The 3-D fast path takes
+// SAME / MIRROR / COARSE (2:1) sides; sides facing finer blocks are GENERAL (face-list body), so every
+// boundary cell has exactly one face and the halo table has one slot per (side, t): htab3[blk][s*64 + t].
+struct BlockDesc3 {
+    int32_t base;
+    int32_t type[6];
+    int32_t nb[6];
+    int32_t sub[6];
+    float h[3];
+    float rh[3];
+    float q[6];
+    float rt[6];
+};
+
 struct DimData {
     int32_t nf = 0;
     int32_t *owners = nullptr, *neighbors = nullptr;  // [nf] 0-based
@@ -54,6 +69,8 @@ struct ibh_part {
     int32_t nA1 = 0, nB1 = 0;    // blocks [0,nA1): pass A independent of skirt data; [0,nB1): pass B too
     BlockDesc2* blocks2 = nullptr;
     int32_t* htab = nullptr;     // [nblk][64] halo cell table, same order as blocks2
+    BlockDesc3* blocks3 = nullptr;  // 3-D block table (nd == 3)
+    int32_t* htab3 = nullptr;    // [nblk][384]
     int32_t n_irr = 0;           // cells handled by the general kernels when the fast path is on
     int32_t* irr_cells = nullptr;
     int64_t info[8] = {0};
@@ -109,6 +126,10 @@ struct HostPartView {
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
                          std::vector<int32_t>& irr_cells, int64_t* info, const int32_t* image_in_domain,
                          int32_t n_image, int32_t* n_phase1, std::vector<int32_t>& htab);
+
+void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
+                         int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
+                         std::vector<int32_t>& htab);
 
 static inline int ibh_grid(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;

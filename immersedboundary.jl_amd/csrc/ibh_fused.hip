@@ -391,6 +391,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 }  // namespace
 
 #include "ibh_block2d.h"
+#include "ibh_block3d.h"
 
 namespace {
 
@@ -453,6 +454,25 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
     passB_adv_cell<ND>(p, u, C, ldc, G, ud, c);
 }
 
+// 3-D block kernels: one 512-thread workgroup per 8x8x8 block (the face-list cells get their own launch)
+__global__ __launch_bounds__(512) void k_passA3_blk(uint32_t nc, const float* __restrict__ u, float* __restrict__ G,
+                                                    const BlockDesc3* __restrict__ blocks,
+                                                    const int32_t* __restrict__ htab, int32_t nblk) {
+    __shared__ float lds[896];
+    const int32_t blk = xcd_remap(blockIdx.x, nblk);
+    blk3::passA(blocks, htab, blk, nc, u, G, lds, threadIdx.x);
+}
+
+__global__ __launch_bounds__(512) void k_passB3_adv_blk(uint32_t nc, const float* __restrict__ u,
+                                                        const float* __restrict__ C, uint32_t ldc,
+                                                        const float* __restrict__ G, float* __restrict__ ud,
+                                                        const BlockDesc3* __restrict__ blocks,
+                                                        const int32_t* __restrict__ htab, int32_t nblk) {
+    __shared__ float lds[BLK3_PASSB_LDS];
+    const int32_t blk = xcd_remap(blockIdx.x, nblk);
+    blk3::passB_adv(blocks, htab, blk, nc, u, C, ldc, G, ud, lds, threadIdx.x);
+}
+
 // Euler pass B: the block body and the face-list body are separate kernels (the Float64 flux combine of
 // the literal face-list body needs ~120 VGPRs and would halve the occupancy of the block body).
 __global__ __launch_bounds__(64 * WPB) void k_passB_euler_blk(uint32_t nc, const float* __restrict__ P, uint32_t ldp,
@@ -507,6 +527,32 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     if (p->nc == 0) return 0;
     int rc = ensure_G(p, (size_t)(p->nd + 1) * p->nc);
     if (rc) return rc;
+    if (p->nd == 3 && p->bs == 8 && p->blocks3 && p->nblk > 0 && !(flags & (IBH_FORCE_GENERAL | IBH_EXACT))) {
+        // 3-D block path: block kernels over the requested block range + face-list kernels over the rest
+        const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
+        IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
+        const int32_t a0 = ph2 ? p->nA1 : 0, a1 = ph1 ? p->nA1 : p->nblk;
+        const int32_t b0 = ph2 ? p->nB1 : 0, b1 = ph1 ? p->nB1 : p->nblk;
+        const int32_t nI = ph1 ? 0 : p->n_irr;
+        PartView v = view(p);
+        const bool doA = !(flags & IBH_PASS_B_ONLY), doB = !(flags & IBH_PASS_A_ONLY);
+        if (doA && a1 > a0)
+            hipLaunchKernelGGL(k_passA3_blk, dim3(a1 - a0), dim3(512), 0, ibh_stream, (uint32_t)p->nc, u, p->G,
+                               p->blocks3 + a0, p->htab3 + (size_t)a0 * 384, a1 - a0);
+        if (doA && nI)
+            hipLaunchKernelGGL((k_passA<3, 1, true>), dim3((nI + 64 * WPB - 1) / (64 * WPB)), dim3(64 * WPB), 0, ibh_stream,
+                               v, u, (int64_t)p->nc, p->G, (const BlockDesc2*)nullptr, (const int32_t*)nullptr, 0, 0,
+                               p->irr_cells, nI);
+        if (doB && b1 > b0)
+            hipLaunchKernelGGL(k_passB3_adv_blk, dim3(b1 - b0), dim3(512), 0, ibh_stream, (uint32_t)p->nc, u, C,
+                               (uint32_t)ldc, p->G, ud, p->blocks3 + b0, p->htab3 + (size_t)b0 * 384, b1 - b0);
+        if (doB && nI)
+            hipLaunchKernelGGL((k_passB_adv<3, true>), dim3((nI + 64 * WPB - 1) / (64 * WPB)), dim3(64 * WPB), 0,
+                               ibh_stream, v, u, C, ldc, p->G, ud, (const BlockDesc2*)nullptr, (const int32_t*)nullptr, 0,
+                               0, p->irr_cells, nI);
+        IBH_LAUNCH_CHECK();
+        return 0;
+    }
     const bool fast = p->bs == 8 && p->nd == 2 && p->nblk > 0 && !(flags & IBH_FORCE_GENERAL);
     const int bpwg = WPB;  // blocks per workgroup
     // overlap phases: INTERIOR = blocks independent of skirt data, BOUNDARY = the rest + face-list cells
