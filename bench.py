@@ -30,14 +30,47 @@ WORKLOADS = {
     "rae2822_0.87M": (2.5e-4, 1.25e-4),
     "rae2822_3.47M": (6e-5, 3e-5),
     "rae2822_37k": (1e-2, 5e-3),
+    # 3-D (secondary): unit sphere (icosphere STL) in a [-8,8]^3 box, 8^3 blocks (BASELINE.json configs[3] shape)
+    "sphere3d_1.6M": 0.06,
+    "sphere3d_4.6M": 0.03,
 }
+
+
+def icosphere(radius=1.0, subdiv=3):
+    """Triangulated sphere as a Stereolitography (the reference reads such surfaces from STL files)."""
+    from ibamd.mesher import Stereolitography
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]])
+    for _ in range(subdiv):
+        nv, nf, cache = list(v), [], {}
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                nv.append((nv[a] + nv[b]) / 2)
+                cache[k] = len(nv) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v, f = np.array(nv), np.array(nf)
+    v = v / np.linalg.norm(v, axis=1, keepdims=True) * radius
+    return Stereolitography(v.T.astype(np.float32), (f.T + 1).astype(np.int64))
 
 
 def build_mesh(name):
     import ibamd
     from ibamd.mesher import DistanceField, Mesh, Stereolitography, feature_regions, merge_points
-    hw, hf = WORKLOADS[name]
     f32 = np.float32
+    if name.startswith("sphere3d"):
+        msh = Mesh(f32([-8, -8, -8]), f32([16, 16, 16]), ("sphere", icosphere(), f32(WORKLOADS[name])))
+        msh.distance_fields = {}  # the sweep benchmark builds no ghost-cell boundaries
+        return msh
+    hw, hf = WORKLOADS[name]
     stl = merge_points(Stereolitography(os.path.join(ROOT, "tests", "golden", "rae2822.dat")))
     features = DistanceField(feature_regions(stl, radius=0.05))
     return Mesh(f32([-25.0, -25.0]), f32([50.0, 50.0]), ("wall", stl, f32(hw)),
@@ -45,12 +78,14 @@ def build_mesh(name):
 
 
 def synthetic_fields(centers, seed=12345):
-    """u = sin(2 pi x) cos(2 pi y) + 0.1 noise, C = (1, 1)  (SURVEY.md 8d)."""
+    """u = sin(2 pi x) cos(2 pi y) [+ 0.3 z] + 0.1 noise, C = (1, ..., 1)  (SURVEY.md 8d)."""
     rng = np.random.default_rng(seed)
     x, y = centers[:, 0].astype(np.float64), centers[:, 1].astype(np.float64)
-    u = (np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) + 0.1 * rng.uniform(-1, 1, x.size)).astype(np.float32)
-    C = np.ones((x.size, 2), dtype=np.float32)
-    return u, C
+    u = np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) + 0.1 * rng.uniform(-1, 1, x.size)
+    if centers.shape[1] == 3:
+        u = u + 0.3 * centers[:, 2]
+    C = np.ones((x.size, centers.shape[1]), dtype=np.float32)
+    return u.astype(np.float32), C
 
 
 def cpu_baseline(part, u, C, budget_s=12.0):
@@ -136,8 +171,9 @@ def main():
 
     msh = build_mesh(args.workload)
     ncells = len(msh)
+    npb = msh.block_size ** msh.ndims
     mps = -(-ncells // world)
-    mps = -(-mps // 64) * 64  # block-aligned partitions
+    mps = -(-mps // npb) * npb  # block-aligned partitions
     dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=False, only=[rank + 1])
     part = dom.partitions[rank + 1]
     n_image = int(part.image.size)
@@ -282,7 +318,11 @@ def main():
     tB = time_pass(ibamd.IBH_PASS_B_ONLY, reps)
     tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
     cells_launch = dpart.nc
-    b_alg = 32.0 if euler else B_ALG_2D  # R2 = 2 * 4 * (nd + 2) B/cell in 2-D
+    is3d = msh.ndims == 3
+    if is3d and (euler or world > 1):
+        raise SystemExit("3-D workloads: scalar sweep on one GPU only (secondary measurement)")
+    # R1 = 4*(1 + nd + 1) B/cell, R2 = 2 * 4 * (nd + 2) B/cell
+    b_alg = 32.0 if euler else (20.0 if is3d else B_ALG_2D)
     achieved = b_alg * cells_launch / tB / 1e9
     # HBM-side traffic of one pass-B launch from the committed PMC passes of this build (separate
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
@@ -297,18 +337,20 @@ def main():
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_passB_euler_blk" if euler else "k_passB_adv<2,false>",
+                "kernel": "k_passB_euler_blk" if euler else ("k_passB3_adv_blk" if is3d else "k_passB_adv<2,false>"),
                 "kernel_us": round(tB * 1e6, 3), "passA_us": round(tA * 1e6, 3),
                 "alg_bytes_per_cell": b_alg, "cells_per_launch": cells_launch,
                 "sweep_frac": round(b_alg * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
 
     out = {
-        "metric": "Mcells*iters/s residual sweep (%s), 2D RAE2822" % ("Euler HLL-JST-MUSCL" if euler else "advection-JST-MUSCL"),
+        "metric": "Mcells*iters/s residual sweep (%s), %s" % ("Euler HLL-JST-MUSCL" if euler else "advection-JST-MUSCL",
+                                                              "3D sphere" if is3d else "2D RAE2822"),
         "value": round(value, 2), "unit": "Mcells*iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: 2D RAE2822 block quadtree, {ncells} cells, "
-                               f"{msh.nblocks} 8x8 blocks, {world} partition(s), skirt depth 2, "
+        "config": {"workload": f"{args.workload}: {'3D sphere block octree' if is3d else '2D RAE2822 block quadtree'}, "
+                               f"{ncells} cells, {msh.nblocks} {'8x8x8' if is3d else '8x8'} blocks, "
+                               f"{world} partition(s), skirt depth 2, "
                                f"{'R2 Euler HLL' if euler else 'R1 advection'}-JST-MUSCL residual, fields resident in HBM",
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
                    "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else "block-fast-path"),
@@ -321,7 +363,7 @@ def main():
                    "block_analysis": dpart.info},
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler and not is3d:
         v, n, secs = cpu_baseline(part, u_h, C_h)
         out["cpu_baseline"] = {"value": round(v, 3), "unit": "Mcells*iters/s", "cores": 1, "kind": "port",
                                "sample": f"{n} sweeps of the same {u_h.shape[0]}-cell partition in {secs:.1f} s, "

@@ -180,6 +180,34 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         p->info[0] = 0;
         p->info[1] = nc;
     }
+    // flattened stencil records of the face-list cells
+    if (p->n_irr > 0) {
+        std::vector<int32_t> irr(p->n_irr);
+        IBH_HIP(hipMemcpy(irr.data(), p->irr_cells, sizeof(int32_t) * p->n_irr, hipMemcpyDeviceToHost));
+        const size_t n = (size_t)p->n_irr;
+        std::vector<int32_t> rec((size_t)nd * 2 * 5 * n, 0);
+        bool ok = true;
+        for (size_t t = 0; t < n && ok; ++t) {
+            const int32_t cc = irr[t];
+            for (int d = 0; d < nd && ok; ++d)
+                for (int side = 0; side < 2 && ok; ++side) {
+                    const std::vector<int32_t>& off = side ? v.roff[d] : v.loff[d];
+                    const std::vector<int32_t>& idx = side ? v.ridx[d] : v.lidx[d];
+                    const int cnt = off[cc + 1] - off[cc];
+                    if (cnt > 4) { ok = false; break; }
+                    const size_t q = (size_t)(2 * d + side);
+                    rec[(q * 5) * n + t] = cnt;
+                    for (int k = 0; k < cnt; ++k) {
+                        const int32_t f = idx[off[cc] + k];
+                        const int32_t o = v.owners[d][f], nn = v.neighbors[d][f];
+                        // left face: this cell is the neighbour, the other cell is the owner (and vice versa)
+                        if ((side ? o : nn) != cc) { ok = false; break; }
+                        rec[(q * 5 + 1 + k) * n + t] = side ? nn : o;
+                    }
+                }
+        }
+        if (ok && (rc = ibh_upload(&p->irr_rec, rec.data(), rec.size()))) return rc;
+    }
     *out = p;
     return 0;
 }
@@ -199,6 +227,7 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->blocks3);
     hipFree(p->htab3);
     hipFree(p->irr_cells);
+    hipFree(p->irr_rec);
     hipFree(p->G);
     delete p;
     return 0;

@@ -73,6 +73,11 @@ struct ibh_part {
     int32_t* htab3 = nullptr;    // [nblk][384]
     int32_t n_irr = 0;           // cells handled by the general kernels when the fast path is on
     int32_t* irr_cells = nullptr;
+    // Flattened stencils of the face-list cells (built when every such cell has <= 4 faces per direction):
+    // rec[(q*5)*n_irr + t] = number of faces of cell irr_cells[t] in direction q = 2*d + (0 left / 1 right),
+    // rec[(q*5 + 1 + k)*n_irr + t] = the cell across its k-th face (accumulator order).  One coalesced read
+    // replaces the offsets -> face ids -> owner/neighbour chain of the CSR walk.
+    int32_t* irr_rec = nullptr;
     int64_t info[8] = {0};
     // workspace for per-cell gradients + sensor (pass A output)
     float* G = nullptr;

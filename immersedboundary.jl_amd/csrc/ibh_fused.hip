@@ -191,6 +191,103 @@ __device__ __forceinline__ void passB_euler_cell(const PartView& p, const float*
 }
 
 // ------------------------------------------------------------------------------------------
+// face-list bodies over flattened stencil records (same arithmetic and summation order as the CSR
+// walk above, two dependent memory trips instead of four)
+// ------------------------------------------------------------------------------------------
+struct FlatRec {
+    const int32_t* rec;
+    int32_t n;
+};
+
+template <int ND, int NV>
+__device__ __forceinline__ void passA_flat(const PartView& p, const FlatRec& R, int32_t t, int32_t c,
+                                           const float* __restrict__ u, int64_t ldu, float* __restrict__ G) {
+    const int64_t nc = p.nc;
+    float D = 1e-7f;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const float* h = p.spacing + d * nc;
+        const float hc = h[c];
+        float s[2][NV], sd[2] = {0.f, 0.f}, sa[2] = {0.f, 0.f};
+        float uc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            uc[v] = u[c + v * ldu];
+            s[0][v] = s[1][v] = 0.f;
+        }
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int64_t q = 2 * d + side;
+            const int cnt = R.rec[(q * 5) * R.n + t];
+            const float w = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < cnt) {
+                    const int32_t o = R.rec[(q * 5 + 1 + k) * R.n + t];
+                    const float ho = h[o];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const float uo = u[o + v * ldu];
+                        // side 1 (right face): owner = this cell, neighbour = o; side 0: owner = o
+                        const float fa = side ? face_avg(uc[v], uo, hc, ho) : face_avg(uo, uc[v], ho, hc);
+                        const float tt = fa * w;
+                        s[side][v] = (k == 0) ? tt : s[side][v] + tt;
+                        if (v == 0) {
+                            const float df = side ? (uo - uc[v]) : (uc[v] - uo);
+                            const float td = df * w, ta = fabsf(df) * w;
+                            sd[side] = (k == 0) ? td : sd[side] + td;
+                            sa[side] = (k == 0) ? ta : sa[side] + ta;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) G[(int64_t)(d * NV + v) * nc + c] = (s[1][v] - s[0][v]) / hc;
+        const float gg = (sd[1] - sd[0]) / hc;
+        const float ugg = (sa[1] + sa[0]) / hc;
+        D = fmaxf(D, (1e-7f + fabsf(gg)) / (1e-7f + ugg));
+    }
+    G[(int64_t)(ND * NV) * nc + c] = D;
+}
+
+template <int ND>
+__device__ __forceinline__ void passB_adv_flat(const PartView& p, const FlatRec& R, int32_t t, int32_t c,
+                                               const float* __restrict__ u, const float* __restrict__ C, int64_t ldc,
+                                               const float* __restrict__ G, float* __restrict__ ud) {
+    const int64_t nc = p.nc;
+    const float* Ds = G + (int64_t)ND * nc;
+    const float uc = u[c], Dc = Ds[c];
+    float r = 0.0f;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const float* h = p.spacing + d * nc;
+        const float* g = G + (int64_t)d * nc;
+        const float* Cd = C + (int64_t)d * ldc;
+        const float hc = h[c], gc = g[c], Cc = Cd[c];
+        float fs[2] = {0.f, 0.f};
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int64_t q = 2 * d + side;
+            const int cnt = R.rec[(q * 5) * R.n + t];
+            const float w = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < cnt) {
+                    const int32_t o = R.rec[(q * 5 + 1 + k) * R.n + t];
+                    const float fl = side ? adv_flux(uc, u[o], gc, g[o], Dc, Ds[o], Cc, Cd[o], hc, h[o])
+                                          : adv_flux(u[o], uc, g[o], gc, Ds[o], Dc, Cd[o], Cc, h[o], hc);
+                    const float tt = fl * w;
+                    fs[side] = (k == 0) ? tt : fs[side] + tt;
+                }
+            }
+        }
+        r = r - (fs[1] - fs[0]) / hc;
+    }
+    ud[c] = r;
+}
+
+// ------------------------------------------------------------------------------------------
 // block fast path, 2-D, 8x8 blocks.  LDS per wave and per field: tile[64] + halo[4][8][2].
 // halo slot (s, t, k): side s, boundary cell t along the side, k-th face (k = 1 only on FINE sides)
 // ------------------------------------------------------------------------------------------
@@ -404,13 +501,16 @@ template <int ND, int NV, bool EXACT>
 __global__ __launch_bounds__(64 * WPB) void k_passA(PartView p, const float* __restrict__ u, int64_t ldu,
                                                float* __restrict__ G, const BlockDesc2* __restrict__ blocks,
                                                const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg_fast,
-                                               const int32_t* __restrict__ cells, int32_t ncells) {
-    // `blocks`/`htab`/`nblk` describe the sub-range of the block table this launch covers
+                                               const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
+    // `blocks`/`htab`/`nblk` describe the sub-range of the block table this launch covers.
+    // grid = [face-list workgroups | block workgroups]: the latency-bound face-list cells go first
     __shared__ float lds[WPB * NV * 128];
-    if ((int32_t)blockIdx.x < nwg_fast) {
+    const int32_t gI = (ncells + 64 * WPB - 1) / (64 * WPB);
+    if ((int32_t)blockIdx.x >= gI) {
+        const int32_t wg = blockIdx.x - gI;
         if constexpr (ND == 2) {
             int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg_fast) * WPB + wave);
+            int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(wg, nwg_fast) * WPB + wave);
             if (blk < nblk) {
                 if constexpr (EXACT)
                     passA_block2<NV>(blocks, htab, blk, p.spacing, p.nc, u, ldu, G, lds + wave * NV * 128, lane);
@@ -420,10 +520,11 @@ __global__ __launch_bounds__(64 * WPB) void k_passA(PartView p, const float* __r
         }
         return;
     }
-    int64_t t = (int64_t)(blockIdx.x - nwg_fast) * blockDim.x + threadIdx.x;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncells) return;
     int32_t c = cells ? cells[t] : (int32_t)t;
-    passA_cell<ND, NV>(p, u, ldu, G, c);
+    if (flat.rec) passA_flat<ND, NV>(p, flat, (int32_t)t, c, u, ldu, G);
+    else passA_cell<ND, NV>(p, u, ldu, G, c);
 }
 
 template <int ND, bool EXACT>
@@ -431,13 +532,15 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
                                                    int64_t ldc, const float* __restrict__ G, float* __restrict__ ud,
                                                    const BlockDesc2* __restrict__ blocks,
                                                    const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg_fast,
-                                                   const int32_t* __restrict__ cells, int32_t ncells) {
+                                                   const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
     constexpr int LDSW = EXACT ? 6 * 128 : BLK2_PASSB_LDS;  // floats per wave
     __shared__ float lds[WPB * LDSW];
-    if ((int32_t)blockIdx.x < nwg_fast) {
+    const int32_t gI = (ncells + 64 * WPB - 1) / (64 * WPB);
+    if ((int32_t)blockIdx.x >= gI) {
+        const int32_t wg = blockIdx.x - gI;
         if constexpr (ND == 2) {
             int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg_fast) * WPB + wave);
+            int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(wg, nwg_fast) * WPB + wave);
             if (blk < nblk) {
                 if constexpr (EXACT)
                     passB_adv_block2(blocks, htab, blk, p.nc, u, C, ldc, G, ud, lds + wave * LDSW, lane);
@@ -448,29 +551,54 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
         }
         return;
     }
-    int64_t t = (int64_t)(blockIdx.x - nwg_fast) * blockDim.x + threadIdx.x;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncells) return;
     int32_t c = cells ? cells[t] : (int32_t)t;
-    passB_adv_cell<ND>(p, u, C, ldc, G, ud, c);
+    if (flat.rec) passB_adv_flat<ND>(p, flat, (int32_t)t, c, u, C, ldc, G, ud);
+    else passB_adv_cell<ND>(p, u, C, ldc, G, ud, c);
 }
 
 // 3-D block kernels: one 512-thread workgroup per 8x8x8 block (the face-list cells get their own launch)
-__global__ __launch_bounds__(512) void k_passA3_blk(uint32_t nc, const float* __restrict__ u, float* __restrict__ G,
+// grid = [face-list workgroups over `cells` | nblk block workgroups]: the face-list cells (sides facing finer
+// blocks, partial skirt blocks) are few but latency-bound (a ~20 us chain of dependent loads); dispatched FIRST
+// in the same launch they run underneath the block work instead of forming a tail.
+__global__ __launch_bounds__(512) void k_passA3_blk(PartView p, const float* __restrict__ u, float* __restrict__ G,
                                                     const BlockDesc3* __restrict__ blocks,
-                                                    const int32_t* __restrict__ htab, int32_t nblk) {
+                                                    const int32_t* __restrict__ htab, int32_t nblk,
+                                                    const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
     __shared__ float lds[896];
-    const int32_t blk = xcd_remap(blockIdx.x, nblk);
-    blk3::passA(blocks, htab, blk, nc, u, G, lds, threadIdx.x);
+    const int32_t gI = (ncells + 511) / 512;
+    if ((int32_t)blockIdx.x >= gI) {
+        const int32_t blk = xcd_remap(blockIdx.x - gI, nblk);
+        blk3::passA(blocks, htab, blk, (uint32_t)p.nc, u, G, lds, threadIdx.x);
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ncells) {
+        if (flat.rec) passA_flat<3, 1>(p, flat, (int32_t)t, cells[t], u, (int64_t)p.nc, G);
+        else passA_cell<3, 1>(p, u, (int64_t)p.nc, G, cells[t]);
+    }
 }
 
-__global__ __launch_bounds__(512) void k_passB3_adv_blk(uint32_t nc, const float* __restrict__ u,
-                                                        const float* __restrict__ C, uint32_t ldc,
+__global__ __launch_bounds__(512) void k_passB3_adv_blk(PartView p, const float* __restrict__ u,
+                                                        const float* __restrict__ C, int64_t ldc,
                                                         const float* __restrict__ G, float* __restrict__ ud,
                                                         const BlockDesc3* __restrict__ blocks,
-                                                        const int32_t* __restrict__ htab, int32_t nblk) {
+                                                        const int32_t* __restrict__ htab, int32_t nblk,
+                                                        const int32_t* __restrict__ cells, int32_t ncells,
+                                                        FlatRec flat) {
     __shared__ float lds[BLK3_PASSB_LDS];
-    const int32_t blk = xcd_remap(blockIdx.x, nblk);
-    blk3::passB_adv(blocks, htab, blk, nc, u, C, ldc, G, ud, lds, threadIdx.x);
+    const int32_t gI = (ncells + 511) / 512;
+    if ((int32_t)blockIdx.x >= gI) {
+        const int32_t blk = xcd_remap(blockIdx.x - gI, nblk);
+        blk3::passB_adv(blocks, htab, blk, (uint32_t)p.nc, u, C, (uint32_t)ldc, G, ud, lds, threadIdx.x);
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ncells) {
+        if (flat.rec) passB_adv_flat<3>(p, flat, (int32_t)t, cells[t], u, C, ldc, G, ud);
+        else passB_adv_cell<3>(p, u, C, ldc, G, ud, cells[t]);
+    }
 }
 
 // Euler pass B: the block body and the face-list body are separate kernels (the Float64 flux combine of
@@ -507,6 +635,16 @@ PartView view(const ibh_part* p) {
     return v;
 }
 
+// flattened records apply only when a launch walks exactly the partition's face-list cell list
+FlatRec flat_of(const ibh_part* p, const int32_t* cells) {
+    FlatRec r{nullptr, 0};
+    if (cells && cells == p->irr_cells && p->irr_rec) {
+        r.rec = p->irr_rec;
+        r.n = p->n_irr;
+    }
+    return r;
+}
+
 int ensure_G(ibh_part* p, size_t floats) {
     size_t bytes = floats * sizeof(float);
     if (p->G_bytes >= bytes) return 0;
@@ -536,20 +674,13 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         const int32_t nI = ph1 ? 0 : p->n_irr;
         PartView v = view(p);
         const bool doA = !(flags & IBH_PASS_B_ONLY), doB = !(flags & IBH_PASS_A_ONLY);
-        if (doA && a1 > a0)
-            hipLaunchKernelGGL(k_passA3_blk, dim3(a1 - a0), dim3(512), 0, ibh_stream, (uint32_t)p->nc, u, p->G,
-                               p->blocks3 + a0, p->htab3 + (size_t)a0 * 384, a1 - a0);
-        if (doA && nI)
-            hipLaunchKernelGGL((k_passA<3, 1, true>), dim3((nI + 64 * WPB - 1) / (64 * WPB)), dim3(64 * WPB), 0, ibh_stream,
-                               v, u, (int64_t)p->nc, p->G, (const BlockDesc2*)nullptr, (const int32_t*)nullptr, 0, 0,
-                               p->irr_cells, nI);
-        if (doB && b1 > b0)
-            hipLaunchKernelGGL(k_passB3_adv_blk, dim3(b1 - b0), dim3(512), 0, ibh_stream, (uint32_t)p->nc, u, C,
-                               (uint32_t)ldc, p->G, ud, p->blocks3 + b0, p->htab3 + (size_t)b0 * 384, b1 - b0);
-        if (doB && nI)
-            hipLaunchKernelGGL((k_passB_adv<3, true>), dim3((nI + 64 * WPB - 1) / (64 * WPB)), dim3(64 * WPB), 0,
-                               ibh_stream, v, u, C, ldc, p->G, ud, (const BlockDesc2*)nullptr, (const int32_t*)nullptr, 0,
-                               0, p->irr_cells, nI);
+        const int32_t gI = (nI + 511) / 512;
+        if (doA && (a1 > a0 || gI))
+            hipLaunchKernelGGL(k_passA3_blk, dim3(a1 - a0 + gI), dim3(512), 0, ibh_stream, v, u, p->G, p->blocks3 + a0,
+                               p->htab3 + (size_t)a0 * 384, a1 - a0, p->irr_cells, nI, flat_of(p, p->irr_cells));
+        if (doB && (b1 > b0 || gI))
+            hipLaunchKernelGGL(k_passB3_adv_blk, dim3(b1 - b0 + gI), dim3(512), 0, ibh_stream, v, u, C, ldc, p->G, ud,
+                               p->blocks3 + b0, p->htab3 + (size_t)b0 * 384, b1 - b0, p->irr_cells, nI, flat_of(p, p->irr_cells));
         IBH_LAUNCH_CHECK();
         return 0;
     }
@@ -585,24 +716,24 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     if (p->nd == 2 && exact) {
         if (doA)
             hipLaunchKernelGGL((k_passA<2, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA, htA,
-                               a1 - a0, nwgA_fast, cellsA, nA);
+                               a1 - a0, nwgA_fast, cellsA, nA, flat_of(p, cellsA));
         if (doB)
             hipLaunchKernelGGL((k_passB_adv<2, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB, htB,
-                               b1 - b0, nwgB_fast, cellsB, nB);
+                               b1 - b0, nwgB_fast, cellsB, nB, flat_of(p, cellsB));
     } else if (p->nd == 2) {
         if (doA)
             hipLaunchKernelGGL((k_passA<2, 1, false>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA, htA,
-                               a1 - a0, nwgA_fast, cellsA, nA);
+                               a1 - a0, nwgA_fast, cellsA, nA, flat_of(p, cellsA));
         if (doB)
             hipLaunchKernelGGL((k_passB_adv<2, false>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB, htB,
-                               b1 - b0, nwgB_fast, cellsB, nB);
+                               b1 - b0, nwgB_fast, cellsB, nB, flat_of(p, cellsB));
     } else {
         if (doA)
             hipLaunchKernelGGL((k_passA<3, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,
-                               p->htab, p->nblk, 0, cellsA, nA);
+                               p->htab, p->nblk, 0, cellsA, nA, flat_of(p, cellsA));
         if (doB)
             hipLaunchKernelGGL((k_passB_adv<3, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
-                               p->htab, p->nblk, 0, cellsB, nB);
+                               p->htab, p->nblk, 0, cellsB, nB, flat_of(p, cellsB));
     }
     IBH_LAUNCH_CHECK();
     return 0;
@@ -633,10 +764,10 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     if (p->nd == 2) {
         if (doA && fast)
             hipLaunchKernelGGL((k_passA<2, 4, false>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
-                               p->nblk, nwg_fast, cellsA, nA);
+                               p->nblk, nwg_fast, cellsA, nA, flat_of(p, cellsA));
         else if (doA)
             hipLaunchKernelGGL((k_passA<2, 4, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
-                               p->nblk, 0, cellsA, nA);
+                               p->nblk, 0, cellsA, nA, flat_of(p, cellsA));
         if (doB && nwg_fast)
             hipLaunchKernelGGL(k_passB_euler_blk, dim3(nwg_fast), blk, 0, ibh_stream, (uint32_t)p->nc, P, (uint32_t)ldp,
                                p->G, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks2, p->htab, p->nblk, nwg_fast);
@@ -646,7 +777,7 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     } else {
         if (doA)
             hipLaunchKernelGGL((k_passA<3, 5, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
-                               p->nblk, 0, cellsA, nA);
+                               p->nblk, 0, cellsA, nA, flat_of(p, cellsA));
         if (doB && gB.x)
             hipLaunchKernelGGL((k_passB_euler<3>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
                                fluid->gamma, cellsB, nB);
