@@ -26,7 +26,7 @@ inline int coord(int pos, int d) { return (pos / STR[d]) % 8; }
 
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
-                         std::vector<int32_t>& htab) {
+                         std::vector<int32_t>& htab, std::vector<int32_t>& ftab) {
     const int32_t nc = v.nc;
     const float* hh[3] = {v.spacing, v.spacing + nc, v.spacing + 2 * (size_t)nc};
     auto gid = [&](int32_t c) { return (int64_t)v.domain[c] - v.index_base; };
@@ -56,6 +56,9 @@ void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks,
     std::vector<char> cell_irr(nc, 0);
     for (int32_t c = 0; c < nc; ++c) cell_irr[c] = !in_full[c];
     int64_t counts[5] = {0, 0, 0, 0, 0};
+    std::vector<int32_t> fine0;        // sub-face-0 cells of FINE sides, 64 per entry of fine0_key
+    std::vector<int64_t> fine0_key;    // (block base << 3) | side
+    std::unordered_map<int64_t, std::vector<int32_t>> fine_nb;  // same key -> bases of the 4 fine neighbour blocks
 
     for (int32_t base : bases) {
         bool good = true;
@@ -79,6 +82,8 @@ void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks,
         }
         BlockDesc3 b;
         b.base = base;
+        b.fine = -1;
+        int32_t fcell[6][64][4];  // fine neighbour cells of FINE sides, sub-face k = k1 + 2*k2
         for (int d = 0; d < 3; ++d) {
             b.h[d] = hh[d][base];
             b.rh[d] = 1.0f / b.h[d];
@@ -95,7 +100,28 @@ void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks,
             for (int t = 0; t < 64 && ok; ++t) {
                 const int t1 = t % 8, t2 = t / 8;
                 const int32_t c = base + pos3(d, low ? 0 : 7, t1, t2);
-                if (off[c + 1] - off[c] != 1) { ok = false; break; }
+                const int nfc = off[c + 1] - off[c];
+                if (nfc == 4) {  // candidate FINE side: 4 faces to the 2x2 fine cells behind this boundary cell
+                    int a, bb2;
+                    tang(d, a, bb2);
+                    bool seen[4] = {false, false, false, false};
+                    for (int kf = 0; kf < 4 && ok; ++kf) {
+                        const int32_t f4 = idx[off[c] + kf];
+                        const int32_t me4 = low ? v.neighbors[d][f4] : v.owners[d][f4];
+                        const int32_t o4 = low ? v.owners[d][f4] : v.neighbors[d][f4];
+                        if (me4 != c || o4 == c || !in_full[o4] || hh[d][o4] != hc * 0.5f) { ok = false; break; }
+                        const int pos4 = (int)(gid(o4) % NPB);
+                        if (coord(pos4, d) != (low ? 7 : 0)) { ok = false; break; }
+                        const int k1 = coord(pos4, a) - 2 * (t1 & 3), k2 = coord(pos4, bb2) - 2 * (t2 & 3);
+                        if (k1 < 0 || k1 > 1 || k2 < 0 || k2 > 1 || seen[k1 + 2 * k2]) { ok = false; break; }
+                        seen[k1 + 2 * k2] = true;
+                        fcell[s][t][k1 + 2 * k2] = o4;
+                    }
+                    if (!ok) break;
+                    if (t == 0) type = SIDE_FINE; else if (type != SIDE_FINE) { ok = false; break; }
+                    continue;
+                }
+                if (nfc != 1) { ok = false; break; }
                 const int32_t f = idx[off[c]];
                 const int32_t me = low ? v.neighbors[d][f] : v.owners[d][f];
                 const int32_t o = low ? v.owners[d][f] : v.neighbors[d][f];
@@ -130,8 +156,23 @@ void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks,
             b.type[s] = type;
             b.nb[s] = nb;
             b.sub[s] = sub < 0 ? 0 : sub;
-            b.q[s] = type == SIDE_COARSE ? (1.0f / 3.0f) : 0.5f;
-            b.rt[s] = type == SIDE_COARSE ? 2.0f : 1.0f;
+            b.q[s] = type == SIDE_COARSE ? (1.0f / 3.0f) : type == SIDE_FINE ? (2.0f / 3.0f) : 0.5f;
+            b.rt[s] = type == SIDE_COARSE ? 2.0f : type == SIDE_FINE ? 0.5f : 1.0f;
+            if (type == SIDE_FINE) {
+                if (b.fine < 0) {
+                    b.fine = (int32_t)(ftab.size() / (6 * 64 * 3));
+                    ftab.resize(ftab.size() + 6 * 64 * 3, b.base);
+                }
+                b.nb[s] = -2;  // marker: sub-face 0 cells are taken from fcell when the halo table is written
+                for (int t = 0; t < 64; ++t)
+                    for (int k = 1; k < 4; ++k)
+                        ftab[((size_t)b.fine * 6 + s) * 64 * 3 + t * 3 + (k - 1)] = fcell[s][t][k];
+                for (int t = 0; t < 64; ++t) fine0.push_back(fcell[s][t][0]);
+                fine0_key.push_back(((int64_t)base << 3) | s);
+                std::vector<int32_t>& nbs = fine_nb[((int64_t)base << 3) | s];
+                for (int t = 0; t < 64; t += 4)  // one boundary cell of every 4x4 quadrant (t1 = 0 or 4, t2 = 0 or 4)
+                    if ((t % 8) % 4 == 0 && (t / 8) % 4 == 0) nbs.push_back(blockbase[gid(fcell[s][t][0]) / NPB]);
+            }
             counts[type]++;
             if (type == SIDE_GENERAL)
                 for (int t = 0; t < 64; ++t) cell_irr[base + pos3(d, low ? 0 : 7, t % 8, t / 8)] = 1;
@@ -167,6 +208,13 @@ void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks,
                 const int ty = blocks[b].type[s];
                 if (ty == SIDE_MIRROR) continue;
                 if (ty == SIDE_GENERAL) { ok = false; break; }
+                if (ty == SIDE_FINE) {
+                    for (int32_t fb : fine_nb[((int64_t)blocks[b].base << 3) | s]) {
+                        auto itf = base2a1.find(fb);
+                        ok = ok && itf != base2a1.end() && itf->second;
+                    }
+                    continue;
+                }
                 auto it = base2a1.find(blocks[b].nb[s]);
                 ok = it != base2a1.end() && it->second;
             }
@@ -181,6 +229,8 @@ void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks,
         for (size_t b = 0; b < blocks.size(); ++b) if (!a1[b]) ordered.push_back(blocks[b]);
         blocks.swap(ordered);
     }
+    std::unordered_map<int64_t, size_t> fine0_at;
+    for (size_t e = 0; e < fine0_key.size(); ++e) fine0_at[fine0_key[e]] = e;
     htab.resize(blocks.size() * 384);
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const BlockDesc3& b = blocks[bi];
@@ -193,6 +243,8 @@ void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks,
                 if (b.type[s] == SIDE_SAME) cell = b.nb[s] + pos3(d, low ? 7 : 0, t1, t2);
                 else if (b.type[s] == SIDE_COARSE)
                     cell = b.nb[s] + pos3(d, low ? 7 : 0, 4 * (b.sub[s] & 1) + t1 / 2, 4 * (b.sub[s] >> 1) + t2 / 2);
+                else if (b.type[s] == SIDE_FINE)
+                    cell = fine0[fine0_at[((int64_t)b.base << 3) | s] * 64 + t];
                 else cell = b.base + pos3(d, low ? 0 : 7, t1, t2);
                 htab[bi * 384 + s * 64 + t] = cell;
             }

@@ -162,12 +162,13 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         if ((rc = ibh_upload(&p->irr_cells, irr.data(), irr.size()))) return rc;
     } else if (domain && block_size == 8 && nd == 3) {
         std::vector<BlockDesc3> blocks;
-        std::vector<int32_t> irr, htab;
+        std::vector<int32_t> irr, htab, ftab;
         int32_t nph[2] = {0, 0};
         std::vector<int32_t> none;
         const bool have_img = n_image > 0 && image_in_domain;
         ibh_analyze_blocks3(v, blocks, irr, p->info, have_img ? image_in_domain : none.data(), have_img ? n_image : 0,
-                            nph, htab);
+                            nph, htab, ftab);
+        if ((rc = ibh_upload(&p->ftab3, ftab.data(), ftab.size()))) return rc;
         p->nA1 = nph[0];
         p->nB1 = nph[1];
         p->bs = block_size;
@@ -226,6 +227,7 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->htab);
     hipFree(p->blocks3);
     hipFree(p->htab3);
+    hipFree(p->ftab3);
     hipFree(p->irr_cells);
     hipFree(p->irr_rec);
     hipFree(p->G);

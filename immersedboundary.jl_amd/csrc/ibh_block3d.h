@@ -50,8 +50,8 @@ __device__ __forceinline__ Lane3 lane_info(const BlockDesc3& b, int tid) {
 // pass A (scalar field): gradients along x, y, z + JST sensor.  LDS: 896 floats.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void passA(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
-                                      int32_t blk, uint32_t nc, const float* __restrict__ u, float* __restrict__ G,
-                                      float* lds, int tid) {
+                                      const int32_t* __restrict__ ftab, int32_t blk, uint32_t nc,
+                                      const float* __restrict__ u, float* __restrict__ G, float* lds, int tid) {
     const BlockDesc3 bb = blocks[blk];
     const uint32_t c = (uint32_t)bb.base + tid;
     const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
@@ -62,16 +62,32 @@ __device__ __forceinline__ void passA(const BlockDesc3* __restrict__ blocks, con
     const Lane3 L = lane_info(bb, tid);
     __syncthreads();
     float g[3], D = 1e-7f;
+    const int tt[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float rh = bb.rh[d];
-        const float l = lds[L.nidx[2 * d]], r = lds[L.nidx[2 * d + 1]];
-        const float fr = uc + L.q[2 * d + 1] * (r - uc);  // at_faces: (1-q)*u_self + q*u_nb
-        const float fl = uc + L.q[2 * d] * (l - uc);
+        float vm[2], am[2];  // mean neighbour value and mean |difference| towards the low / high side
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int s = 2 * d + side;
+            const float v0 = lds[L.nidx[s]];
+            vm[side] = v0;
+            am[side] = fabsf(v0 - uc);
+            if (bb.type[s] == SIDE_FINE) {  // wave-uniform: 4 fine cells behind every boundary cell of this side
+                if (L.edge[s]) {
+                    const int32_t* ft = ftab + (((size_t)bb.fine * 6 + s) * 64 + tt[d]) * 3;
+                    const float v1 = ldg(u, (uint32_t)ft[0]), v2 = ldg(u, (uint32_t)ft[1]), v3 = ldg(u, (uint32_t)ft[2]);
+                    vm[side] = 0.25f * (v0 + v1 + v2 + v3);
+                    am[side] = 0.25f * (fabsf(v0 - uc) + fabsf(v1 - uc) + fabsf(v2 - uc) + fabsf(v3 - uc));
+                }
+            }
+        }
+        const float fr = uc + L.q[2 * d + 1] * (vm[1] - uc);  // at_faces: (1-q)*u_self + q*u_nb
+        const float fl = uc + L.q[2 * d] * (vm[0] - uc);
         g[d] = (fr - fl) * rh;
-        const float dr = r - uc, dl = uc - l;
+        const float dr = vm[1] - uc, dl = uc - vm[0];
         const float gg = (dr - dl) * rh;
-        const float ugg = (fabsf(dr) + fabsf(dl)) * rh;
+        const float ugg = (am[1] + am[0]) * rh;
         D = fmaxf(D, (1e-7f + fabsf(gg)) * __builtin_amdgcn_rcpf(1e-7f + ugg));
     }
     if (!L.general) {
@@ -88,7 +104,8 @@ __device__ __forceinline__ void passA(const BlockDesc3* __restrict__ blocks, con
 #define BLK3_PASSB_LDS (896 * 2 + 1536 + 384 + 1536 + 384 + 192 + 1536)
 
 __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
-                                          int32_t blk, uint32_t nc, const float* __restrict__ u,
+                                          const int32_t* __restrict__ ftab, int32_t blk, uint32_t nc,
+                                          const float* __restrict__ u,
                                           const float* __restrict__ C, uint32_t ldc, const float* __restrict__ G,
                                           float* __restrict__ ud, float* lds, int tid) {
     const BlockDesc3 bb = blocks[blk];
@@ -138,6 +155,7 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
         invs[s] = 2.0f * bb.rh[s >> 1] * bb.q[s];
     }
     // ---- main pass: the +x, +y, +z face of every cell
+    const int tth[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
     float F[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -148,6 +166,19 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
         const float Cb = e ? hC[ni - 512] : tC[d * 512 + ni];
         const float hd = 0.5f * bb.h[d];
         F[d] = adv_flux(uc, fU[ni], gc[d], gb, Dc, fD[ni], cc[d], Cb, hd, e ? dBs[s] : hd, e ? invs[s] : bb.rh[d]);
+        if (bb.type[s] == SIDE_FINE) {  // wave-uniform: 3 more sub-faces, straight from global memory
+            if (e) {
+                const int32_t* ft = ftab + (((size_t)bb.fine * 6 + s) * 64 + tth[d]) * 3;
+                float acc = F[d];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t cl = (uint32_t)ft[k];
+                    acc += adv_flux(uc, ldg(u, cl), gc[d], ldg(G + (size_t)d * nc, cl), Dc, ldg(Gs, cl), cc[d],
+                                    ldg(C + (size_t)d * ldc, cl), hd, dBs[s], invs[s]);
+                }
+                F[d] = 0.25f * acc;
+            }
+        }
     }
     // ---- extra pass: the 3 x 64 low-side block faces (halo cell = owner), threads 0..191
     {
@@ -159,8 +190,19 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
         const float hd = 0.5f * (dn == 0 ? bb.h[0] : dn == 1 ? bb.h[1] : bb.h[2]);
         const float dB = dn == 0 ? dBs[0] : dn == 1 ? dBs[2] : dBs[4];
         const float inv = dn == 0 ? invs[0] : dn == 1 ? invs[2] : invs[4];
-        const float X = adv_flux(fU[512 + slot], fU[pos], hG[slot], tG[dn * 512 + pos], fD[512 + slot], fD[pos], hC[slot],
-                                 tC[dn * 512 + pos], dB, hd, inv);
+        float X = adv_flux(fU[512 + slot], fU[pos], hG[slot], tG[dn * 512 + pos], fD[512 + slot], fD[pos], hC[slot],
+                           tC[dn * 512 + pos], dB, hd, inv);
+        const int tyl = dn == 0 ? bb.type[0] : dn == 1 ? bb.type[2] : bb.type[4];  // uniform per 64-thread role group
+        if (tyl == SIDE_FINE && tid < 192) {
+            const int32_t* ft = ftab + (((size_t)bb.fine * 6 + 2 * dn) * 64 + t) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t cl = (uint32_t)ft[k];
+                X += adv_flux(ldg(u, cl), fU[pos], ldg(G + (size_t)dn * nc, cl), tG[dn * 512 + pos], ldg(Gs, cl), fD[pos],
+                              ldg(C + (size_t)dn * ldc, cl), tC[dn * 512 + pos], dB, hd, inv);
+            }
+            X *= 0.25f;
+        }
         if (tid < 192) ex[tid] = X;
     }
 #pragma unroll

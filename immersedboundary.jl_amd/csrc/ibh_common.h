@@ -37,8 +37,11 @@ struct BlockDesc2 {  // 2-D
 // side indexed t = t1 + 8*t2 over the two tangential dims in increasing order.  The 3-D fast path takes
 // SAME / MIRROR / COARSE (2:1) sides; sides facing finer blocks are GENERAL (face-list body), so every
 // boundary cell has exactly one face and the halo table has one slot per (side, t): htab3[blk][s*64 + t].
+// FINE sides (4 faces per boundary cell, sub-face k = k1 + 2*k2): sub-face 0 sits in the halo table, sub-faces
+// 1..3 in ftab3[fine][s][t][k-1]; only the boundary threads of such a side touch them (wave-uniform branch).
 struct BlockDesc3 {
     int32_t base;
+    int32_t fine;     // index into the fine-side table (ftab3) or -1: blocks with a side facing finer blocks
     int32_t type[6];
     int32_t nb[6];
     int32_t sub[6];
@@ -71,6 +74,7 @@ struct ibh_part {
     int32_t* htab = nullptr;     // [nblk][64] halo cell table, same order as blocks2
     BlockDesc3* blocks3 = nullptr;  // 3-D block table (nd == 3)
     int32_t* htab3 = nullptr;    // [nblk][384]
+    int32_t* ftab3 = nullptr;    // [nfine][6][64][3] sub-faces 1..3 of FINE sides
     int32_t n_irr = 0;           // cells handled by the general kernels when the fast path is on
     int32_t* irr_cells = nullptr;
     // Flattened stencils of the face-list cells (built when every such cell has <= 4 faces per direction):
@@ -134,7 +138,7 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
 
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
-                         std::vector<int32_t>& htab);
+                         std::vector<int32_t>& htab, std::vector<int32_t>& ftab);
 
 static inline int ibh_grid(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;

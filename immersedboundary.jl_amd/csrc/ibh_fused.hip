@@ -564,13 +564,14 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
 // in the same launch they run underneath the block work instead of forming a tail.
 __global__ __launch_bounds__(512) void k_passA3_blk(PartView p, const float* __restrict__ u, float* __restrict__ G,
                                                     const BlockDesc3* __restrict__ blocks,
-                                                    const int32_t* __restrict__ htab, int32_t nblk,
+                                                    const int32_t* __restrict__ htab,
+                                                    const int32_t* __restrict__ ftab, int32_t nblk,
                                                     const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
     __shared__ float lds[896];
     const int32_t gI = (ncells + 511) / 512;
     if ((int32_t)blockIdx.x >= gI) {
         const int32_t blk = xcd_remap(blockIdx.x - gI, nblk);
-        blk3::passA(blocks, htab, blk, (uint32_t)p.nc, u, G, lds, threadIdx.x);
+        blk3::passA(blocks, htab, ftab, blk, (uint32_t)p.nc, u, G, lds, threadIdx.x);
         return;
     }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -584,14 +585,15 @@ __global__ __launch_bounds__(512) void k_passB3_adv_blk(PartView p, const float*
                                                         const float* __restrict__ C, int64_t ldc,
                                                         const float* __restrict__ G, float* __restrict__ ud,
                                                         const BlockDesc3* __restrict__ blocks,
-                                                        const int32_t* __restrict__ htab, int32_t nblk,
+                                                        const int32_t* __restrict__ htab,
+                                                        const int32_t* __restrict__ ftab, int32_t nblk,
                                                         const int32_t* __restrict__ cells, int32_t ncells,
                                                         FlatRec flat) {
     __shared__ float lds[BLK3_PASSB_LDS];
     const int32_t gI = (ncells + 511) / 512;
     if ((int32_t)blockIdx.x >= gI) {
         const int32_t blk = xcd_remap(blockIdx.x - gI, nblk);
-        blk3::passB_adv(blocks, htab, blk, (uint32_t)p.nc, u, C, (uint32_t)ldc, G, ud, lds, threadIdx.x);
+        blk3::passB_adv(blocks, htab, ftab, blk, (uint32_t)p.nc, u, C, (uint32_t)ldc, G, ud, lds, threadIdx.x);
         return;
     }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -677,10 +679,10 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         const int32_t gI = (nI + 511) / 512;
         if (doA && (a1 > a0 || gI))
             hipLaunchKernelGGL(k_passA3_blk, dim3(a1 - a0 + gI), dim3(512), 0, ibh_stream, v, u, p->G, p->blocks3 + a0,
-                               p->htab3 + (size_t)a0 * 384, a1 - a0, p->irr_cells, nI, flat_of(p, p->irr_cells));
+                               p->htab3 + (size_t)a0 * 384, p->ftab3, a1 - a0, p->irr_cells, nI, flat_of(p, p->irr_cells));
         if (doB && (b1 > b0 || gI))
             hipLaunchKernelGGL(k_passB3_adv_blk, dim3(b1 - b0 + gI), dim3(512), 0, ibh_stream, v, u, C, ldc, p->G, ud,
-                               p->blocks3 + b0, p->htab3 + (size_t)b0 * 384, b1 - b0, p->irr_cells, nI, flat_of(p, p->irr_cells));
+                               p->blocks3 + b0, p->htab3 + (size_t)b0 * 384, p->ftab3, b1 - b0, p->irr_cells, nI, flat_of(p, p->irr_cells));
         IBH_LAUNCH_CHECK();
         return 0;
     }

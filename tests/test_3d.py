@@ -151,6 +151,9 @@ def test_3d_block_path(octree8_mesh, nparts):
         dpart = ibamd.to_backend(part, ibamd.hip)
         info = dpart.info
         assert info["full_blocks"] > 0 and info["sides_coarse"] > 0 and info["sides_mirror"] > 0
+        assert info["sides_fine"] > 0
+        if nparts == 1:
+            assert info["sides_general"] == 0 and info["irregular_cells"] == 0
         x = part.centers
         nc = x.shape[0]
         u = (np.sin(2 * x[:, 0]) * np.cos(3 * x[:, 1]) + 0.3 * x[:, 2] + 0.1 * rng.uniform(-1, 1, nc)).astype(f32)
