@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general", action="store_true", help="force the face-list kernels (no block fast path)")
     ap.add_argument("--exact", action="store_true", help="block path with the literal IEEE arithmetic")
+    ap.add_argument("--no-fuse", action="store_true", help="keep the two-kernel sweep where one kernel could do it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -195,6 +196,7 @@ def main():
         P = ibamd.hip(P_h)
         Rres = torch.zeros((4, dpart.nc), dtype=torch.float32, device=P.device).T
     flags = (ibamd.IBH_FORCE_GENERAL if args.general else 0) | (ibamd.IBH_EXACT if args.exact else 0)
+    flags |= ibamd.IBH_NO_FUSE if args.no_fuse else 0
 
     hx = None
     comm_stream = None
@@ -315,30 +317,37 @@ def main():
             torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / (5 * reps) * 1e-3
     reps = 50
-    tB = time_pass(ibamd.IBH_PASS_B_ONLY, reps)
-    tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
     cells_launch = dpart.nc
     is3d = msh.ndims == 3
     if is3d and (euler or world > 1):
         raise SystemExit("3-D workloads: scalar sweep on one GPU only (secondary measurement)")
+    # single-kernel sweep: every block eligible, no face-list cells (2-D scalar sweep on one partition)
+    fused = (not euler and not is3d and flags == 0 and dpart.info["irregular_cells"] == 0
+             and dpart.info["fusable_blocks"] == dpart.info["full_blocks"] > 0)
+    if fused:
+        tB, tA = time_pass(0, reps), None
+    else:
+        tB = time_pass(ibamd.IBH_PASS_B_ONLY, reps)
+        tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
     # R1 = 4*(1 + nd + 1) B/cell, R2 = 2 * 4 * (nd + 2) B/cell
     b_alg = 32.0 if euler else (20.0 if is3d else B_ALG_2D)
     achieved = b_alg * cells_launch / tB / 1e9
-    # HBM-side traffic of one pass-B launch from the committed PMC passes of this build (separate
+    # HBM-side traffic of one launch of the dominant kernel from the committed PMC passes of this build (separate
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
     # calibrated against the kernel's known tile loads); null if not profiled.
+    kernel = ("k_passB_euler_blk" if euler else "k_passB3_adv_blk" if is3d else
+              "k_sweep_adv" if fused else "k_passB_adv<2,false>")
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "current_pmc.json")) as f:
             pm = json.load(f)
-        if pm.get("workload") == args.workload and not args.general and not args.exact and world == 1 and not euler:
-            traffic = round((2.0 * pm["passB_fetch_kb"] + pm["passB_write_kb"]) * 1024.0)
+        if pm.get("workload") == args.workload and pm.get("kernel") == kernel and world == 1:
+            traffic = round((2.0 * pm["fetch_kb"] + pm["write_kb"]) * 1024.0)
     except (OSError, KeyError, ValueError):
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_passB_euler_blk" if euler else ("k_passB3_adv_blk" if is3d else "k_passB_adv<2,false>"),
-                "kernel_us": round(tB * 1e6, 3), "passA_us": round(tA * 1e6, 3),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
+                "kernel_us": round(tB * 1e6, 3), "passA_us": None if tA is None else round(tA * 1e6, 3),
                 "alg_bytes_per_cell": b_alg, "cells_per_launch": cells_launch,
                 "sweep_frac": round(b_alg * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
 
@@ -353,7 +362,8 @@ def main():
                                f"{world} partition(s), skirt depth 2, "
                                f"{'R2 Euler HLL' if euler else 'R1 advection'}-JST-MUSCL residual, fields resident in HBM",
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
-                   "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else "block-fast-path"),
+                   "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else
+                            "block-fast-path, single kernel" if fused else "block-fast-path, two kernels"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",
                    "halo": None if hx is None else {"backend": args.backend, "exchange": halo_kind,
                                                     "overlap": comm_stream is not None,

@@ -34,6 +34,7 @@ IBH_PASS_B_ONLY = 8
 IBH_EXACT = 16
 IBH_PHASE_INTERIOR = 32
 IBH_PHASE_BOUNDARY = 64
+IBH_NO_FUSE = 128
 
 _initialised = {}
 
@@ -160,10 +161,11 @@ class DevicePartition:
         self.domain = torch.from_numpy(dom).to(dev)
         self.image = torch.from_numpy(np.ascontiguousarray(part.image, dtype=np.int32)).to(dev)
         self.image_in_domain = torch.from_numpy(iid).to(dev)
-        info = (C.c_int64 * 8)()
-        call("ibh_partition_info", h, info, 8)
+        info = (C.c_int64 * 10)()
+        call("ibh_partition_info", h, info, 10)
         self.info = dict(full_blocks=info[0], irregular_cells=info[1], sides_same=info[2], sides_mirror=info[3],
-                         sides_coarse=info[4], sides_fine=info[5], sides_general=info[6], interior_blocks=info[7])
+                         sides_coarse=info[4], sides_fine=info[5], sides_general=info[6], interior_blocks=info[7],
+                         fusable_blocks=info[8])
 
     @property
     def ndims(self):

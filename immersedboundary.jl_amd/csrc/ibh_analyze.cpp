@@ -23,7 +23,7 @@ inline bool on_opp_edge(int s, int pos) {
 
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks, std::vector<int32_t>& irr,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
-                         std::vector<int32_t>& htab) {
+                         std::vector<int32_t>& htab, std::vector<int32_t>& etab, std::vector<char>& fus) {
     const int32_t nc = v.nc;
     const int NPB = 64;
     const float* hx = v.spacing;
@@ -233,6 +233,68 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
                     else cell = b.base + pos_own(s, t);
                     htab[bi * 64 + (s * 8 + t) * 2 + k] = cell;
                 }
+    }
+    // 6. single-kernel sweep (blk2::sweep_adv): the wave of a block also computes gradient + sensor of its 64
+    //    halo cells, from (a) the halo values, (b) the cell one step deeper inside the neighbour block
+    //    (halo id -/+ 1 or 8: interior to a verified block), (c) the lateral neighbours along the side = the
+    //    adjacent halo slots, and (d) at the two ends of every side the cells across the neighbour block's
+    //    perpendicular side: etab[blk][(s*2 + end)*2 + k], taken from that block's own (verified) halo row.
+    //    A block is eligible when none of its sides is GENERAL, every neighbour block is in the table with a
+    //    verified side facing back, the perpendicular sides used at the ends are not GENERAL, and the two fine
+    //    blocks of a FINE side are SAME-level neighbours of each other.
+    etab.assign(blocks.size() * 16, 0);
+    fus.assign(blocks.size(), 0);
+    {
+        std::unordered_map<int32_t, int32_t> base2idx;
+        for (size_t bi = 0; bi < blocks.size(); ++bi) base2idx[blocks[bi].base] = (int32_t)bi;
+        auto find = [&](int32_t base) -> int32_t {
+            auto it = base2idx.find(base);
+            return it == base2idx.end() ? -1 : it->second;
+        };
+        int64_t nfus = 0;
+        for (size_t bi = 0; bi < blocks.size(); ++bi) {
+            const BlockDesc2& b = blocks[bi];
+            bool ok = true;
+            for (int k = 0; k < NPB && ok; ++k) ok = !cell_irr[b.base + k];
+            for (int s = 0; s < 4; ++s) {
+                int32_t* e = &etab[bi * 16 + s * 4];
+                e[0] = e[1] = e[2] = e[3] = b.base + pos_own(s, 0);
+                if (!ok) continue;
+                const int ty = b.type[s];
+                if (ty == SIDE_MIRROR) continue;
+                if (ty == SIDE_GENERAL) { ok = false; continue; }
+                const int td = 1 - s / 2, s_lo = 2 * td, s_hi = s_lo + 1, opp = s ^ 1;
+                const int tp = (s % 2 == 0) ? 7 : 0;  // index of the halo line along the neighbour's perpendicular sides
+                auto edge_ids = [&](int32_t ni, int side, int32_t* out) -> bool {
+                    if (blocks[ni].type[side] == SIDE_GENERAL) return false;
+                    out[0] = htab[(size_t)ni * 64 + (side * 8 + tp) * 2];
+                    out[1] = htab[(size_t)ni * 64 + (side * 8 + tp) * 2 + 1];
+                    return true;
+                };
+                const int32_t n0 = find(b.nb[s][0]);
+                if (n0 < 0 || blocks[n0].type[opp] == SIDE_GENERAL) { ok = false; continue; }
+                if (ty == SIDE_SAME) {
+                    ok = edge_ids(n0, s_lo, e) && edge_ids(n0, s_hi, e + 2);
+                } else if (ty == SIDE_COARSE) {
+                    const int sub = b.sub[s];
+                    if (sub == 0) ok = edge_ids(n0, s_lo, e);
+                    else e[0] = e[1] = blocks[n0].base + pos_opp(s, 3);
+                    if (ok) {
+                        if (sub == 1) ok = edge_ids(n0, s_hi, e + 2);
+                        else e[2] = e[3] = blocks[n0].base + pos_opp(s, 4);
+                    }
+                } else {  // FINE
+                    const int32_t n1 = find(b.nb[s][1]);
+                    if (n1 < 0 || blocks[n1].type[opp] == SIDE_GENERAL) { ok = false; continue; }
+                    ok = blocks[n0].type[s_hi] == SIDE_SAME && blocks[n0].nb[s_hi][0] == blocks[n1].base &&
+                         blocks[n1].type[s_lo] == SIDE_SAME && blocks[n1].nb[s_lo][0] == blocks[n0].base &&
+                         edge_ids(n0, s_lo, e) && edge_ids(n1, s_hi, e + 2);
+                }
+            }
+            fus[bi] = ok;
+            nfus += ok;
+        }
+        info[8] = nfus;
     }
     info[7] = n_phase1[1];
     info[0] = (int64_t)blocks.size();

@@ -145,14 +145,17 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         std::vector<BlockDesc2> blocks;
         std::vector<int32_t> irr;
         int32_t nph[2] = {0, 0};
-        std::vector<int32_t> htab;
+        std::vector<int32_t> htab, etab;
+        std::vector<char> fus;
         if (n_image > 0 && image_in_domain)
-            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph, htab);
+            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph, htab, etab, fus);
         else {  // no image information: everything is "boundary"
             std::vector<int32_t> none;
-            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph, htab);
+            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph, htab, etab, fus);
         }
         if ((rc = ibh_upload(&p->htab, htab.data(), htab.size()))) return rc;
+        if ((rc = ibh_upload(&p->etab, etab.data(), etab.size()))) return rc;
+        p->fuse_all = !blocks.empty() && irr.empty() && p->info[8] == (int64_t)blocks.size();
         p->nA1 = nph[0];
         p->nB1 = nph[1];
         p->bs = block_size;
@@ -225,6 +228,7 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->image_in_domain);
     hipFree(p->blocks2);
     hipFree(p->htab);
+    hipFree(p->etab);
     hipFree(p->blocks3);
     hipFree(p->htab3);
     hipFree(p->ftab3);
@@ -237,7 +241,7 @@ int ibh_partition_destroy(ibh_part* p) {
 
 int ibh_partition_info(const ibh_part* p, int64_t* info, int n) {
     IBH_REQUIRE(p && info, "ibh_partition_info: null argument");
-    for (int i = 0; i < n && i < 8; ++i) info[i] = p->info[i];
+    for (int i = 0; i < n && i < 10; ++i) info[i] = p->info[i];
     return 0;
 }
 

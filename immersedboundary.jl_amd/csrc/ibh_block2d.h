@@ -202,50 +202,17 @@ __device__ __forceinline__ Role role_of(int lane) {
 // of GY/CY on y sides) + extra[64]
 #define BLK2_PASSB_LDS (6 * 128 + 64)
 
-__device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
-                                          int32_t blk, uint32_t nc, const float* __restrict__ u,
-                                          const float* __restrict__ C, uint32_t ldc, const float* __restrict__ G,
-                                          float* __restrict__ ud, float* lds, int lane) {
-    const BlockDesc2 bb = blocks[blk];  // by value: wave-uniform, lives in SGPRs, no per-lane descriptor loads
-    const uint32_t c = (uint32_t)bb.base + lane;
-    float* fU = lds;
-    float* fD = lds + 128;
-    float* fGX = lds + 256;
-    float* fGY = lds + 384;
-    float* fCX = lds + 512;
-    float* fCY = lds + 640;
+// fluxes + Green-Gauss of one block once U, D, GX, GY, CX, CY are staged as [tile | halo] fields
+__device__ __forceinline__ void passB_adv_core(const BlockDesc2& bb, const Lane& L, int lane, uint32_t c, float* lds,
+                                               float uc, float Dc, float gxc, float gyc, float cxc, float cyc,
+                                               float* __restrict__ ud) {
+    const float* fU = lds;
+    const float* fD = lds + 128;
+    const float* fGX = lds + 256;
+    const float* fGY = lds + 384;
+    const float* fCX = lds + 512;
+    const float* fCY = lds + 640;
     float* ex = lds + 768;
-    const float* Gs = G + (size_t)2 * nc;
-    // issue order: halo table (needs nothing), own-cell loads (need the descriptor), and only then the
-    // gathers that wait for the table -- the scheduling barrier keeps them from being hoisted in between
-    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
-    const float uc = ldg(u, c), Dc = ldg(Gs, c), gxc = ldg(G, c), gyc = ldg(G + nc, c);
-    const float cxc = ldg(C, c), cyc = ldg(C + ldc, c);
-    __builtin_amdgcn_sched_barrier(0);
-    // halo slot of this lane: sides 0,1 need the x-gradient / Cx of the neighbour, sides 2,3 the y ones
-    const int dn = lane >> 5;
-#ifdef IBH_ABLATE_NOHALO
-    const float hu = 0.f, hD = 0.f, hg = 0.f, hc = 0.f;
-#else
-    const float hu = ldg(u, hidx), hD = ldg(Gs, hidx);
-    const float hg = ldg(G + (size_t)dn * nc, hidx);
-    const float hc = ldg(C + (size_t)dn * ldc, hidx);
-#endif
-    fU[lane] = uc;
-    fD[lane] = Dc;
-    fGX[lane] = gxc;
-    fGY[lane] = gyc;
-    fCX[lane] = cxc;
-    fCY[lane] = cyc;
-    fU[64 + lane] = hu;
-    fD[64 + lane] = hD;
-    fGX[64 + lane] = hg;  // slots of sides 2,3 hold gy here; they are only read through fGY below
-    fGY[64 + lane] = hg;
-    fCX[64 + lane] = hc;
-    fCY[64 + lane] = hc;
-    const Lane L = lane_info(bb, lane);
-    wave_lds_sync();
-
     const float hx = bb.h[0], hy = bb.h[1], rhx = bb.rh[0], rhy = bb.rh[1];
     // per-side half-widths of the neighbour and 1/(dA+dB), wave-uniform (scalar registers)
     const float dBs[4] = {0.5f * hx * bb.rt[0], 0.5f * hx * bb.rt[1], 0.5f * hy * bb.rt[2], 0.5f * hy * bb.rt[3]};
@@ -286,6 +253,51 @@ __device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks,
     FT = L.edge[3] ? 0.5f * (FT + FT1) : FT;
     const float res = -((FR - FL) * rhx) - ((FT - FB) * rhy);
     if (!L.general) stg(ud, c, res);
+}
+
+__device__ __forceinline__ void passB_adv(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                          int32_t blk, uint32_t nc, const float* __restrict__ u,
+                                          const float* __restrict__ C, uint32_t ldc, const float* __restrict__ G,
+                                          float* __restrict__ ud, float* lds, int lane) {
+    const BlockDesc2 bb = blocks[blk];  // by value: wave-uniform, lives in SGPRs, no per-lane descriptor loads
+    const uint32_t c = (uint32_t)bb.base + lane;
+    float* fU = lds;
+    float* fD = lds + 128;
+    float* fGX = lds + 256;
+    float* fGY = lds + 384;
+    float* fCX = lds + 512;
+    float* fCY = lds + 640;
+    const float* Gs = G + (size_t)2 * nc;
+    // issue order: halo table (needs nothing), own-cell loads (need the descriptor), and only then the
+    // gathers that wait for the table -- the scheduling barrier keeps them from being hoisted in between
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
+    const float uc = ldg(u, c), Dc = ldg(Gs, c), gxc = ldg(G, c), gyc = ldg(G + nc, c);
+    const float cxc = ldg(C, c), cyc = ldg(C + ldc, c);
+    __builtin_amdgcn_sched_barrier(0);
+    // halo slot of this lane: sides 0,1 need the x-gradient / Cx of the neighbour, sides 2,3 the y ones
+    const int dn = lane >> 5;
+#ifdef IBH_ABLATE_NOHALO
+    const float hu = 0.f, hD = 0.f, hg = 0.f, hc = 0.f;
+#else
+    const float hu = ldg(u, hidx), hD = ldg(Gs, hidx);
+    const float hg = ldg(G + (size_t)dn * nc, hidx);
+    const float hc = ldg(C + (size_t)dn * ldc, hidx);
+#endif
+    fU[lane] = uc;
+    fD[lane] = Dc;
+    fGX[lane] = gxc;
+    fGY[lane] = gyc;
+    fCX[lane] = cxc;
+    fCY[lane] = cyc;
+    fU[64 + lane] = hu;
+    fD[64 + lane] = hD;
+    fGX[64 + lane] = hg;  // slots of sides 2,3 hold gy here; they are only read through fGY below
+    fGY[64 + lane] = hg;
+    fCX[64 + lane] = hc;
+    fCY[64 + lane] = hc;
+    const Lane L = lane_info(bb, lane);
+    wave_lds_sync();
+    passB_adv_core(bb, L, lane, c, lds, uc, Dc, gxc, gyc, cxc, cyc, ud);
 }
 
 // ------------------------------------------------------------------------------------------

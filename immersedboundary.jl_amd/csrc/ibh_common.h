@@ -72,6 +72,8 @@ struct ibh_part {
     int32_t nA1 = 0, nB1 = 0;    // blocks [0,nA1): pass A independent of skirt data; [0,nB1): pass B too
     BlockDesc2* blocks2 = nullptr;
     int32_t* htab = nullptr;     // [nblk][64] halo cell table, same order as blocks2
+    int32_t* etab = nullptr;     // [nblk][16] end table of the single-kernel sweep (see ibh_analyze.cpp step 6)
+    int32_t fuse_all = 0;        // 1: every block is eligible for the single-kernel sweep and there are no face-list cells
     BlockDesc3* blocks3 = nullptr;  // 3-D block table (nd == 3)
     int32_t* htab3 = nullptr;    // [nblk][384]
     int32_t* ftab3 = nullptr;    // [nfine][6][64][3] sub-faces 1..3 of FINE sides
@@ -82,7 +84,7 @@ struct ibh_part {
     // rec[(q*5 + 1 + k)*n_irr + t] = the cell across its k-th face (accumulator order).  One coalesced read
     // replaces the offsets -> face ids -> owner/neighbour chain of the CSR walk.
     int32_t* irr_rec = nullptr;
-    int64_t info[8] = {0};
+    int64_t info[10] = {0};
     // workspace for per-cell gradients + sensor (pass A output)
     float* G = nullptr;
     size_t G_bytes = 0;
@@ -134,7 +136,8 @@ struct HostPartView {
 };
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
                          std::vector<int32_t>& irr_cells, int64_t* info, const int32_t* image_in_domain,
-                         int32_t n_image, int32_t* n_phase1, std::vector<int32_t>& htab);
+                         int32_t n_image, int32_t* n_phase1, std::vector<int32_t>& htab,
+                         std::vector<int32_t>& etab, std::vector<char>& fusable);
 
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,

@@ -17,6 +17,8 @@
 //     IBH_FORCE_GENERAL is set.
 // Both bodies call the same per-face functions (ibh_flux.h) in the same order, so they agree
 // bit for bit with each other and with the oracle's array-at-a-time evaluation.
+#include <algorithm>
+
 #include "ibh_common.h"
 #include "ibh_flux.h"
 
@@ -488,6 +490,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 }  // namespace
 
 #include "ibh_block2d.h"
+#include "ibh_sweep2d.h"
 #include "ibh_block3d.h"
 
 namespace {
@@ -556,6 +559,23 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
     int32_t c = cells ? cells[t] : (int32_t)t;
     if (flat.rec) passB_adv_flat<ND>(p, flat, (int32_t)t, c, u, C, ldc, G, ud);
     else passB_adv_cell<ND>(p, u, C, ldc, G, ud, c);
+}
+
+// Single-kernel sweep over a range of eligible blocks (blk2::sweep_adv): no workspace traffic, one launch.
+// A workgroup owns WPB*iters consecutive blocks; wave w takes block (first + k*WPB + w), k = 0..iters-1, so the
+// waves of a workgroup always work on adjacent blocks and the lane-only index arithmetic is paid once per wave.
+__global__ __launch_bounds__(64 * WPB) void k_sweep_adv(const float* __restrict__ u, const float* __restrict__ C,
+                                                        uint32_t ldc, float* __restrict__ ud,
+                                                        const BlockDesc2* __restrict__ blocks,
+                                                        const int32_t* __restrict__ htab,
+                                                        const int32_t* __restrict__ etab, int32_t nblk, int32_t nwg,
+                                                        int32_t iters) {
+    __shared__ float lds[WPB * BLK2_SWEEP_LDS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * (WPB * iters) + wave);
+    if (first >= nblk) return;
+    const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPB - 1) / WPB));
+    blk2::sweep_adv(blocks, htab, etab, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
 }
 
 // 3-D block kernels: one 512-thread workgroup per 8x8x8 block (the face-list cells get their own launch)
@@ -629,6 +649,9 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_euler(PartView p, const floa
     passB_euler_cell<ND>(p, P, ldp, G, R, ldr, Rgas, gamma, c);
 }
 
+// blocks per wave of the single-kernel sweep; 0 = automatic (IBH_SWEEP_ITERS overrides, for tuning)
+const int ibh_sweep_iters = getenv("IBH_SWEEP_ITERS") ? atoi(getenv("IBH_SWEEP_ITERS")) : 0;
+
 PartView view(const ibh_part* p) {
     PartView v;
     v.nc = p->nc;
@@ -683,6 +706,23 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         if (doB && (b1 > b0 || gI))
             hipLaunchKernelGGL(k_passB3_adv_blk, dim3(b1 - b0 + gI), dim3(512), 0, ibh_stream, v, u, C, ldc, p->G, ud,
                                p->blocks3 + b0, p->htab3 + (size_t)b0 * 384, p->ftab3, b1 - b0, p->irr_cells, nI, flat_of(p, p->irr_cells));
+        IBH_LAUNCH_CHECK();
+        return 0;
+    }
+    if (p->nd == 2 && p->bs == 8 && p->fuse_all &&
+        !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY))) {
+        // every block is eligible: the whole sweep (or one overlap phase of it) is one launch
+        const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
+        IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
+        const int32_t b0 = ph2 ? p->nB1 : 0, b1 = ph1 ? p->nB1 : p->nblk;
+        // blocks per wave: keep enough waves to fill the chip before a wave takes a second block
+        const int32_t nbl = b1 - b0;
+        // (measured on 13.5 k and 54 k blocks, scripts/sweep_iters.sh: 2-3 and 4-6 blocks per wave are best)
+        const int32_t iters = ibh_sweep_iters > 0 ? ibh_sweep_iters : std::min(6, std::max(1, nbl / 6000));
+        const int32_t nwg = (nbl + WPB * iters - 1) / (WPB * iters);
+        if (nwg > 0)
+            hipLaunchKernelGGL(k_sweep_adv, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
+                               p->blocks2 + b0, p->htab + (size_t)b0 * 64, p->etab + (size_t)b0 * 16, nbl, nwg, iters);
         IBH_LAUNCH_CHECK();
         return 0;
     }

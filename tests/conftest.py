@@ -109,3 +109,20 @@ def rel_inf(a, b):
     den = np.abs(b).max(axis=0)
     den = np.where(den == 0, 1.0, den)
     return (np.abs(a - b).max(axis=0) / den).max()
+
+
+def oracle_view(part):
+    """Oracle-side view of a product partition (same arrays, oracle Accumulator objects)."""
+    from oracle.accumulator import Accumulator as OAcc
+
+    class P:
+        pass
+    op = P()
+    op.ndims, op.spacing, op.centers = part.ndims, part.spacing, part.centers
+    op.face_owners_neighbors = part.face_owners_neighbors
+    op.face_accumulators = {}
+    for k, acc in part.face_accumulators.items():
+        o = object.__new__(OAcc)
+        o.n_output, o.first_index, o.stencils = acc.n_output, True, acc.stencils
+        op.face_accumulators[k] = o
+    return op

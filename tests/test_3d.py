@@ -111,21 +111,7 @@ def test_3d_residuals_match_oracle(sphere_domains):
         assert rel_inf(got, R) <= 1e-5
 
 
-def _oracle_view(part):
-    """Oracle-side view of a product partition (same arrays, oracle Accumulator objects)."""
-    from oracle.accumulator import Accumulator as OAcc
-
-    class P:
-        pass
-    op = P()
-    op.ndims, op.spacing, op.centers = part.ndims, part.spacing, part.centers
-    op.face_owners_neighbors = part.face_owners_neighbors
-    op.face_accumulators = {}
-    for k, acc in part.face_accumulators.items():
-        o = object.__new__(OAcc)
-        o.n_output, o.first_index, o.stencils = acc.n_output, True, acc.stencils
-        op.face_accumulators[k] = o
-    return op
+from conftest import oracle_view as _oracle_view  # noqa: E402
 
 
 @pytest.fixture(scope="module")

@@ -135,3 +135,33 @@ def test_overlap_phases_equal_full_sweep(rae_domains, flags):
         img = part.image_in_domain
         assert np.array_equal(got[img], ud_full[img])
     assert n_int > 0
+
+
+@pytest.mark.parametrize("kind", ["smooth", "step", "noise"])
+def test_single_kernel_sweep(rae_mesh_small, kind):
+    """One partition with no face-list cells: the whole sweep is one launch that also computes gradient and
+    sensor of the halo cells (blk2::sweep_adv).  It must agree with the oracle, with the two-kernel form
+    (IBH_NO_FUSE) and with itself when split in overlap phases."""
+    from conftest import RAE_FAMILIES
+    dom = ibamd.Domain(rae_mesh_small, hypercube_families=RAE_FAMILIES, max_partition_size=10 ** 9, boundaries=False)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    assert dpart.info["fusable_blocks"] == dpart.info["full_blocks"] > 0 and dpart.info["irregular_cells"] == 0
+    if kind == "noise":
+        u = np.random.default_rng(7).uniform(-1, 1, part.centers.shape[0]).astype(f32)
+    else:
+        u = seeded_field(part.centers, kind=kind)
+    C = np.stack([f32(1) + seeded_field(part.centers, seed=5) * f32(0.3),
+                  f32(-0.5) + seeded_field(part.centers, seed=3) * f32(0.1)], axis=1)
+    from conftest import oracle_view
+    exp = oracle_advection_residual(oracle_view(part), u, C)
+    one = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C)))
+    two = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), flags=ibamd.IBH_NO_FUSE))
+    assert rel_inf(two, exp) <= TOL
+    assert rel_inf(one, exp) <= TOL
+    assert rel_inf(one, two) <= 2e-6
+    import torch
+    ud = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+    ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud, flags=ibamd.IBH_PHASE_INTERIOR)
+    ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud, flags=ibamd.IBH_PHASE_BOUNDARY)
+    assert np.array_equal(ibamd.to_host(ud), one)
