@@ -564,14 +564,17 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
 // Single-kernel sweep over a range of eligible blocks (blk2::sweep_adv): no workspace traffic, one launch.
 // A workgroup owns WPB*iters consecutive blocks; wave w takes block (first + k*WPB + w), k = 0..iters-1, so the
 // waves of a workgroup always work on adjacent blocks and the lane-only index arithmetic is paid once per wave.
-__global__ __launch_bounds__(64 * WPB) void k_sweep_adv(const float* __restrict__ u, const float* __restrict__ C,
+#ifndef IBH_SWEEP_WAVES
+#define IBH_SWEEP_WAVES 5
+#endif
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(IBH_SWEEP_WAVES, IBH_SWEEP_WAVES))) void k_sweep_adv(const float* __restrict__ u, const float* __restrict__ C,
                                                         uint32_t ldc, float* __restrict__ ud,
                                                         const BlockDesc2* __restrict__ blocks,
                                                         const int32_t* __restrict__ htab,
                                                         const int32_t* __restrict__ etab, int32_t nblk, int32_t nwg,
                                                         int32_t iters) {
     __shared__ float lds[WPB * BLK2_SWEEP_LDS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform LDS base
     const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * (WPB * iters) + wave);
     if (first >= nblk) return;
     const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPB - 1) / WPB));

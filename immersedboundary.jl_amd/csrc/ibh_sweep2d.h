@@ -52,16 +52,41 @@ __device__ __forceinline__ float flux_w(float ua, float ub, float Sa, float Sb, 
     return Cf * A + fabsf(Cf) * B;
 }
 
-// undivided slope and sensor term of one direction: l0,l1 / r0,r1 the neighbour values on the low / high side
-// (equal when the side has one face), qL, qR the at_faces weights of the neighbours, rh = 1/h
-__device__ __forceinline__ void slope_dir(float uc, float l0, float l1, float r0, float r1, float qL, float qR,
-                                          float rh, float& S, float& nu) {
-    const float dR = 0.5f * (r0 + r1) - uc;
-    const float dL = uc - 0.5f * (l0 + l1);
-    S = qR * dR + qL * dL;
-    const float gg = dR - dL;
-    const float a2 = (fabsf(r0 - uc) + fabsf(r1 - uc)) + (fabsf(uc - l0) + fabsf(uc - l1));
-    nu = (1e-7f + fabsf(gg) * rh) * __builtin_amdgcn_rcpf(1e-7f + a2 * (0.5f * rh));
+// ---- the same arithmetic on (x, y) pairs: v_pk_{add,mul,fma}_f32 do two lanes' worth per instruction
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f v2(float a, float b) { return v2f{a, b}; }
+__device__ __forceinline__ v2f v2(float a) { return v2f{a, a}; }
+__device__ __forceinline__ v2f absv(v2f a) { return v2f{fabsf(a.x), fabsf(a.y)}; }
+
+__device__ __forceinline__ v2f flux_w2(v2f ua, v2f ub, v2f Sa, v2f Sb, v2f Da, v2f Db, v2f Ca, v2f Cb, v2f wa) {
+    const v2f d = ub - ua;
+    const v2f gu = Sa - d * wa;
+    const v2f Du = Sb - d * (1.0f - wa);
+    const v2f s = v2f{__builtin_amdgcn_fmed3f(Du.x, gu.x, 0.0f), __builtin_amdgcn_fmed3f(Du.y, gu.y, 0.0f)};
+    const v2f t16 = (Sa - Sb) * 0.0625f;
+    const v2f uf = (ua + wa * d) + t16;
+    const v2f mu = d * (0.5f - wa) - t16;
+    const v2f Df = v2f{fmaxf(fmaxf(Da.x, Db.x), 1e-7f), fmaxf(fmaxf(Da.y, Db.y), 1e-7f)};
+    const v2f A = uf + Df * mu;
+    const v2f Cf = Ca + wa * (Cb - Ca);
+    const v2f B = Df * (s - 0.5f * d);
+    return Cf * A + absv(Cf) * B;
+}
+
+// sensor terms of a cell of value uc in two directions at once: a0,a1 / b0,b1 the neighbour values on the two
+// sides of each direction (equal when a side has one face), rh = 1/h per direction:
+//   (1e-7 + |gg|)/(1e-7 + ugg)  of JST_sensor(:1077-1097) with gg, ugg the signed / unsigned Green-Gauss sums
+__device__ __forceinline__ v2f sensor2(float uc, v2f a0, v2f a1, v2f b0, v2f b1, v2f rh) {
+    // differences packed; the sums of absolute values scalar (|x| is a free source modifier there, packed
+    // instructions would need a v_and per operand)
+    const v2f c = v2(uc), hrh = 0.5f * rh;
+    const v2f d0 = a0 - c, d1 = a1 - c, d2 = b0 - c, d3 = b1 - c;
+    const v2f g = (d0 + d1) + (d2 + d3);  // = 2 * (signed sum)
+    const float ax = (fabsf(d0.x) + fabsf(d1.x)) + (fabsf(d2.x) + fabsf(d3.x));
+    const float ay = (fabsf(d0.y) + fabsf(d1.y)) + (fabsf(d2.y) + fabsf(d3.y));
+    const float nx = (1e-7f + fabsf(g.x) * hrh.x) * __builtin_amdgcn_rcpf(1e-7f + ax * hrh.x);
+    const float ny = (1e-7f + fabsf(g.y) * hrh.y) * __builtin_amdgcn_rcpf(1e-7f + ay * hrh.y);
+    return v2f{nx, ny};
 }
 
 // what a wave fetches for a block before anything depends on anything: issued one block ahead
@@ -92,6 +117,20 @@ __device__ __forceinline__ SweepPre sweep_prefetch(const BlockDesc2* __restrict_
     P.cxc = ldg(C, c);
     P.cyc = ldg(C + ldc, c);
     return P;
+}
+// the dependent loads of a block (addresses from the halo / end tables): issued one block ahead as well
+struct SweepGat {
+    float hu, hdeep, hc, eu;
+};
+__device__ __forceinline__ SweepGat sweep_gather(const SweepPre& P, int delta, bool dn, const float* __restrict__ u,
+                                                 const float* __restrict__ C, uint32_t ldc) {
+    SweepGat G;
+    const uint32_t didx = P.ty == SIDE_MIRROR ? P.hidx : P.hidx + (uint32_t)delta;
+    G.hu = ldg(u, P.hidx);
+    G.hdeep = ldg(u, didx);
+    G.hc = ldg(C + (dn ? ldc : 0u), P.hidx);
+    G.eu = ldg(u, P.eidx);
+    return G;
 }
 static_assert(offsetof(BlockDesc2, type) == 4 && offsetof(BlockDesc2, q) == 84, "sweep_prefetch reads type/q by offset");
 
@@ -134,17 +173,23 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
     const float* xS = xd ? fSY : fSX;
     const float* xC = xd ? fCY : fCX;
 
-    SweepPre N = sweep_prefetch(blocks, htab, etab, blk0, u, C, ldc, lane);
+    // two-stage pipeline: while block k is computed, the gathers of block k+1 and the tables of block k+2 are in flight
+    SweepPre T1 = sweep_prefetch(blocks, htab, etab, blk0, u, C, ldc, lane);
+    SweepGat G1 = sweep_gather(T1, delta, dn != 0, u, C, ldc);
+    SweepPre T2 = T1;
+    if (nb > 1) T2 = sweep_prefetch(blocks, htab, etab, blk0 + stride, u, C, ldc, lane);
     for (int32_t it = 0; it < nb; ++it) {
-        const SweepPre P = N;
-        if (it + 1 < nb) N = sweep_prefetch(blocks, htab, etab, blk0 + (it + 1) * stride, u, C, ldc, lane);
+        const SweepPre P = T1;
+        const SweepGat G = G1;
+        if (it + 1 < nb) {
+            T1 = T2;
+            G1 = sweep_gather(T1, delta, dn != 0, u, C, ldc);
+        }
+        if (it + 2 < nb) T2 = sweep_prefetch(blocks, htab, etab, blk0 + (it + 2) * stride, u, C, ldc, lane);
         const BlockDesc2& bb = P.bb;
         const float uc = P.uc, cxc = P.cxc, cyc = P.cyc;
         const bool mirror = P.ty == SIDE_MIRROR, isC = P.ty == SIDE_COARSE, isF = P.ty == SIDE_FINE;
-        const uint32_t didx = mirror ? P.hidx : P.hidx + (uint32_t)delta;
-        const float hu = ldg(u, P.hidx), hdeep = ldg(u, didx);
-        const float hc = ldg(C + (size_t)dn * ldc, P.hidx);
-        const float eu = ldg(u, P.eidx);
+        const float hu = G.hu, hdeep = G.hdeep, hc = G.hc, eu = G.eu;
         if (it) wave_lds_sync();  // the previous block's last LDS reads are done
         fU[lane] = uc;
         fCX[lane] = cxc;
@@ -159,13 +204,18 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
         const float q0 = e0 ? bb.q[0] : 0.5f, q1 = e1 ? bb.q[1] : 0.5f;
         const float q2 = e2 ? bb.q[2] : 0.5f, q3 = e3 ? bb.q[3] : 0.5f;
         wave_lds_sync();
-        // ---- own cells: undivided slopes + sensor
+        // ---- own cells: undivided slopes + sensor, x and y together
         float Sx, Sy, Dc;
         {
-            float nx, ny;
-            slope_dir(uc, fU[n0], fU[n0b], fU[n1], fU[n1b], q0, q1, bb.rh[0], Sx, nx);
-            slope_dir(uc, fU[n2], fU[n2b], fU[n3], fU[n3b], q2, q3, bb.rh[1], Sy, ny);
-            Dc = fmaxf(fmaxf(nx, ny), 1e-7f);
+            const v2f l0 = v2(fU[n0], fU[n2]), l1 = v2(fU[n0b], fU[n2b]);
+            const v2f r0 = v2(fU[n1], fU[n3]), r1 = v2(fU[n1b], fU[n3b]);
+            const v2f c = v2(uc);
+            const v2f dR = 0.5f * (r0 + r1) - c, dL = c - 0.5f * (l0 + l1);
+            const v2f S = v2(q1, q3) * dR + v2(q0, q2) * dL;
+            const v2f nu = sensor2(uc, l0, l1, r0, r1, v2(bb.rh[0], bb.rh[1]));
+            Sx = S.x;
+            Sy = S.y;
+            Dc = fmaxf(fmaxf(nu.x, nu.y), 1e-7f);
         }
         fSX[lane] = Sx;
         fSY[lane] = Sy;
@@ -181,8 +231,6 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
             const float dde = hdeep - hu;              // away from it
             const float x = (1.0f - P.qs) * din - 0.5f * dde;  // u_face,in - u_face,deep
             Sh = (s & 1) ? -x : x;
-            const float an = (fabsf(m0 - hu) + fabsf(m1 - hu)) + 2.0f * fabsf(dde);
-            const float nun = (1e-7f + fabsf(din + dde) * ihn) * __builtin_amdgcn_rcpf(1e-7f + an * (0.5f * ihn));
             const int mask = isF ? 15 : isC ? 12 : 14;
             const int pm = p & mask, w = 16 - mask, e0i = pm + 2;
             const bool single = mask == 15;
@@ -190,11 +238,10 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
             const int lo1 = lo0 + ((pm == 0 || !single) ? 1 : 0);
             const int hi0 = e0i + w;
             const int hi1 = hi0 + ((hi0 == 18 || !single) ? 1 : 0);
-            const float l0 = el[lo0], l1 = el[lo1], r0 = el[hi0], r1 = el[hi1];
-            const float gt = 0.5f * ((r0 + r1) + (l0 + l1)) - 2.0f * hu;
-            const float at = (fabsf(r0 - hu) + fabsf(r1 - hu)) + (fabsf(hu - l0) + fabsf(hu - l1));
-            const float nut = (1e-7f + fabsf(gt) * iht) * __builtin_amdgcn_rcpf(1e-7f + at * (0.5f * iht));
-            Dh = fmaxf(fmaxf(nun, nut), 1e-7f);
+            // normal and tangential direction together
+            const v2f nu = sensor2(hu, v2(m0, el[lo0]), v2(m1, el[lo1]), v2(hdeep, el[hi0]), v2(hdeep, el[hi1]),
+                                   v2(ihn, iht));
+            Dh = fmaxf(fmaxf(nu.x, nu.y), 1e-7f);
         }
         wave_lds_sync();
         {
@@ -207,8 +254,9 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
         fD[64 + lane] = Dh;
         wave_lds_sync();
         // ---- fluxes: right (x+) and top (y+) face of every cell, sub-face 0 on block sides
-        float FR = flux_w(uc, fU[n1], Sx, fSX[n1], Dc, fD[n1], cxc, fCX[n1], q1);
-        float FT = flux_w(uc, fU[n3], Sy, fSY[n3], Dc, fD[n3], cyc, fCY[n3], q3);
+        const v2f F2 = flux_w2(v2(uc), v2(fU[n1], fU[n3]), v2(Sx, Sy), v2(fSX[n1], fSY[n3]), v2(Dc), v2(fD[n1], fD[n3]),
+                               v2(cxc, cyc), v2(fCX[n1], fCY[n3]), v2(q1, q3));
+        float FR = F2.x, FT = F2.y;
         // low sides: the halo cell is the owner, this block's cell the neighbour
         ex[lane] = flux_w(fU[xslot], fU[xpos], xS[xslot], xS[xpos], fD[xslot], fD[xpos], xC[xslot], xC[xpos],
                           1.0f - (xd ? bb.q[2] : bb.q[0]));
