@@ -322,10 +322,17 @@ def main():
     if is3d and (euler or world > 1):
         raise SystemExit("3-D workloads: scalar sweep on one GPU only (secondary measurement)")
     # single-kernel sweep: every block eligible, no face-list cells (2-D scalar sweep on one partition)
-    fused = (not euler and not is3d and flags == 0 and dpart.info["irregular_cells"] == 0
-             and dpart.info["fusable_blocks"] == dpart.info["full_blocks"] > 0)
+    inf = dpart.info
+    fused = (not euler and not is3d and flags == 0 and inf["irregular_cells"] == 0
+             and inf["fusable_blocks"] == inf["full_blocks"] > 0)
+    # partitions with skirt blocks: eligible blocks in the single kernel, the rest in the two-kernel form
+    mixed = (not euler and not is3d and flags == 0 and not fused
+             and 0 < inf["fusable_blocks"] and 4 * inf["fusable_blocks"] >= inf["full_blocks"])
     if fused:
         tB, tA = time_pass(0, reps), None
+    elif mixed:
+        tB, tA = time_pass(ibamd.IBH_SWEEP_ONLY, reps), None
+        cells_launch = 64 * inf["fusable_blocks"]
     else:
         tB = time_pass(ibamd.IBH_PASS_B_ONLY, reps)
         tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
@@ -336,7 +343,7 @@ def main():
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
     # calibrated against the kernel's known tile loads); null if not profiled.
     kernel = ("k_passB_euler_blk" if euler else "k_passB3_adv_blk" if is3d else
-              "k_sweep_adv" if fused else "k_passB_adv<2,false>")
+              "k_sweep_adv" if (fused or mixed) else "k_passB_adv<2,false>")
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "current_pmc.json")) as f:
@@ -363,7 +370,9 @@ def main():
                                f"{'R2 Euler HLL' if euler else 'R1 advection'}-JST-MUSCL residual, fields resident in HBM",
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
                    "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else
-                            "block-fast-path, single kernel" if fused else "block-fast-path, two kernels"),
+                            "block-fast-path, single kernel" if fused else
+                            "block-fast-path, single kernel on %d of %d blocks" % (inf["fusable_blocks"], inf["full_blocks"])
+                            if mixed else "block-fast-path, two kernels"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",
                    "halo": None if hx is None else {"backend": args.backend, "exchange": halo_kind,
                                                     "overlap": comm_stream is not None,

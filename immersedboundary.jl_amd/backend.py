@@ -35,6 +35,7 @@ IBH_EXACT = 16
 IBH_PHASE_INTERIOR = 32
 IBH_PHASE_BOUNDARY = 64
 IBH_NO_FUSE = 128
+IBH_SWEEP_ONLY = 256
 
 _initialised = {}
 
@@ -165,7 +166,7 @@ class DevicePartition:
         call("ibh_partition_info", h, info, 10)
         self.info = dict(full_blocks=info[0], irregular_cells=info[1], sides_same=info[2], sides_mirror=info[3],
                          sides_coarse=info[4], sides_fine=info[5], sides_general=info[6], interior_blocks=info[7],
-                         fusable_blocks=info[8])
+                         fusable_blocks=info[8], workspace_blocks=info[9])
 
     @property
     def ndims(self):

@@ -23,7 +23,8 @@ inline bool on_opp_edge(int s, int pos) {
 
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks, std::vector<int32_t>& irr,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
-                         std::vector<int32_t>& htab, std::vector<int32_t>& etab, std::vector<char>& fus) {
+                         std::vector<int32_t>& htab, std::vector<int32_t>& etab, std::vector<char>& fus,
+                         std::vector<char>& needg) {
     const int32_t nc = v.nc;
     const int NPB = 64;
     const float* hx = v.spacing;
@@ -295,6 +296,28 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
             nfus += ok;
         }
         info[8] = nfus;
+    }
+    // 7. mixed launches (partitions with skirt blocks): eligible blocks take the single kernel, the others the
+    //    two-kernel form.  The gradient workspace is then needed only where somebody reads it: in the blocks
+    //    that are not eligible, in their halo cells and in the face neighbours of the face-list cells.
+    needg.assign(blocks.size(), 0);
+    {
+        std::vector<char> mark(nc, 0);
+        for (int32_t c : irr) {
+            mark[c] = 1;
+            for (int d = 0; d < v.nd; ++d) {
+                for (int32_t k = v.loff[d][c]; k < v.loff[d][c + 1]; ++k) mark[v.owners[d][v.lidx[d][k]]] = 1;
+                for (int32_t k = v.roff[d][c]; k < v.roff[d][c + 1]; ++k) mark[v.neighbors[d][v.ridx[d][k]]] = 1;
+            }
+        }
+        for (size_t bi = 0; bi < blocks.size(); ++bi)
+            if (!fus[bi])
+                for (int k = 0; k < 64; ++k) mark[htab[bi * 64 + k]] = 1;
+        for (size_t bi = 0; bi < blocks.size(); ++bi) {
+            bool need = !fus[bi];
+            for (int k = 0; k < NPB && !need; ++k) need = mark[blocks[bi].base + k];
+            needg[bi] = need;
+        }
     }
     info[7] = n_phase1[1];
     info[0] = (int64_t)blocks.size();

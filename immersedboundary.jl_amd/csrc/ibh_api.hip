@@ -146,16 +146,31 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         std::vector<int32_t> irr;
         int32_t nph[2] = {0, 0};
         std::vector<int32_t> htab, etab;
-        std::vector<char> fus;
+        std::vector<char> fus, needg;
         if (n_image > 0 && image_in_domain)
-            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph, htab, etab, fus);
+            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph, htab, etab, fus, needg);
         else {  // no image information: everything is "boundary"
             std::vector<int32_t> none;
-            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph, htab, etab, fus);
+            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph, htab, etab, fus, needg);
         }
         if ((rc = ibh_upload(&p->htab, htab.data(), htab.size()))) return rc;
         if ((rc = ibh_upload(&p->etab, etab.data(), etab.size()))) return rc;
         p->fuse_all = !blocks.empty() && irr.empty() && p->info[8] == (int64_t)blocks.size();
+        if (!p->fuse_all && p->info[8] > 0) {
+            std::vector<int32_t> fz, ng, nf;
+            for (int32_t b = 0; b < (int32_t)blocks.size(); ++b) {
+                if (fus[b]) { fz.push_back(b); p->n_fz_int += b < nph[1]; }
+                else { nf.push_back(b); p->n_nf_int += b < nph[1]; }
+                if (needg[b]) { ng.push_back(b); p->n_ng_int += b < nph[0]; }
+            }
+            p->n_fz = (int32_t)fz.size();
+            p->n_ng = (int32_t)ng.size();
+            p->n_nf = (int32_t)nf.size();
+            if ((rc = ibh_upload(&p->fz_list, fz.data(), fz.size()))) return rc;
+            if ((rc = ibh_upload(&p->ng_list, ng.data(), ng.size()))) return rc;
+            if ((rc = ibh_upload(&p->nf_list, nf.data(), nf.size()))) return rc;
+        }
+        p->info[9] = p->fuse_all ? 0 : p->n_ng;
         p->nA1 = nph[0];
         p->nB1 = nph[1];
         p->bs = block_size;
@@ -229,6 +244,9 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->blocks2);
     hipFree(p->htab);
     hipFree(p->etab);
+    hipFree(p->fz_list);
+    hipFree(p->ng_list);
+    hipFree(p->nf_list);
     hipFree(p->blocks3);
     hipFree(p->htab3);
     hipFree(p->ftab3);

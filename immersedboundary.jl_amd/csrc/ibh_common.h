@@ -74,6 +74,11 @@ struct ibh_part {
     int32_t* htab = nullptr;     // [nblk][64] halo cell table, same order as blocks2
     int32_t* etab = nullptr;     // [nblk][16] end table of the single-kernel sweep (see ibh_analyze.cpp step 6)
     int32_t fuse_all = 0;        // 1: every block is eligible for the single-kernel sweep and there are no face-list cells
+    // mixed launches (fuse_all == 0): ascending block indices, interior-phase entries first
+    int32_t* fz_list = nullptr;  // eligible blocks                       [n_fz], the first n_fz_int of them < nB1
+    int32_t* ng_list = nullptr;  // blocks whose gradients somebody reads [n_ng], the first n_ng_int of them < nA1
+    int32_t* nf_list = nullptr;  // blocks left to the two-kernel form    [n_nf], the first n_nf_int of them < nB1
+    int32_t n_fz = 0, n_fz_int = 0, n_ng = 0, n_ng_int = 0, n_nf = 0, n_nf_int = 0;
     BlockDesc3* blocks3 = nullptr;  // 3-D block table (nd == 3)
     int32_t* htab3 = nullptr;    // [nblk][384]
     int32_t* ftab3 = nullptr;    // [nfine][6][64][3] sub-faces 1..3 of FINE sides
@@ -137,7 +142,7 @@ struct HostPartView {
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
                          std::vector<int32_t>& irr_cells, int64_t* info, const int32_t* image_in_domain,
                          int32_t n_image, int32_t* n_phase1, std::vector<int32_t>& htab,
-                         std::vector<int32_t>& etab, std::vector<char>& fusable);
+                         std::vector<int32_t>& etab, std::vector<char>& fusable, std::vector<char>& needg);
 
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,

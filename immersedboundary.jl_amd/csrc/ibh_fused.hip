@@ -504,8 +504,10 @@ template <int ND, int NV, bool EXACT>
 __global__ __launch_bounds__(64 * WPB) void k_passA(PartView p, const float* __restrict__ u, int64_t ldu,
                                                float* __restrict__ G, const BlockDesc2* __restrict__ blocks,
                                                const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg_fast,
-                                               const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
-    // `blocks`/`htab`/`nblk` describe the sub-range of the block table this launch covers.
+                                               const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat,
+                                               const int32_t* __restrict__ blist) {
+    // `blocks`/`htab`/`nblk` describe the sub-range of the block table this launch covers, or, with `blist`,
+    // the whole table and the list of the nblk block indices to take.
     // grid = [face-list workgroups | block workgroups]: the latency-bound face-list cells go first
     __shared__ float lds[WPB * NV * 128];
     const int32_t gI = (ncells + 64 * WPB - 1) / (64 * WPB);
@@ -515,6 +517,7 @@ __global__ __launch_bounds__(64 * WPB) void k_passA(PartView p, const float* __r
             int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
             int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(wg, nwg_fast) * WPB + wave);
             if (blk < nblk) {
+                if (blist) blk = blist[blk];
                 if constexpr (EXACT)
                     passA_block2<NV>(blocks, htab, blk, p.spacing, p.nc, u, ldu, G, lds + wave * NV * 128, lane);
                 else
@@ -535,7 +538,8 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
                                                    int64_t ldc, const float* __restrict__ G, float* __restrict__ ud,
                                                    const BlockDesc2* __restrict__ blocks,
                                                    const int32_t* __restrict__ htab, int32_t nblk, int32_t nwg_fast,
-                                                   const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
+                                                   const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat,
+                                                   const int32_t* __restrict__ blist) {
     constexpr int LDSW = EXACT ? 6 * 128 : BLK2_PASSB_LDS;  // floats per wave
     __shared__ float lds[WPB * LDSW];
     const int32_t gI = (ncells + 64 * WPB - 1) / (64 * WPB);
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
             int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
             int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(wg, nwg_fast) * WPB + wave);
             if (blk < nblk) {
+                if (blist) blk = blist[blk];
                 if constexpr (EXACT)
                     passB_adv_block2(blocks, htab, blk, p.nc, u, C, ldc, G, ud, lds + wave * LDSW, lane);
                 else
@@ -572,13 +577,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(IBH_SW
                                                         const BlockDesc2* __restrict__ blocks,
                                                         const int32_t* __restrict__ htab,
                                                         const int32_t* __restrict__ etab, int32_t nblk, int32_t nwg,
-                                                        int32_t iters) {
+                                                        int32_t iters, const int32_t* __restrict__ blist) {
     __shared__ float lds[WPB * BLK2_SWEEP_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform LDS base
     const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * (WPB * iters) + wave);
     if (first >= nblk) return;
     const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPB - 1) / WPB));
-    blk2::sweep_adv(blocks, htab, etab, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
+    blk2::sweep_adv(blocks, htab, etab, blist, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
 }
 
 // 3-D block kernels: one 512-thread workgroup per 8x8x8 block (the face-list cells get their own launch)
@@ -712,20 +717,55 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         IBH_LAUNCH_CHECK();
         return 0;
     }
-    if (p->nd == 2 && p->bs == 8 && p->fuse_all &&
-        !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY))) {
+    const bool tuned2 = p->nd == 2 && p->bs == 8 && p->nblk > 0 &&
+                        !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY));
+    // single-kernel sweep (blk2::sweep_adv) over the eligible blocks: `count` list positions from `first`
+    auto launch_sweep = [&](const int32_t* list, int32_t first, int32_t count) {
+        if (count <= 0) return;
+        // blocks per wave: keep enough waves to fill the chip before a wave takes a second block
+        // (measured on 13.5 k and 54 k blocks, scripts/sweep_iters.sh: 2-3 and 4-6 blocks per wave are best)
+        const int32_t iters = ibh_sweep_iters > 0 ? ibh_sweep_iters : std::min(6, std::max(1, count / 6000));
+        const int32_t nwg = (count + WPB * iters - 1) / (WPB * iters);
+        if (list)
+            hipLaunchKernelGGL(k_sweep_adv, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
+                               p->blocks2, p->htab, p->etab, count, nwg, iters, list + first);
+        else
+            hipLaunchKernelGGL(k_sweep_adv, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
+                               p->blocks2 + first, p->htab + (size_t)first * 64, p->etab + (size_t)first * 16, count,
+                               nwg, iters, (const int32_t*)nullptr);
+    };
+    if (tuned2 && p->fuse_all) {
         // every block is eligible: the whole sweep (or one overlap phase of it) is one launch
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
         IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
         const int32_t b0 = ph2 ? p->nB1 : 0, b1 = ph1 ? p->nB1 : p->nblk;
-        // blocks per wave: keep enough waves to fill the chip before a wave takes a second block
-        const int32_t nbl = b1 - b0;
-        // (measured on 13.5 k and 54 k blocks, scripts/sweep_iters.sh: 2-3 and 4-6 blocks per wave are best)
-        const int32_t iters = ibh_sweep_iters > 0 ? ibh_sweep_iters : std::min(6, std::max(1, nbl / 6000));
-        const int32_t nwg = (nbl + WPB * iters - 1) / (WPB * iters);
-        if (nwg > 0)
-            hipLaunchKernelGGL(k_sweep_adv, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
-                               p->blocks2 + b0, p->htab + (size_t)b0 * 64, p->etab + (size_t)b0 * 16, nbl, nwg, iters);
+        launch_sweep(nullptr, b0, b1 - b0);
+        IBH_LAUNCH_CHECK();
+        return 0;
+    }
+    if (tuned2 && p->fz_list && 4 * (int64_t)p->n_fz >= p->nblk) {
+        // mixed: eligible blocks in one kernel; the rest (skirt blocks, blocks next to face-list cells) in the
+        // two-kernel form, with the gradient workspace filled only where it is read (ng_list)
+        const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
+        IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
+        const int32_t f0 = ph2 ? p->n_fz_int : 0, f1 = ph1 ? p->n_fz_int : p->n_fz;
+        const int32_t g0 = ph2 ? p->n_ng_int : 0, g1 = ph1 ? p->n_ng_int : p->n_ng;
+        const int32_t r0 = ph2 ? p->n_nf_int : 0, r1 = ph1 ? p->n_nf_int : p->n_nf;
+        const int32_t nI = ph1 ? 0 : p->n_irr;
+        const int32_t gI = (nI + 64 * WPB - 1) / (64 * WPB);
+        PartView v = view(p);
+        const int32_t nwgA = (g1 - g0 + WPB - 1) / WPB, nwgB = (r1 - r0 + WPB - 1) / WPB;
+        if (!(flags & IBH_SWEEP_ONLY)) {
+            if (nwgA + gI)
+                hipLaunchKernelGGL((k_passA<2, 1, false>), dim3(nwgA + gI), dim3(64 * WPB), 0, ibh_stream, v, u,
+                                   (int64_t)p->nc, p->G, p->blocks2, p->htab, g1 - g0, nwgA, p->irr_cells, nI,
+                                   flat_of(p, p->irr_cells), p->ng_list + g0);
+            if (nwgB + gI)
+                hipLaunchKernelGGL((k_passB_adv<2, false>), dim3(nwgB + gI), dim3(64 * WPB), 0, ibh_stream, v, u, C, ldc,
+                                   p->G, ud, p->blocks2, p->htab, r1 - r0, nwgB, p->irr_cells, nI,
+                                   flat_of(p, p->irr_cells), p->nf_list + r0);
+        }
+        launch_sweep(p->fz_list, f0, f1 - f0);
         IBH_LAUNCH_CHECK();
         return 0;
     }
@@ -761,24 +801,24 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     if (p->nd == 2 && exact) {
         if (doA)
             hipLaunchKernelGGL((k_passA<2, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA, htA,
-                               a1 - a0, nwgA_fast, cellsA, nA, flat_of(p, cellsA));
+                               a1 - a0, nwgA_fast, cellsA, nA, flat_of(p, cellsA), nullptr);
         if (doB)
             hipLaunchKernelGGL((k_passB_adv<2, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB, htB,
-                               b1 - b0, nwgB_fast, cellsB, nB, flat_of(p, cellsB));
+                               b1 - b0, nwgB_fast, cellsB, nB, flat_of(p, cellsB), nullptr);
     } else if (p->nd == 2) {
         if (doA)
             hipLaunchKernelGGL((k_passA<2, 1, false>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, blkA, htA,
-                               a1 - a0, nwgA_fast, cellsA, nA, flat_of(p, cellsA));
+                               a1 - a0, nwgA_fast, cellsA, nA, flat_of(p, cellsA), nullptr);
         if (doB)
             hipLaunchKernelGGL((k_passB_adv<2, false>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, blkB, htB,
-                               b1 - b0, nwgB_fast, cellsB, nB, flat_of(p, cellsB));
+                               b1 - b0, nwgB_fast, cellsB, nB, flat_of(p, cellsB), nullptr);
     } else {
         if (doA)
             hipLaunchKernelGGL((k_passA<3, 1, true>), gA, blk, 0, ibh_stream, v, u, (int64_t)p->nc, p->G, p->blocks2,
-                               p->htab, p->nblk, 0, cellsA, nA, flat_of(p, cellsA));
+                               p->htab, p->nblk, 0, cellsA, nA, flat_of(p, cellsA), nullptr);
         if (doB)
             hipLaunchKernelGGL((k_passB_adv<3, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
-                               p->htab, p->nblk, 0, cellsB, nB, flat_of(p, cellsB));
+                               p->htab, p->nblk, 0, cellsB, nB, flat_of(p, cellsB), nullptr);
     }
     IBH_LAUNCH_CHECK();
     return 0;
@@ -809,10 +849,10 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     if (p->nd == 2) {
         if (doA && fast)
             hipLaunchKernelGGL((k_passA<2, 4, false>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
-                               p->nblk, nwg_fast, cellsA, nA, flat_of(p, cellsA));
+                               p->nblk, nwg_fast, cellsA, nA, flat_of(p, cellsA), nullptr);
         else if (doA)
             hipLaunchKernelGGL((k_passA<2, 4, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
-                               p->nblk, 0, cellsA, nA, flat_of(p, cellsA));
+                               p->nblk, 0, cellsA, nA, flat_of(p, cellsA), nullptr);
         if (doB && nwg_fast)
             hipLaunchKernelGGL(k_passB_euler_blk, dim3(nwg_fast), blk, 0, ibh_stream, (uint32_t)p->nc, P, (uint32_t)ldp,
                                p->G, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks2, p->htab, p->nblk, nwg_fast);
@@ -822,7 +862,7 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     } else {
         if (doA)
             hipLaunchKernelGGL((k_passA<3, 5, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,
-                               p->nblk, 0, cellsA, nA, flat_of(p, cellsA));
+                               p->nblk, 0, cellsA, nA, flat_of(p, cellsA), nullptr);
         if (doB && gB.x)
             hipLaunchKernelGGL((k_passB_euler<3>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
                                fluid->gamma, cellsB, nB);

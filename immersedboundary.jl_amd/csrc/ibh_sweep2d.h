@@ -134,10 +134,12 @@ __device__ __forceinline__ SweepGat sweep_gather(const SweepPre& P, int delta, b
 }
 static_assert(offsetof(BlockDesc2, type) == 4 && offsetof(BlockDesc2, q) == 84, "sweep_prefetch reads type/q by offset");
 
-// `nb` blocks blk0, blk0 + stride, ... by this wave; the lane-only index arithmetic is shared by all of them
-// and the independent loads of block k+1 are in flight while block k is computed
+// `nb` blocks at positions blk0, blk0 + stride, ... (block indices, or entries of `blist`) by this wave; the
+// lane-only index arithmetic is shared by all of them and the loads of the next blocks are in flight while a
+// block is computed
 __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
-                                          const int32_t* __restrict__ etab, int32_t blk0, int32_t stride, int32_t nb,
+                                          const int32_t* __restrict__ etab, const int32_t* __restrict__ blist,
+                                          int32_t blk0, int32_t stride, int32_t nb,
                                           const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
                                           float* __restrict__ ud, float* lds, int lane) {
     float* fU = lds;
@@ -174,10 +176,11 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
     const float* xC = xd ? fCY : fCX;
 
     // two-stage pipeline: while block k is computed, the gathers of block k+1 and the tables of block k+2 are in flight
-    SweepPre T1 = sweep_prefetch(blocks, htab, etab, blk0, u, C, ldc, lane);
+    auto at = [&](int32_t pos) { return blist ? blist[pos] : pos; };
+    SweepPre T1 = sweep_prefetch(blocks, htab, etab, at(blk0), u, C, ldc, lane);
     SweepGat G1 = sweep_gather(T1, delta, dn != 0, u, C, ldc);
     SweepPre T2 = T1;
-    if (nb > 1) T2 = sweep_prefetch(blocks, htab, etab, blk0 + stride, u, C, ldc, lane);
+    if (nb > 1) T2 = sweep_prefetch(blocks, htab, etab, at(blk0 + stride), u, C, ldc, lane);
     for (int32_t it = 0; it < nb; ++it) {
         const SweepPre P = T1;
         const SweepGat G = G1;
@@ -185,7 +188,7 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
             T1 = T2;
             G1 = sweep_gather(T1, delta, dn != 0, u, C, ldc);
         }
-        if (it + 2 < nb) T2 = sweep_prefetch(blocks, htab, etab, blk0 + (it + 2) * stride, u, C, ldc, lane);
+        if (it + 2 < nb) T2 = sweep_prefetch(blocks, htab, etab, at(blk0 + (it + 2) * stride), u, C, ldc, lane);
         const BlockDesc2& bb = P.bb;
         const float uc = P.uc, cxc = P.cxc, cyc = P.cyc;
         const bool mirror = P.ty == SIDE_MIRROR, isC = P.ty == SIDE_COARSE, isF = P.ty == SIDE_FINE;

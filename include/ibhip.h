@@ -89,7 +89,8 @@ int ibh_partition_destroy(ibh_part* part);
 /* Introspection of the block analysis: info[0]=full blocks, [1]=irregular cells,
  * [2..6] = number of block sides classified SAME, MIRROR, COARSE, FINE, GENERAL,
  * [7] = blocks whose whole sweep is independent of skirt cells (IBH_PHASE_INTERIOR),
- * [8] = blocks eligible for the single-kernel sweep. */
+ * [8] = blocks eligible for the single-kernel sweep, [9] = blocks whose gradients go through the workspace
+ *       in a mixed launch (0 when every block is eligible). */
 int ibh_partition_info(const ibh_part* part, int64_t* info, int n);
 
 /* ---- grid operators on a Partition (ImmersedBoundary.jl:873-1157) ----------
@@ -170,6 +171,7 @@ int ibh_copy_rows(const int32_t* dst_rows, const int32_t* src_rows, int32_t n,
 #define IBH_PHASE_INTERIOR 32 /* only blocks that do not depend on skirt cells (run while the halo exchange is in flight) */
 #define IBH_PHASE_BOUNDARY 64 /* the complement: remaining blocks + face-list cells (run after the exchange) */
 #define IBH_NO_FUSE 128       /* keep the two-kernel form (gradient workspace) even where one kernel could do the sweep */
+#define IBH_SWEEP_ONLY 256     /* measurement: of a mixed launch run only the single-kernel part */
 #define IBH_EXACT 16      /* block fast path with the literal IEEE arithmetic (bit-comparable with the face-list path) */
 int ibh_residual_advection(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags);
 int ibh_residual_euler_hll(ibh_part*, const float* P, int64_t ldp, float* R, int64_t ldr,

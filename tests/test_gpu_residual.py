@@ -165,3 +165,25 @@ def test_single_kernel_sweep(rae_mesh_small, kind):
     ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud, flags=ibamd.IBH_PHASE_INTERIOR)
     ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud, flags=ibamd.IBH_PHASE_BOUNDARY)
     assert np.array_equal(ibamd.to_host(ud), one)
+
+
+def test_mixed_launch_matches_two_kernel_form(rae_domains):
+    """Partitions with skirt blocks: eligible blocks go through the single kernel, the rest through the
+    two-kernel form with the workspace filled only where it is read.  Same results as the pure two-kernel
+    form and as the oracle, on every cell."""
+    dp, do = rae_domains
+    mixed = 0
+    for k in dp.partitions:
+        dpart, opart = ibamd.to_backend(dp.partitions[k], ibamd.hip), do.partitions[k]
+        info = dpart.info
+        if 0 < info["fusable_blocks"] < info["full_blocks"] and 4 * info["fusable_blocks"] >= info["full_blocks"]:
+            mixed += 1
+            assert 0 < info["workspace_blocks"] < info["full_blocks"]
+        u = seeded_field(opart.centers, kind="step")
+        C = np.stack([np.ones_like(u), f32(0.5) + seeded_field(opart.centers, seed=3) * f32(0.1)], axis=1)
+        exp = oracle_advection_residual(opart, u, C)
+        one = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C)))
+        two = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), flags=ibamd.IBH_NO_FUSE))
+        assert rel_inf(one, exp) <= TOL
+        assert rel_inf(one, two) <= 2e-6
+    assert mixed > 0
