@@ -749,7 +749,10 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
         IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
         const int32_t f0 = ph2 ? p->n_fz_int : 0, f1 = ph1 ? p->n_fz_int : p->n_fz;
-        const int32_t g0 = ph2 ? p->n_ng_int : 0, g1 = ph1 ? p->n_ng_int : p->n_ng;
+        // interior phase without blocks of the two-kernel form: nothing reads the workspace before the boundary
+        // phase, so all of pass A is done there and the interior phase is one launch
+        const bool defer = p->n_nf_int == 0;
+        const int32_t g0 = ph2 ? (defer ? 0 : p->n_ng_int) : 0, g1 = ph1 ? (defer ? 0 : p->n_ng_int) : p->n_ng;
         const int32_t r0 = ph2 ? p->n_nf_int : 0, r1 = ph1 ? p->n_nf_int : p->n_nf;
         const int32_t nI = ph1 ? 0 : p->n_irr;
         const int32_t gI = (nI + 64 * WPB - 1) / (64 * WPB);
