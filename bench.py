@@ -88,42 +88,38 @@ def synthetic_fields(centers, seed=12345):
     return u.astype(np.float32), C
 
 
-def cpu_baseline(part, u, C, budget_s=12.0):
-    """Oracle (numpy restatement, array-at-a-time like the Julia broadcasts) timed on this host."""
-    from oracle import domain as od
-    from oracle.accumulator import Accumulator as OAcc
+def cpu_baseline(part, u, C, budget_s=10.0):
+    """The oracle timed on this host: the C restatement (oracle/csrc/residual.c) in both of its forms -- one array
+    pass per reference broadcast like the Julia code ("faithful"), and cell-fused -- each at its best OpenMP thread
+    count from a short scan (the box may give this job fewer CPUs than it shows).  The reported value is the faster."""
+    from oracle import residual_c as rc
+    cp = rc.CPart(part)
 
-    class P:  # oracle-side view of the same partition
-        pass
-    op = P()
-    op.ndims = part.ndims
-    op.spacing, op.centers = part.spacing, part.centers
-    op.face_owners_neighbors = part.face_owners_neighbors
-    op.face_accumulators = {}
-    for k, acc in part.face_accumulators.items():
-        o = object.__new__(OAcc)
-        o.n_output, o.first_index, o.stencils = acc.n_output, True, acc.stencils
-        op.face_accumulators[k] = o
-    f32 = np.float32
-
-    def sweep():
-        ud = np.zeros_like(u)
-        D = od.JST_sensor(op, u)
-        for dim in (1, 2):
-            Cf = od.at_faces(op, np.ascontiguousarray(C[:, dim - 1]), dim)
-            gu = od.cell_gradient(op, u, dim)
-            uL, uR = od.MUSCL(op, u, gu, dim, D=D, high_order=True)
-            ud -= od.green_gauss(op, (uL + uR) * Cf / f32(2) + np.abs(Cf) * (uL - uR) / f32(2), dim)
-        return ud
-    sweep()
+    def rate(fused, threads, reps):
+        cp.residual_advection(u, C, fused=fused, threads=threads)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cp.residual_advection(u, C, fused=fused)
+        return reps / (time.perf_counter() - t0)
+    best = {}
+    for fused in (False, True):
+        cands = [(rate(fused, t, 3), t) for t in sorted({1, 8, 16, 32, 64, rc.max_threads()}) if t <= rc.max_threads()]
+        best[fused] = max(cands)
+    fused = best[True][0] > best[False][0]
+    threads = best[fused][1]
+    cp.residual_advection(u, C, fused=fused, threads=threads)
     n, t0 = 0, time.perf_counter()
     while True:
-        sweep()
+        cp.residual_advection(u, C, fused=fused)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 50:
+        if dt > budget_s or n >= 2000:
             break
-    return u.shape[0] * n / dt / 1e6, n, dt
+    mc = u.shape[0] / 1e6
+    other = best[not fused]
+    return dict(value=mc * n / dt, n=n, secs=dt, threads=threads, form="cell-fused" if fused else "faithful",
+                other_form="faithful" if fused else "cell-fused", other_value=mc * other[0], other_threads=other[1],
+                one_thread=mc * rate(False, 1, 2))
 
 
 def main():
@@ -297,6 +293,28 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = total_cells * args.steps / dt / 1e6
 
+    # --- what this box's memory system delivers (report the fraction against the measured device
+    #     bandwidth as well): 1 GiB device-to-device copy and a triad a = b + s*c over 3 x 1 GiB, HIP events
+    def measured_bandwidth():
+        n = 1 << 28
+        a = torch.empty(n, dtype=torch.float32, device=u.device)
+        b = torch.ones(n, dtype=torch.float32, device=u.device)
+        c = torch.ones(n, dtype=torch.float32, device=u.device)
+        res = {}
+        for name, fn, nbytes in (("copy", lambda: a.copy_(b), 8 * n), ("triad", lambda: torch.add(b, c, alpha=0.5, out=a), 12 * n)):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b, c
+        return res
+    bw = measured_bandwidth() if world == 1 else None
+
     # --- roofline of the dominant kernel (pass B: MUSCL + flux + Green-Gauss), HIP events on the launch stream
     def time_pass(f, reps):
         # `reps` launches of one kernel captured in a graph, timed with events on the launch stream
@@ -357,6 +375,9 @@ def main():
                 "kernel_us": round(tB * 1e6, 3), "passA_us": None if tA is None else round(tA * 1e6, 3),
                 "alg_bytes_per_cell": b_alg, "cells_per_launch": cells_launch,
                 "sweep_frac": round(b_alg * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    if bw:
+        roofline.update(measured_copy_gbs=round(bw["copy"], 1), measured_triad_gbs=round(bw["triad"], 1),
+                        frac_of_measured_triad=round(achieved / bw["triad"], 4))
 
     out = {
         "metric": "Mcells*iters/s residual sweep (%s), %s" % ("Euler HLL-JST-MUSCL" if euler else "advection-JST-MUSCL",
@@ -383,11 +404,14 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler and not is3d:
-        v, n, secs = cpu_baseline(part, u_h, C_h)
-        out["cpu_baseline"] = {"value": round(v, 3), "unit": "Mcells*iters/s", "cores": 1, "kind": "port",
-                               "sample": f"{n} sweeps of the same {u_h.shape[0]}-cell partition in {secs:.1f} s, "
-                                         "numpy oracle (array-at-a-time restatement of the Julia closure), "
-                                         f"host has {os.cpu_count()} cores"}
+        cb = cpu_baseline(part, u_h, C_h)
+        out["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "Mcells*iters/s", "cores": cb["threads"],
+                               "kind": "port",
+                               "sample": f"{cb['n']} sweeps of the same {u_h.shape[0]}-cell partition in {cb['secs']:.1f} s: "
+                                         f"C restatement of the Julia closure (oracle/csrc/residual.c), {cb['form']} form, "
+                                         f"OpenMP on {cb['threads']} threads of a {os.cpu_count()}-core host (best of a scan); "
+                                         f"{cb['other_form']} form {cb['other_value']:.1f} on {cb['other_threads']} threads, "
+                                         f"faithful form on 1 thread {cb['one_thread']:.1f} Mcells*iters/s"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
