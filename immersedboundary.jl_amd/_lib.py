@@ -84,6 +84,17 @@ _SIGS = {
     "ibh_axpy_clamped": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_axpy": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_sumsq": [c_i64, c_vp, c_vp],
+    "ibh_pi_rademacher": [c_i64, C.c_uint64, c_vp],
+    "ibh_pi_perturb": [c_i64, c_vp, c_vp, C.c_float, c_vp],
+    "ibh_pi_fd": [c_i64, c_vp, c_vp, C.c_float, c_vp],
+    "ibh_pi_hutch_accum": [c_i64, c_int, c_vp, c_vp, c_vp, C.c_float, c_vp],
+    "ibh_pi_div_scalar": [c_i64, C.c_float, c_vp],
+    "ibh_pi_invert_blocks": [c_i64, c_int, c_vp],
+    "ibh_pi_apply_blocks": [c_i64, c_int, c_vp, c_vp, c_vp],
+    "ibh_dot": [c_i64, c_vp, c_vp, c_vp],
+    "ibh_maxabs": [c_i64, c_vp, c_vp],
+    "ibh_pi_update": [c_i64, c_vp, C.c_float, c_vp, c_vp, c_vp, c_vp],
+    "ibh_pi_normalize": [c_i64, c_vp, c_vp, C.c_float, c_vp],
 }
 
 EXPORTS = sorted(list(_SIGS) + ["ibh_last_error"])

@@ -228,6 +228,32 @@ int ibh_axpy(int64_t n, float a, const float* x, float* y);
 /* *out (device, double) = sum(x^2) */
 int ibh_sumsq(int64_t n, const float* x, double* out);
 
+/* ---- point-implicit smoother (reference: the orphan file src/point_implicit.jl) ------------------------------
+ * Arrays are dense column-major (n points, nv variables) with leading dimension n, i.e. n*nv contiguous floats;
+ * the block diagonal D is (n, nv, nv) column-major: D[p + n*(k + nv*i)] = d f_k / d x_i at point p (:56-91). */
+/* z[i] = +1 / -1 from a counter-based hash of (seed, i)  (the Rademacher samples of :36-38) */
+int ibh_pi_rademacher(int64_t n, uint64_t seed, float* z);
+/* out = x + v*h  (:30, :112) */
+int ibh_pi_perturb(int64_t n, const float* x, const float* v, float h, float* out);
+/* out = (fxb - fx) / h : the Jacobian-vector product of a Linearization (:110-114) */
+int ibh_pi_fd(int64_t n, const float* fxb, const float* fx, float h, float* out);
+/* s[p,k] += z[p] * (fxb[p,k] - fx[p,k]) / h  (:40) */
+int ibh_pi_hutch_accum(int64_t n, int nv, const float* fxb, const float* fx, const float* z, float h, float* s);
+/* s /= d  (:43) */
+int ibh_pi_div_scalar(int64_t n, float d, float* s);
+/* in place: nv == 1: D = 1/(eps + D) (:124-126); else per-point Moore-Penrose inverse of the nv x nv block
+ * (:127-135; one-sided Jacobi SVD, tolerance eps*nv*sigma_max like LinearAlgebra.pinv).  1 <= nv <= 8. */
+int ibh_pi_invert_blocks(int64_t n, int nv, float* D);
+/* out[p,k] = sum_i v[p,i] * invD[p,k,i]  (:153-161; nv == 1: out = v .* invD :141-146) */
+int ibh_pi_apply_blocks(int64_t n, int nv, const float* invD, const float* v, float* out);
+/* *out (device, double) = sum(a .* b);  *out (device, float) = maximum(abs, a) */
+int ibh_dot(int64_t n, const float* a, const float* b, double* out);
+int ibh_maxabs(int64_t n, const float* a, float* out);
+/* alpha = dots[0] / (dots[1] + eps) read on the device; x += s*alpha; r -= As*alpha  (:229-236, :291-294) */
+int ibh_pi_update(int64_t n, const double* dots, float eps, const float* s, const float* As, float* x, float* r);
+/* s = r / (eps + *maxabs)  (:297-299) */
+int ibh_pi_normalize(int64_t n, const float* r, const float* maxabs, float eps, float* s);
+
 #ifdef __cplusplus
 }
 #endif
