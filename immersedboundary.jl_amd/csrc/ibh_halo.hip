@@ -43,6 +43,92 @@ __global__ void k_flag_wait(uint32_t* __restrict__ counter, const uint32_t* cons
     __threadfence_system();
 }
 
+// ---- the whole exchange in two launches (a step of a strong-scaled run is a handful of ~3 us kernels, so every
+// launch counts): push = pack for ALL peers + signal by the last workgroup to finish; pull = bounded wait on ALL
+// flags + unpack.  Per-peer segments of the concatenated index lists: seg[q] .. seg[q+1].
+#define IBH_MAX_PEERS 16
+struct PushArgs {
+    float* dst[IBH_MAX_PEERS];        // peer receive buffer (parity and my offset applied)
+    uint32_t* flag[IBH_MAX_PEERS];    // my slot in the peer's flag array
+    int32_t seg[IBH_MAX_PEERS + 1];
+    int32_t n;
+};
+struct PullArgs {
+    const uint32_t* flag[IBH_MAX_PEERS];  // local flag slot of each source peer
+    int32_t seg[IBH_MAX_PEERS + 1];
+    int32_t n;
+};
+
+__device__ __forceinline__ int seg_of(const int32_t* seg, int n, int32_t t) {
+    int q = 0;
+    while (q + 1 < n && t >= seg[q + 1]) ++q;
+    return q;
+}
+
+// state: [0] signal sequence, [1] wait sequence, [2] status, [3] push workgroups done, [4] pull workgroups done
+__global__ void k_halo_push(const float* __restrict__ f, int nv, int64_t ld, const int32_t* __restrict__ send_all,
+                            PushArgs P, uint32_t* __restrict__ state) {
+    const int32_t total = P.seg[P.n];
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int q = seg_of(P.seg, P.n, t);
+        const int32_t i = t - P.seg[q], nq = P.seg[q + 1] - P.seg[q];
+        const int32_t c = send_all[t];
+        for (int v = 0; v < nv; ++v) P.dst[q][i + (int64_t)v * nq] = f[c + (int64_t)v * ld];
+    }
+    __threadfence_system();  // this workgroup's stores are visible system-wide before it counts as done
+    __shared__ uint32_t last, seq;
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&state[3], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) {
+        seq = state[0] + 1u;
+        state[0] = seq;
+        state[3] = 0u;
+    }
+    __syncthreads();
+    __threadfence_system();
+    if ((int)threadIdx.x < P.n) __hip_atomic_store(P.flag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_halo_pull(float* __restrict__ f, int nv, int64_t ld, const int32_t* __restrict__ recv_all,
+                            const float* __restrict__ src, PullArgs R, uint32_t* __restrict__ state,
+                            uint32_t max_spins) {
+    __shared__ uint32_t exp, last;
+    if (threadIdx.x == 0) exp = state[1] + 1u;  // advanced only by the last workgroup to finish (below)
+    __syncthreads();
+    if ((int)threadIdx.x < R.n) {
+        const uint32_t* s = R.flag[threadIdx.x];
+        uint32_t spins = 0;
+        // relaxed system-scope polls (bypass the caches), bounded: every wave reaches the exit
+        while (__hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < exp) {
+            if (++spins >= max_spins) {
+                atomicOr(&state[2], 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();  // acquire: the peers' data stores precede their flag stores
+    const int32_t total = R.seg[R.n];
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int q = seg_of(R.seg, R.n, t);
+        const int32_t i = t - R.seg[q], nq = R.seg[q + 1] - R.seg[q];
+        const float* sq = src + (int64_t)R.seg[q] * nv;
+        const int32_t c = recv_all[t];
+        for (int v = 0; v < nv; ++v)
+            f[c + (int64_t)v * ld] = __builtin_nontemporal_load(sq + i + (int64_t)v * nq);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&state[4], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        state[1] = exp;
+        state[4] = 0u;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -94,6 +180,49 @@ int ibh_flag_signal(uint32_t* counter, uint32_t* const* slots, int n) {
 int ibh_flag_wait(uint32_t* counter, const uint32_t* const* slots, int n, uint32_t max_spins, uint32_t* status) {
     IBH_REQUIRE(counter && slots && status && n >= 0 && n <= 64, "ibh_flag_wait: bad argument");
     hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, ibh_stream, counter, slots, n, max_spins, status);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_halo_push(const float* f, int nv, int64_t ld, const int32_t* send_all, int n_peers, const int32_t* seg,
+                  float* const* dst, uint32_t* const* flags, uint32_t* state) {
+    IBH_REQUIRE(n_peers >= 0 && n_peers <= IBH_MAX_PEERS, "ibh_halo_push: at most 16 peers");
+    if (n_peers == 0) return 0;
+    IBH_REQUIRE(f && send_all && seg && dst && flags && state && nv >= 1, "ibh_halo_push: bad argument");
+    PushArgs P;
+    memset(&P, 0, sizeof(P));
+    P.n = n_peers;
+    for (int q = 0; q < n_peers; ++q) {
+        P.dst[q] = dst[q];
+        P.flag[q] = flags[q];
+        P.seg[q] = seg[q];
+        IBH_REQUIRE(seg[q + 1] >= seg[q], "ibh_halo_push: segments must ascend");
+    }
+    P.seg[n_peers] = seg[n_peers];
+    int g = (seg[n_peers] + 255) / 256;
+    g = g < 1 ? 1 : g > 256 ? 256 : g;
+    hipLaunchKernelGGL(k_halo_push, dim3(g), dim3(256), 0, ibh_stream, f, nv, ld, send_all, P, state);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_halo_pull(float* f, int nv, int64_t ld, const int32_t* recv_all, const float* src, int n_peers,
+                  const int32_t* seg, const uint32_t* const* flags, uint32_t* state, uint32_t max_spins) {
+    IBH_REQUIRE(n_peers >= 0 && n_peers <= IBH_MAX_PEERS, "ibh_halo_pull: at most 16 peers");
+    if (n_peers == 0) return 0;
+    IBH_REQUIRE(f && recv_all && src && seg && flags && state && nv >= 1, "ibh_halo_pull: bad argument");
+    PullArgs R;
+    memset(&R, 0, sizeof(R));
+    R.n = n_peers;
+    for (int q = 0; q < n_peers; ++q) {
+        R.flag[q] = flags[q];
+        R.seg[q] = seg[q];
+        IBH_REQUIRE(seg[q + 1] >= seg[q], "ibh_halo_pull: segments must ascend");
+    }
+    R.seg[n_peers] = seg[n_peers];
+    int g = (seg[n_peers] + 255) / 256;
+    g = g < 1 ? 1 : g > 64 ? 64 : g;  // every workgroup polls the flags: keep them few
+    hipLaunchKernelGGL(k_halo_pull, dim3(g), dim3(256), 0, ibh_stream, f, nv, ld, recv_all, src, R, state, max_spins);
     IBH_LAUNCH_CHECK();
     return 0;
 }

@@ -186,9 +186,10 @@ class XgmiHalo:
     """Direct peer-write halo exchange over xGMI (same start/finish/exchange interface as HaloExchange).
 
     Every rank owns a fine-grained receive buffer (two parities) and a flag word per peer, exported through
-    HIP IPC and mapped by the peers.  ``start``: one pack kernel per peer stores the skirt values straight
-    into the peer's buffer, then a signal kernel bumps the sequence number in the peer's flag word.
-    ``finish``: a bounded-spin wait kernel on the local flag words, then one unpack kernel.  No host
+    HIP IPC and mapped by the peers.  ``start`` is ONE kernel (``ibh_halo_push``): it stores the skirt values of
+    all peers straight into their buffers and its last workgroup to finish bumps the sequence number in the
+    peers' flag words.  ``finish`` is ONE kernel (``ibh_halo_pull``): bounded-spin wait on the local flag words,
+    then the unpack.  (A strong-scaled step is a handful of ~3 us launches, so every launch counts.)  No host
     synchronisation and no library call besides kernel launches, so a whole sweep (exchange included) can be
     captured in a HIP graph.  Double buffering makes the protocol race-free: a rank can only overwrite
     parity p of a peer after that peer signalled step n+1, which it does after unpacking step n.
@@ -251,49 +252,49 @@ class XgmiHalo:
         self.send_idx = {q: torch.from_numpy(plan.send[q]).to(self.device) for q in self.peers_send}
         self.recv_idx = {q: torch.from_numpy(plan.recv[q]).to(self.device) for q in self.peers_recv}
         self.recv_all = torch.cat([self.recv_idx[q] for q in self.peers_recv]) if self.peers_recv else None
-        self.sig_slots = torch.tensor([self.remote[q][3] for q in self.peers_send] or [0], dtype=torch.int64,
-                                      device=self.device)
-        self.wait_slots = torch.tensor([self._flags.value + 4 * (q - 1) for q in self.peers_recv] or [0],
-                                       dtype=torch.int64, device=self.device)
-        self.state = torch.zeros(4, dtype=torch.int32, device=self.device)  # signal counter, wait counter, status
+        self.send_all = torch.cat([self.send_idx[q] for q in self.peers_send]) if self.peers_send else None
+        self.state = torch.zeros(8, dtype=torch.int32, device=self.device)  # signal seq, wait seq, status, done x2
+        # host-side launch tables of the two-kernel exchange (ibh_halo_push / ibh_halo_pull)
+        ns, nr = len(self.peers_send), len(self.peers_recv)
+        if max(ns, nr) > 16:
+            raise RuntimeError("XgmiHalo: more than 16 peers")
+        sseg = np.concatenate([[0], np.cumsum([plan.send[q].size for q in self.peers_send])]).astype(np.int32)
+        rseg = np.concatenate([[0], np.cumsum([plan.recv[q].size for q in self.peers_recv])]).astype(np.int32)
+        self._sseg = (C.c_int32 * (ns + 1))(*sseg.tolist())
+        self._rseg = (C.c_int32 * (nr + 1))(*rseg.tolist())
+        self._dst = []
+        for par in (0, 1):
+            self._dst.append((C.c_void_p * max(ns, 1))(*[self.remote[q][0] + 4 * (par * self.remote[q][1] + self.remote[q][2])
+                                                        for q in self.peers_send]))
+        self._sflags = (C.c_void_p * max(ns, 1))(*[self.remote[q][3] for q in self.peers_send])
+        self._rflags = (C.c_void_p * max(nr, 1))(*[self._flags.value + 4 * (q - 1) for q in self.peers_recv])
         self.step = 0
         torch.cuda.synchronize()
         dist.barrier(group=group)
 
     def start(self, field):
-        B, nv = self.B, self.nv
+        B, C, nv = self.B, self.C, self.nv
         f, fnv, ld = B._field(field)
         if fnv != nv:
             raise ValueError(f"XgmiHalo was built for nv={nv}")
         par = self.step & 1
         self.step += 1
         B._stream()
-        for q in self.peers_send:
-            base, nq, off, _ = self.remote[q]
-            idx = self.send_idx[q]
-            B.call("ibh_gather_rows", B._ptr(idx), idx.numel(), B._ptr(f), nv, ld,
-                   B.c_vp(base + 4 * (par * nq + off)), idx.numel())
         if self.peers_send:
-            B.call("ibh_flag_signal", B.c_vp(self.state.data_ptr()), B._ptr(self.sig_slots), len(self.peers_send))
+            B.call("ibh_halo_push", B._ptr(f), nv, ld, B._ptr(self.send_all), len(self.peers_send),
+                   C.cast(self._sseg, B.c_vp), C.cast(self._dst[par], B.c_vp), C.cast(self._sflags, B.c_vp),
+                   B.c_vp(self.state.data_ptr()))
         return (f, ld, par)
 
     def finish(self, handle):
-        B, nv = self.B, self.nv
+        B, C, nv = self.B, self.C, self.nv
         f, ld, par = handle
         if not self.peers_recv:
             return
         B._stream()
-        B.call("ibh_flag_wait", B.c_vp(self.state.data_ptr() + 4), B._ptr(self.wait_slots), len(self.peers_recv),
-               self.max_spins, B.c_vp(self.state.data_ptr() + 8))
-        base = self._recv.value + 4 * par * self.n_recv_f
-        if nv == 1:
-            B.call("ibh_scatter_rows", B._ptr(self.recv_all), self.recv_all.numel(), B.c_vp(base), 1,
-                   self.recv_all.numel(), B._ptr(f), ld)
-        else:
-            for q in self.peers_recv:
-                idx = self.recv_idx[q]
-                B.call("ibh_scatter_rows", B._ptr(idx), idx.numel(), B.c_vp(base + 4 * self.recv_off[q]), nv,
-                       idx.numel(), B._ptr(f), ld)
+        B.call("ibh_halo_pull", B._ptr(f), nv, ld, B._ptr(self.recv_all), B.c_vp(self._recv.value + 4 * par * self.n_recv_f),
+               len(self.peers_recv), C.cast(self._rseg, B.c_vp), C.cast(self._rflags, B.c_vp),
+               B.c_vp(self.state.data_ptr()), self.max_spins)
 
     def exchange(self, field):
         self.finish(self.start(field))

@@ -219,6 +219,16 @@ int ibh_ipc_close(void* dptr);
 int ibh_flag_signal(uint32_t* counter, uint32_t* const* slots, int n);
 /* exp = ++(*counter); wait until *slots[q] >= exp for every q < n, at most max_spins polls each. */
 int ibh_flag_wait(uint32_t* counter, const uint32_t* const* slots, int n, uint32_t max_spins, uint32_t* status);
+/* The whole exchange in two launches.  state = 5 device words {signal seq, wait seq, status, 0, 0}.
+ * push: for every peer q the rows send_all[seg[q]..seg[q+1]) of f go to dst[q] as (n_q, nv) column-major, then the
+ *   last workgroup to finish stores ++signal seq into flags[q] of every peer (system-scope release).
+ * pull: waits (bounded by max_spins polls, time-out sets status bit 0) until every flags[q] >= wait seq + 1, then
+ *   scatters src (the peers' blocks back to back, block q = (n_q, nv) column-major) to the rows recv_all[..] of f.
+ * seg / dst / flags are host arrays, copied into the launch.  At most 16 peers. */
+int ibh_halo_push(const float* f, int nv, int64_t ld, const int32_t* send_all, int n_peers, const int32_t* seg,
+                  float* const* dst, uint32_t* const* flags, uint32_t* state);
+int ibh_halo_pull(float* f, int nv, int64_t ld, const int32_t* recv_all, const float* src, int n_peers,
+                  const int32_t* seg, const uint32_t* const* flags, uint32_t* state, uint32_t max_spins);
 
 /* ---- small device-resident vector ops for the FAS loop (solver.jl:79-88) ---------- */
 /* q += clamp(omega,0,1) * r ; omega scalar */
