@@ -222,6 +222,299 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
     if (!L.general) stg(ud, c, res);
 }
 
+// ------------------------------------------------------------------------------------------
+// Euler sweep in 3-D (P = [p T u v w], cfd.jl:106-151 / :459-508), the block form of the R2 residual.
+// pass A: gradients of the NV primitives along x, y, z + JST sensor of the pressure.
+//   G layout as the face-list kernels: grad of var v along dim d at G[(d*NV + v)*nc + c], sensor at G[3*NV*nc + c].
+//   LDS: NV x 896 floats.
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void passA_nv(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                         const int32_t* __restrict__ ftab, int32_t blk, uint32_t nc,
+                                         const float* __restrict__ P, uint32_t ldp, float* __restrict__ G, float* lds,
+                                         int tid) {
+    const BlockDesc3 bb = blocks[blk];
+    const uint32_t c = (uint32_t)bb.base + tid;
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
+    float self[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        self[v] = ldg(P + (size_t)v * ldp, c);
+        const float hv = ldg(P + (size_t)v * ldp, hidx);
+        lds[v * 896 + tid] = self[v];
+        if (tid < 384) lds[v * 896 + 512 + tid] = hv;
+    }
+    const Lane3 L = lane_info(bb, tid);
+    __syncthreads();
+    const int tt[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
+    float D = 1e-7f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float rh = bb.rh[d];
+        // the three extra fine cells behind a boundary cell of a FINE side (workgroup-uniform branch)
+        uint32_t fc[2][3];
+        bool fine[2];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int s = 2 * d + side;
+            fine[side] = false;
+            if (bb.type[s] == SIDE_FINE) {
+                if (L.edge[s]) {
+                    const int32_t* ft = ftab + (((size_t)bb.fine * 6 + s) * 64 + tt[d]) * 3;
+                    fc[side][0] = (uint32_t)ft[0];
+                    fc[side][1] = (uint32_t)ft[1];
+                    fc[side][2] = (uint32_t)ft[2];
+                    fine[side] = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float uc = self[v];
+            float vm[2], am[2];
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int s = 2 * d + side;
+                const float v0 = lds[v * 896 + L.nidx[s]];
+                vm[side] = v0;
+                am[side] = fabsf(v0 - uc);
+                if (bb.type[s] == SIDE_FINE) {
+                    if (fine[side]) {
+                        const float* Pv = P + (size_t)v * ldp;
+                        const float v1 = ldg(Pv, fc[side][0]), v2 = ldg(Pv, fc[side][1]), v3 = ldg(Pv, fc[side][2]);
+                        vm[side] = 0.25f * (v0 + v1 + v2 + v3);
+                        am[side] = 0.25f * (fabsf(v0 - uc) + fabsf(v1 - uc) + fabsf(v2 - uc) + fabsf(v3 - uc));
+                    }
+                }
+            }
+            const float fr = uc + L.q[2 * d + 1] * (vm[1] - uc);
+            const float fl = uc + L.q[2 * d] * (vm[0] - uc);
+            if (!L.general) stg(G + (size_t)(d * NV + v) * nc, c, (fr - fl) * rh);
+            if (v == 0) {
+                const float gg = ((vm[1] - uc) - (uc - vm[0])) * rh;
+                const float ugg = (am[1] + am[0]) * rh;
+                D = fmaxf(D, (1e-7f + fabsf(gg)) * __builtin_amdgcn_rcpf(1e-7f + ugg));
+            }
+        }
+    }
+    if (!L.general) stg(G + (size_t)(3 * NV) * nc, c, D);
+}
+
+struct Gas3 {
+    float R, gamma;
+};
+
+__device__ __forceinline__ void euler_side3(const float* P, int dn, const Gas3& gas, float* Q, float* F, float& un,
+                                            float& a) {
+    const float p = P[0];
+    const float T = fmaxf(P[1], 10.0f);
+    const float k = 0.5f * (P[2] * P[2] + P[3] * P[3] + P[4] * P[4]);
+    const float rho = p * __builtin_amdgcn_rcpf(gas.R * T);
+    const float E = rho * (gas.R / (gas.gamma - 1.0f) * T + k);
+    Q[0] = rho;
+    Q[1] = E;
+    Q[2] = rho * P[2];
+    Q[3] = rho * P[3];
+    Q[4] = rho * P[4];
+    un = dn == 0 ? P[2] : dn == 1 ? P[3] : P[4];
+    a = __builtin_amdgcn_sqrtf(gas.gamma * gas.R * T);
+    F[0] = Q[0] * un;
+    F[1] = (Q[1] + p) * un;
+    F[2] = Q[2] * un + (dn == 0 ? p : 0.0f);
+    F[3] = Q[3] * un + (dn == 1 ? p : 0.0f);
+    F[4] = Q[4] * un + (dn == 2 ? p : 0.0f);
+}
+
+// a = owner (towards -), b = neighbour; ga / gb the gradients of the 5 primitives along the face normal
+__device__ __forceinline__ void euler_flux3(const float* Pa, const float* Pb, const float* ga, const float* gb, float Da,
+                                            float Db, float dA, float dB, float inv, int dn, const Gas3& gas, float* F) {
+    float PL[5], PR[5];
+    const float Df = fmaxf(fmaxf(Da, Db), 1e-7f);
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        const float guf = (Pb[v] - Pa[v]) * inv;
+        const float gu = (2.0f * ga[v] - guf) * dA;
+        const float Du = (2.0f * gb[v] - guf) * dB;
+        const float s = blk2::minmod(Du, gu);
+        const float l = Pa[v] + s, r = Pb[v] - s;
+        const float uf = (Pa[v] * dB + Pb[v] * dA) * inv + (ga[v] * dA - gb[v] * dB) * 0.125f;
+        PL[v] = uf + Df * (l - uf);
+        PR[v] = uf + Df * (r - uf);
+    }
+    float QL[5], FL[5], QR[5], FR[5], uL, aL, uR, aR;
+    euler_side3(PL, dn, gas, QL, FL, uL, aL);
+    euler_side3(PR, dn, gas, QR, FR, uR, aR);
+    const float SR = fminf(uR - aR, 0.0f);
+    const float SL = fmaxf(uL + aL, 0.0f);
+    const float rs = __builtin_amdgcn_rcpf(SL - SR);
+#pragma unroll
+    for (int v = 0; v < 5; ++v) F[v] = (SL * FL[v] - SR * FR[v] + SR * SL * (QR[v] - QL[v])) * rs;
+}
+
+// pass B, Euler.  LDS (floats): fP 5x896 | fD 896 | 2 x (tG 5x512 | hG 5x128) | ex 5x192 | FF 5x512
+//   fP, fD: [tile | halo of all six sides]; tG / hG: gradients along ONE dim (tile / halo of its two sides), double
+//   buffered: the loads of the next dim are issued before the barrier that ends the current one.
+#define BLK3_EULER_LDS (5 * 896 + 896 + 2 * (5 * 512 + 5 * 128) + 5 * 192 + 5 * 512)
+
+__device__ __forceinline__ void passB_euler(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                            const int32_t* __restrict__ ftab, int32_t blk, uint32_t nc,
+                                            const float* __restrict__ P, uint32_t ldp, const float* __restrict__ G,
+                                            float* __restrict__ Rr, uint32_t ldr, Gas3 gas, float* lds, int tid) {
+    const BlockDesc3 bb = blocks[blk];
+    const uint32_t c = (uint32_t)bb.base + tid;
+    float* fP = lds;                 // [5][896]
+    float* fD = lds + 5 * 896;       // [896]
+    float* gbuf = fD + 896;          // 2 x ([5][512] tile | [5][128] halo)
+    float* ex = gbuf + 2 * 3200;     // [3][5][64]
+    float* FF = ex + 5 * 192;        // [5][512]
+    const float* Gs = G + (size_t)15 * nc;
+    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
+    float Pc[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) Pc[v] = ldg(P + (size_t)v * ldp, c);
+    const float Dc = ldg(Gs, c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        const float hv = ldg(P + (size_t)v * ldp, hidx);
+        fP[v * 896 + tid] = Pc[v];
+        if (tid < 384) fP[v * 896 + 512 + tid] = hv;
+    }
+    {
+        const float hD = ldg(Gs, hidx);
+        fD[tid] = Dc;
+        if (tid < 384) fD[512 + tid] = hD;
+    }
+    const Lane3 L = lane_info(bb, tid);
+    float dBs[6], invs[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        dBs[s] = 0.5f * bb.h[s >> 1] * bb.rt[s];
+        invs[s] = 2.0f * bb.rh[s >> 1] * bb.q[s];
+    }
+    const int tt[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
+    __syncthreads();
+    // ---- the 3 x 64 low-side block faces (halo cell = owner) by the first three wavefronts, gradients of the
+    //      two cells straight from the workspace
+    if (tid < 192) {
+        const int dn = tid >> 6, t = tid & 63;  // wave-uniform dn
+        const int t1 = t & 7, t2 = t >> 3;
+        const int pos = dn == 0 ? 8 * t1 + 64 * t2 : dn == 1 ? t1 + 64 * t2 : t;
+        const int slot = 512 + dn * 128 + t;  // side 2*dn
+        const uint32_t ch = (uint32_t)htab[(size_t)blk * 384 + dn * 128 + t], cp = (uint32_t)bb.base + pos;
+        const float hd = 0.5f * (dn == 0 ? bb.h[0] : dn == 1 ? bb.h[1] : bb.h[2]);
+        const float dB = dn == 0 ? dBs[0] : dn == 1 ? dBs[2] : dBs[4];
+        const float inv = dn == 0 ? invs[0] : dn == 1 ? invs[2] : invs[4];
+        const int tyl = dn == 0 ? bb.type[0] : dn == 1 ? bb.type[2] : bb.type[4];
+        float Pa[5], Pb[5], ga[5], gb[5], X[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            Pa[v] = fP[v * 896 + slot];
+            Pb[v] = fP[v * 896 + pos];
+            ga[v] = ldg(G + (size_t)(dn * 5 + v) * nc, ch);
+            gb[v] = ldg(G + (size_t)(dn * 5 + v) * nc, cp);
+        }
+        euler_flux3(Pa, Pb, ga, gb, fD[slot], fD[pos], dB, hd, inv, dn, gas, X);
+        if (tyl == SIDE_FINE) {  // wave-uniform: three more fine owners behind this face
+            const int32_t* ft = ftab + (((size_t)bb.fine * 6 + 2 * dn) * 64 + t) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t cl = (uint32_t)ft[k];
+                float Y[5];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    Pa[v] = ldg(P + (size_t)v * ldp, cl);
+                    ga[v] = ldg(G + (size_t)(dn * 5 + v) * nc, cl);
+                }
+                euler_flux3(Pa, Pb, ga, gb, ldg(Gs, cl), fD[pos], dB, hd, inv, dn, gas, Y);
+#pragma unroll
+                for (int v = 0; v < 5; ++v) X[v] += Y[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 5; ++v) X[v] *= 0.25f;
+        }
+#pragma unroll
+        for (int v = 0; v < 5; ++v) ex[(dn * 5 + v) * 64 + t] = X[v];
+    }
+    float res[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int offm[3] = {1, 8, 64};
+    // gradients along dim 0 into buffer 0: own cells, and the halo cells of sides 2d, 2d+1 (slots 128d .. 128d+127)
+    float gc[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        gc[v] = ldg(G + (size_t)v * nc, c);
+        gbuf[v * 512 + tid] = gc[v];
+        if ((tid >> 7) == 0) gbuf[2560 + v * 128 + (tid & 127)] = ldg(G + (size_t)v * nc, hidx);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float* tG = gbuf + (d & 1) * 3200;
+        const float* hG = tG + 2560;
+        __syncthreads();  // the staged gradients (and, first time, fP / fD / ex) are visible
+        const int s = 2 * d + 1;
+        const bool e = L.edge[s];
+        const int ni = L.nidx[s];
+        const float hd = 0.5f * bb.h[d];
+        float Pb[5], gb[5], F[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            Pb[v] = fP[v * 896 + ni];
+            gb[v] = e ? hG[v * 128 + 64 + tt[d]] : tG[v * 512 + ni];
+        }
+        euler_flux3(Pc, Pb, gc, gb, Dc, fD[ni], hd, e ? dBs[s] : hd, e ? invs[s] : bb.rh[d], d, gas, F);
+        if (bb.type[s] == SIDE_FINE) {  // workgroup-uniform: 3 more sub-faces, straight from global memory
+            if (e) {
+                const int32_t* ft = ftab + (((size_t)bb.fine * 6 + s) * 64 + tt[d]) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t cl = (uint32_t)ft[k];
+                    float Y[5];
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) {
+                        Pb[v] = ldg(P + (size_t)v * ldp, cl);
+                        gb[v] = ldg(G + (size_t)(d * 5 + v) * nc, cl);
+                    }
+                    euler_flux3(Pc, Pb, gc, gb, Dc, ldg(Gs, cl), hd, dBs[s], invs[s], d, gas, Y);
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) F[v] += Y[v];
+                }
+#pragma unroll
+                for (int v = 0; v < 5; ++v) F[v] *= 0.25f;
+            }
+        }
+        // the next dim's gradients are requested now and land during the barrier and the low-flux phase
+        float gn[5], hn[5];
+        if (d < 2) {
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                gn[v] = ldg(G + (size_t)((d + 1) * 5 + v) * nc, c);
+                hn[v] = (tid >> 7) == d + 1 ? ldg(G + (size_t)((d + 1) * 5 + v) * nc, hidx) : 0.0f;  // wave-uniform
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 5; ++v) FF[v * 512 + tid] = F[v];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const float Flow = L.edge[2 * d] ? ex[(d * 5 + v) * 64 + tt[d]] : FF[v * 512 + tid - offm[d]];
+            res[v] = res[v] - (F[v] - Flow) * bb.rh[d];
+        }
+        if (d < 2) {  // into the other buffer: last read before the barrier above, one dim ago
+            float* tN = gbuf + ((d + 1) & 1) * 3200;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                gc[v] = gn[v];
+                tN[v * 512 + tid] = gn[v];
+                if ((tid >> 7) == d + 1) tN[2560 + v * 128 + (tid & 127)] = hn[v];
+            }
+        }
+    }
+    if (!L.general) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) stg(Rr + (size_t)v * ldr, c, res[v]);
+    }
+}
+
 #pragma clang fp contract(off)
 
 }  // namespace blk3

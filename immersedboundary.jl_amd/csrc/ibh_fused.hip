@@ -631,6 +631,36 @@ __global__ __launch_bounds__(512) void k_passB3_adv_blk(PartView p, const float*
     }
 }
 
+// 3-D Euler block kernels (5 primitives): same launch layout as the scalar 3-D kernels
+__global__ __launch_bounds__(512) void k_passA3e_blk(PartView p, const float* __restrict__ P, int64_t ldp,
+                                                     float* __restrict__ G, const BlockDesc3* __restrict__ blocks,
+                                                     const int32_t* __restrict__ htab,
+                                                     const int32_t* __restrict__ ftab, int32_t nblk,
+                                                     const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
+    __shared__ float lds[5 * 896];
+    const int32_t gI = (ncells + 511) / 512;
+    if ((int32_t)blockIdx.x >= gI) {
+        const int32_t blk = xcd_remap(blockIdx.x - gI, nblk);
+        blk3::passA_nv<5>(blocks, htab, ftab, blk, (uint32_t)p.nc, P, (uint32_t)ldp, G, lds, threadIdx.x);
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ncells) {
+        if (flat.rec) passA_flat<3, 5>(p, flat, (int32_t)t, cells[t], P, ldp, G);
+        else passA_cell<3, 5>(p, P, ldp, G, cells[t]);
+    }
+}
+
+__global__ __launch_bounds__(512) void k_passB3e_blk(uint32_t nc, const float* __restrict__ P, uint32_t ldp,
+                                                     const float* __restrict__ G, float* __restrict__ R, uint32_t ldr,
+                                                     float Rgas, float gamma, const BlockDesc3* __restrict__ blocks,
+                                                     const int32_t* __restrict__ htab,
+                                                     const int32_t* __restrict__ ftab, int32_t nblk) {
+    __shared__ float lds[BLK3_EULER_LDS];
+    const int32_t blk = xcd_remap(blockIdx.x, nblk);
+    blk3::passB_euler(blocks, htab, ftab, blk, nc, P, ldp, G, R, ldr, blk3::Gas3{Rgas, gamma}, lds, threadIdx.x);
+}
+
 // Euler pass B: the block body and the face-list body are separate kernels (the Float64 flux combine of
 // the literal face-list body needs ~120 VGPRs and would halve the occupancy of the block body).
 __global__ __launch_bounds__(64 * WPB) void k_passB_euler_blk(uint32_t nc, const float* __restrict__ P, uint32_t ldp,
@@ -862,6 +892,20 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
         if (doB && gB.x)
             hipLaunchKernelGGL((k_passB_euler<2>), gB, blk, 0, ibh_stream, v, P, ldp, p->G, R, ldr, fluid->R,
                                fluid->gamma, cellsB, nB);
+    } else if (p->bs == 8 && p->blocks3 && p->nblk > 0 && !(flags & (IBH_FORCE_GENERAL | IBH_EXACT))) {
+        // 3-D block path: block kernels + the face-list kernels over the cells the analysis left out
+        const int32_t nI = p->n_irr;
+        const int32_t gI = (nI + 511) / 512;
+        if (!(flags & IBH_PASS_B_ONLY))
+            hipLaunchKernelGGL(k_passA3e_blk, dim3(p->nblk + gI), dim3(512), 0, ibh_stream, v, P, ldp, p->G, p->blocks3,
+                               p->htab3, p->ftab3, p->nblk, p->irr_cells, nI, flat_of(p, p->irr_cells));
+        if (!(flags & IBH_PASS_A_ONLY)) {
+            hipLaunchKernelGGL(k_passB3e_blk, dim3(p->nblk), dim3(512), 0, ibh_stream, (uint32_t)p->nc, P, (uint32_t)ldp,
+                               p->G, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks3, p->htab3, p->ftab3, p->nblk);
+            if (nI)
+                hipLaunchKernelGGL((k_passB_euler<3>), dim3((nI + 64 * WPB - 1) / (64 * WPB)), blk, 0, ibh_stream, v, P,
+                                   ldp, p->G, R, ldr, fluid->R, fluid->gamma, p->irr_cells, nI);
+        }
     } else {
         if (doA)
             hipLaunchKernelGGL((k_passA<3, 5, true>), gA, blk, 0, ibh_stream, v, P, ldp, p->G, p->blocks2, p->htab,

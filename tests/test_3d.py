@@ -149,8 +149,26 @@ def test_3d_block_path(octree8_mesh, nparts):
         fast = ibamd.to_host(ibamd.residual_advection(dpart, ud_, Cd))
         gen = ibamd.to_host(ibamd.residual_advection(dpart, ud_, Cd, flags=ibamd.IBH_FORCE_GENERAL))
         assert rel_inf(fast, gen) <= 1e-5
+        # Euler sweep (5 primitives): block path vs face-list path (Float64 HLL combine there), and vs the oracle
+        from oracle import cfd as ocfd
+        P = np.stack([f32(1e5) * (1 + f32(0.05) * rng.uniform(-1, 1, nc)), f32(288.15) * (1 + f32(0.05) * rng.uniform(-1, 1, nc)),
+                      f32(100.0) * (1 + f32(0.1) * rng.uniform(-1, 1, nc)), f32(60.0) * (1 + f32(0.1) * rng.uniform(-1, 1, nc)),
+                      f32(-40.0) * (1 + f32(0.1) * rng.uniform(-1, 1, nc))], axis=1).astype(f32)
+        efast = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P)))
+        egen = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=ibamd.IBH_FORCE_GENERAL))
+        for v in range(5):
+            assert rel_inf(efast[:, v], egen[:, v]) <= 1e-5, v
         if nparts == 1:
             op = _oracle_view(part)
+            fluid = ocfd.Fluid()
+            R = np.zeros_like(P)
+            Dp = od.JST_sensor(op, np.ascontiguousarray(P[:, 0]))
+            for dim in (1, 2, 3):
+                gP = od.cell_gradient(op, P, dim)
+                PL, PR = od.MUSCL(op, P, gP, dim, D=Dp, high_order=True)
+                R -= od.green_gauss(op, ocfd.inviscid_fluxes(fluid, PL, PR, dim), dim)
+            for v in range(5):
+                assert rel_inf(efast[:, v], R[:, v]) <= 1e-5, v
             exp = np.zeros(nc, f32)
             D = od.JST_sensor(op, u)
             for dim in (1, 2, 3):
