@@ -196,18 +196,73 @@ function residual_advection!(ud::HipArray, part::HipPartition, u::HipArray, C::H
     ud
 end
 
+# layout of `ibh_fluid` (include/ibhip.h): R, gamma, mu_ref, Tref, S, nk, k[4]
 struct IbhFluid
     R::Float32
     γ::Float32
+    μref::Float32
+    Tref::Float32
+    S::Float32
+    nk::Int32
+    k::NTuple{4, Float32}
 end
+IbhFluid(fluid) = IbhFluid(fluid.R, fluid.γ, fluid.μref, fluid.Tref, fluid.S, Int32(min(length(fluid.k), 4)),
+    ntuple(i -> i <= length(fluid.k) ? Float32(fluid.k[i]) : 0f0, 4))
 
 "`R .= -Σ_d green_gauss(inviscid_fluxes(MUSCL(P)))` with the pressure JST sensor (CFD.inviscid_fluxes, cfd.jl:459)."
 function residual_euler_hll!(R::HipArray, part::HipPartition, P::HipArray, fluid; flags::Integer = 0)
-    f = Ref(IbhFluid(fluid.R, fluid.γ))
+    f = Ref(IbhFluid(fluid))
     check(ccall((:ibh_residual_euler_hll, lib), Cint,
         (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{IbhFluid}, Cint),
         part.handle, P.ptr, ld(P), R.ptr, ld(R), f, flags))
     R
+end
+
+# flags of the fused sweeps (include/ibhip.h)
+const FORCE_GENERAL, IMAGE_ONLY, PASS_A_ONLY, PASS_B_ONLY, EXACT = 1, 2, 4, 8, 16
+const PHASE_INTERIOR, PHASE_BOUNDARY, NO_FUSE = 32, 64, 128
+
+# ---------------------------------------------------------------------------------------------------
+# point-implicit smoother: the device kernels behind src/point_implicit.jl (hutchinson_trick :17-91,
+# _inverse_blocks! :124-135, PIPreconditioner :141-161, proj_along / solve :221-329).  A maintainer adds
+# methods of those functions for HipArray that call these; the Python mirror of this repo
+# (immersedboundary.jl_amd/point_implicit.py) shows the composition one to one.
+# ---------------------------------------------------------------------------------------------------
+"`D .= pinv` of every `nv x nv` block of `D::(n, nv, nv)`, or `1 ./ (eps .+ D)` for a vector (:124-135)."
+function inverse_blocks!(D::HipArray{Float32})
+    n = size(D, 1); nv = ndims(D) == 1 ? 1 : size(D, 2)
+    check(ccall((:ibh_pi_invert_blocks, lib), Cint, (Int64, Cint, Ptr{Cvoid}), n, nv, D.ptr))
+    D
+end
+
+"`out[p, k] = Σ_i v[p, i] * invD[p, k, i]` (:153-161)."
+function apply_blocks!(out::HipArray{Float32}, invD::HipArray{Float32}, v::HipArray{Float32})
+    n = size(v, 1); nv = ndims(v) == 1 ? 1 : size(v, 2)
+    check(ccall((:ibh_pi_apply_blocks, lib), Cint, (Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        n, nv, invD.ptr, v.ptr, out.ptr))
+    out
+end
+
+"`s[p, k] += z[p] * (fxb[p, k] - fx[p, k]) / h`: one Hutchinson sample (:40)."
+function hutch_accum!(s::HipArray{Float32}, fxb::HipArray{Float32}, fx::HipArray{Float32}, z::HipArray{Float32}, h)
+    n = size(s, 1); nv = ndims(s) == 1 ? 1 : size(s, 2)
+    check(ccall((:ibh_pi_hutch_accum, lib), Cint, (Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}),
+        n, nv, fxb.ptr, fx.ptr, z.ptr, Float32(h), s.ptr))
+    s
+end
+
+"`out = x + v*h` (:30, :112) and `out = (fxb - fx)/h` (:110-114)."
+perturb!(out::HipArray{Float32}, x::HipArray{Float32}, v::HipArray{Float32}, h) = (check(ccall((:ibh_pi_perturb, lib), Cint,
+    (Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}), length(x), x.ptr, v.ptr, Float32(h), out.ptr)); out)
+fd!(out::HipArray{Float32}, fxb::HipArray{Float32}, fx::HipArray{Float32}, h) = (check(ccall((:ibh_pi_fd, lib), Cint,
+    (Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}), length(fx), fxb.ptr, fx.ptr, Float32(h), out.ptr)); out)
+
+"`x .+= s .* α; r .-= As .* α` with `α = dots[1] / (dots[2] + eps)` read on the device (:229-236, :291-294)."
+function relax_update!(x::HipArray{Float32}, r::HipArray{Float32}, s::HipArray{Float32}, As::HipArray{Float32},
+                       dots::Ptr{Cvoid})
+    check(ccall((:ibh_pi_update, lib), Cint, (Int64, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        length(r), dots, eps(Float32), s.ptr, As.ptr, x.ptr, r.ptr))
+    nothing
 end
 
 end # module
