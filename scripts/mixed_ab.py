@@ -1,0 +1,46 @@
+"""Single-process timing of the sweep on partition 1 of N of the benchmark mesh (no exchange): mixed launch
+(single kernel on the eligible blocks + two-kernel form on the rest) vs the pure two-kernel form, whole and in phases.
+   python scripts/mixed_ab.py [nparts]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ibamd
+import bench
+nparts = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+msh = bench.build_mesh("rae2822_0.87M")
+n = len(msh)
+mps = -(-(-(-n // nparts)) // 64) * 64
+dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=False, only=[1])
+part = dom.partitions[1]
+dpart = ibamd.to_backend(part, ibamd.hip)
+nc = part.centers.shape[0]
+rng = np.random.default_rng(1)
+u = ibamd.hip(rng.uniform(-1, 1, nc).astype(np.float32))
+C = ibamd.hip(np.ones((nc, 2), dtype=np.float32))
+ud = torch.zeros(nc, dtype=torch.float32, device="cuda")
+side = torch.cuda.Stream()
+for phases, nofuse in ((False, False), (True, False), (False, True), (True, True)):
+    fl = ibamd.IBH_NO_FUSE if nofuse else 0
+
+    def step():
+        if phases:
+            ibamd.residual_advection(dpart, u, C, out=ud, flags=fl | ibamd.IBH_PHASE_INTERIOR)
+            ibamd.residual_advection(dpart, u, C, out=ud, flags=fl | ibamd.IBH_PHASE_BOUNDARY)
+        else:
+            ibamd.residual_advection(dpart, u, C, out=ud, flags=fl)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(20):
+                step()
+        g.replay(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 1000
+    print(f"nparts={nparts} two_kernel_form={nofuse} phases={phases}: {dt * 1e6:.2f} us per sweep", dpart.info["fusable_blocks"], dpart.info["full_blocks"], dpart.info["irregular_cells"])
