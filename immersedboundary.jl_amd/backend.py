@@ -36,6 +36,7 @@ IBH_PHASE_INTERIOR = 32
 IBH_PHASE_BOUNDARY = 64
 IBH_NO_FUSE = 128
 IBH_SWEEP_ONLY = 256
+IBH_FORCE_MIXED = 512
 
 _initialised = {}
 

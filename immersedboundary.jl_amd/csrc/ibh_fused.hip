@@ -774,9 +774,9 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         return 0;
     }
     // A mixed launch is three kernels where the two-kernel form is two: at ~3 us per launch it only pays when the
-    // single kernel saves more than that (0.26 ns per eligible block: scripts/mixed_ab.py), or when the sweep is split
-    // in overlap phases anyway (then both forms take four launches).
-    const bool mixed_pays = p->n_fz >= 12000 || (flags & (IBH_PHASE_INTERIOR | IBH_PHASE_BOUNDARY | IBH_SWEEP_ONLY));
+    // single kernel saves more than that (0.26 ns per eligible block: scripts/mixed_ab.py).  The choice depends on
+    // the partition only, never on the phase flags: a sweep split in phases reproduces the whole sweep bit for bit.
+    const bool mixed_pays = p->n_fz >= 12000 || (flags & (IBH_FORCE_MIXED | IBH_SWEEP_ONLY));
     if (tuned2 && p->fz_list && 4 * (int64_t)p->n_fz >= p->nblk && mixed_pays) {
         // mixed: eligible blocks in one kernel; the rest (skirt blocks, blocks next to face-list cells) in the
         // two-kernel form, with the gradient workspace filled only where it is read (ng_list)

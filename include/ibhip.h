@@ -171,6 +171,7 @@ int ibh_copy_rows(const int32_t* dst_rows, const int32_t* src_rows, int32_t n,
 #define IBH_PHASE_INTERIOR 32 /* only blocks that do not depend on skirt cells (run while the halo exchange is in flight) */
 #define IBH_PHASE_BOUNDARY 64 /* the complement: remaining blocks + face-list cells (run after the exchange) */
 #define IBH_NO_FUSE 128       /* keep the two-kernel form (gradient workspace) even where one kernel could do the sweep */
+#define IBH_FORCE_MIXED 512    /* take the mixed launch (single kernel + two-kernel form) whatever the partition size */
 #define IBH_SWEEP_ONLY 256     /* measurement: of a mixed launch run only the single-kernel part */
 #define IBH_EXACT 16      /* block fast path with the literal IEEE arithmetic (bit-comparable with the face-list path) */
 int ibh_residual_advection(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags);

@@ -21,7 +21,7 @@ C = ibamd.hip(np.ones((nc, 2), dtype=np.float32))
 ud = torch.zeros(nc, dtype=torch.float32, device="cuda")
 side = torch.cuda.Stream()
 for phases, nofuse in ((False, False), (True, False), (False, True), (True, True)):
-    fl = ibamd.IBH_NO_FUSE if nofuse else 0
+    fl = ibamd.IBH_NO_FUSE if nofuse else ibamd.IBH_FORCE_MIXED
 
     def step():
         if phases:

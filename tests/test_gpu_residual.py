@@ -182,12 +182,14 @@ def test_mixed_launch_matches_two_kernel_form(rae_domains):
         u = seeded_field(opart.centers, kind="step")
         C = np.stack([np.ones_like(u), f32(0.5) + seeded_field(opart.centers, seed=3) * f32(0.1)], axis=1)
         exp = oracle_advection_residual(opart, u, C)
-        # small partitions take the mixed launch only when the sweep is split in overlap phases (launch count)
+        # (small partitions take the two-kernel form by default -- launch count; IBH_FORCE_MIXED overrides)
+        FM = ibamd.IBH_FORCE_MIXED
+        one = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), flags=FM))
         import torch
         out = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
-        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out, flags=ibamd.IBH_PHASE_INTERIOR)
-        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out, flags=ibamd.IBH_PHASE_BOUNDARY)
-        one = ibamd.to_host(out)
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out, flags=FM | ibamd.IBH_PHASE_INTERIOR)
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out, flags=FM | ibamd.IBH_PHASE_BOUNDARY)
+        assert np.array_equal(ibamd.to_host(out), one)      # phases == whole sweep, bit for bit
         two = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), flags=ibamd.IBH_NO_FUSE))
         assert rel_inf(one, exp) <= TOL
         assert rel_inf(one, two) <= 2e-6
