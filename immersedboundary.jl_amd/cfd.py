@@ -130,3 +130,44 @@ def viscous_fluxes(fluid, P, Pgrad, dim, mu_t=0.0):
     B.call("ibh_cfd_viscous_fluxes", C.byref(f), nd, int(dim), n, B._ptr(P), ldp, ptrs, n, B._ptr(mt_arr),
            C.c_float(mt_const), B._ptr(F), n)
     return F
+
+
+class FlowBC:
+    """cfd.jl:160-300 -- generic flow boundary condition, called on device arrays inside ``impose_bc`` closures:
+    ``bc(P, bdry.normals)``, ``bc(P, bdry.normals, du_dn=..., image_distances=bdry.image_distances, transpiration=...)``.
+    ``FlowBC(fluid, [p, T, u, v(, w)])`` is a Dirichlet state (inlet/outlet/no-slip wall), ``FlowBC(fluid, [p, T, un],
+    normal_flow=True)`` imposes the normal velocity only (slip wall)."""
+
+    def __init__(self, fluid, P, normal_flow=False):
+        self.fluid = fluid
+        self.p_inf, self.T_inf = float(P[0]), float(P[1])
+        self.u_inf = np.ascontiguousarray(np.asarray(P[2:], dtype=np.float32))
+        self.normal_flow = bool(normal_flow)
+
+    def __call__(self, P, normals, image_distances=None, du_dn=None, transpiration=0.0):
+        P, _, ldp = B._field(P)
+        nd = _nd(P)
+        n = P.shape[0]
+        nrm, nnv, ldn = B._field(normals, n)
+        if nnv != nd:
+            raise ValueError("normals must be (n, nd)")
+        if self.normal_flow:
+            assert self.u_inf.size == 1, "Only 3 parcels in P (p, T and normal flow) allowed for normal_flow = true BC"
+        elif self.u_inf.size != nd:
+            raise ValueError("FlowBC needs one free-stream velocity component per dimension")
+        if (du_dn is None) != (image_distances is None):
+            raise ValueError("du!dn and image_distances must be passed together for BC imposition")
+        imd = None if image_distances is None else B._field(image_distances, n)[0]
+        dn = None if du_dn is None else B._field(du_dn, n)[0]
+        tv, tc = None, 0.0
+        if hasattr(transpiration, "data_ptr"):
+            tv = B._field(transpiration, n)[0]
+        else:
+            tc = float(transpiration)
+        out = B._like(P, n)
+        f = self.fluid._c()
+        B._stream()
+        B.call("ibh_cfd_flow_bc", C.byref(f), nd, n, B._ptr(P), ldp, B._ptr(nrm), ldn, C.c_float(self.p_inf),
+               C.c_float(self.T_inf), self.u_inf.ctypes.data_as(B.c_vp), int(self.normal_flow), B._ptr(imd), B._ptr(dn),
+               C.c_float(tc), B._ptr(tv), B._ptr(out), n)
+        return out

@@ -161,6 +161,62 @@ __global__ void k_viscous(ibh_fluid f, int dim0, int64_t n, const float* __restr
 
 inline dim3 grid1(int64_t n) { int g = ibh_grid(n, CFD_BLOCK); return dim3(g > 4096 ? 4096 : g); }
 
+// FlowBC call, cfd.jl:243-300: characteristic-style boundary state from the image-point primitives
+template <int ND>
+__global__ void k_flow_bc(ibh_fluid f, int64_t n, const float* __restrict__ P, int64_t ldp,
+                          const float* __restrict__ nrm, int64_t ldn, float pinf, float Tinf, float u0, float u1, float u2,
+                          int normal_flow, const float* __restrict__ imd, const float* __restrict__ dudn, float transp,
+                          const float* __restrict__ transp_v, float* __restrict__ out, int64_t ldo) {
+    const float uinf[3] = {u0, u1, u2};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float u[ND], nn[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            u[j] = P[i + (2 + j) * ldp];
+            nn[j] = nrm[i + j * ldn];
+        }
+        const float p = P[i], T = P[i + ldp];
+        float un, cur = u[0] * nn[0];
+#pragma unroll
+        for (int j = 1; j < ND; ++j) cur = cur + u[j] * nn[j];
+        if (normal_flow) {
+            un = u0;
+        } else {
+            un = nn[0] * uinf[0];
+#pragma unroll
+            for (int j = 1; j < ND; ++j) un = un + nn[j] * uinf[j];
+        }
+        const float a = sqrtf(f.gamma * f.R * fmaxf(T, 10.0f));
+        const float M = fabsf(un) / a;
+        // (un >= 0) * ((M > 1) * p_inf + (M <= 1) * p) + (un < 0) * ((M > 1) * p + (M <= 1) * p_inf)
+        const float pb = (un >= 0.0f) ? (M > 1.0f ? pinf : p) : (M > 1.0f ? p : pinf);
+        const float Tb = (un > 0.0f) ? Tinf : T;
+        float ub[ND];
+        if (normal_flow) {
+            const float tr = transp_v ? transp_v[i] : transp;
+            const float d = un - cur + tr;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) ub[j] = u[j] + nn[j] * d;
+        } else {
+#pragma unroll
+            for (int j = 0; j < ND; ++j) ub[j] = (un < 0.0f) ? u[j] : uinf[j];
+        }
+        if (dudn) {
+            float V = ub[0] * ub[0];
+#pragma unroll
+            for (int j = 1; j < ND; ++j) V = V + ub[j] * ub[j];
+            V = sqrtf(V) + 1.1920929e-07f;
+            const float sc = (V - dudn[i] * imd[i]) / V;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) ub[j] = ub[j] * sc;
+        }
+        out[i] = pb;
+        out[i + ldo] = Tb;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) out[i + (2 + j) * ldo] = ub[j];
+    }
+}
+
 }  // namespace
 
 #define CHECK_ND(nd, dim) IBH_REQUIRE(((nd) == 2 || (nd) == 3) && (dim) >= 1 && (dim) <= (nd), "bad nd/dim")
@@ -241,6 +297,25 @@ int ibh_cfd_viscous_fluxes(const ibh_fluid* f, int nd, int dim, int64_t n, const
         hipLaunchKernelGGL(k_viscous<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, dim - 1, n, P, ldp, g, ldg, mu_t,
                            mu_t_const, F, ldf);
     }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_cfd_flow_bc(const ibh_fluid* f, int nd, int64_t n, const float* P, int64_t ldp, const float* normals, int64_t ldn,
+                    float p_inf, float T_inf, const float* u_inf, int normal_flow, const float* image_distances,
+                    const float* dudn, float transpiration, const float* transpiration_v, float* out, int64_t ldo) {
+    IBH_REQUIRE(f && P && normals && u_inf && out, "ibh_cfd_flow_bc: null argument");
+    CHECK_ND(nd, 1);
+    IBH_REQUIRE((image_distances == nullptr) == (dudn == nullptr),
+                "du!dn and image_distances must be passed together for BC imposition");
+    if (n <= 0) return 0;
+    const float u0 = u_inf[0], u1 = normal_flow ? 0.0f : u_inf[1], u2 = (!normal_flow && nd == 3) ? u_inf[2] : 0.0f;
+    if (nd == 2)
+        hipLaunchKernelGGL(k_flow_bc<2>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, n, P, ldp, normals, ldn, p_inf, T_inf,
+                           u0, u1, u2, normal_flow, image_distances, dudn, transpiration, transpiration_v, out, ldo);
+    else
+        hipLaunchKernelGGL(k_flow_bc<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, n, P, ldp, normals, ldn, p_inf, T_inf,
+                           u0, u1, u2, normal_flow, image_distances, dudn, transpiration, transpiration_v, out, ldo);
     IBH_LAUNCH_CHECK();
     return 0;
 }

@@ -239,6 +239,14 @@ int ibh_axpy(int64_t n, float a, const float* x, float* y);
 /* *out (device, double) = sum(x^2) */
 int ibh_sumsq(int64_t n, const float* x, double* out);
 
+/* FlowBC call (cfd.jl:243-300): boundary state [p T u v (w)] from the image-point primitives P and the unit normals.
+ * u_inf: nd components, or ONE component (the normal velocity) when normal_flow != 0.  image_distances / dudn: both
+ * null or both given (wall-function slip scaling :287-292); transpiration: scalar, or per-row array when
+ * transpiration_v != null.  Host array u_inf; everything else device. */
+int ibh_cfd_flow_bc(const ibh_fluid* f, int nd, int64_t n, const float* P, int64_t ldp, const float* normals, int64_t ldn,
+                    float p_inf, float T_inf, const float* u_inf, int normal_flow, const float* image_distances,
+                    const float* dudn, float transpiration, const float* transpiration_v, float* out, int64_t ldo);
+
 /* ---- point-implicit smoother (reference: the orphan file src/point_implicit.jl) ------------------------------
  * Arrays are dense column-major (n points, nv variables) with leading dimension n, i.e. n*nv contiguous floats;
  * the block diagonal D is (n, nv, nv) column-major: D[p + n*(k + nv*i)] = d f_k / d x_i at point p (:56-91). */

@@ -67,3 +67,36 @@ def test_viscous_fluxes(nd):
         exp0 = ocfd.viscous_fluxes(of, P, Pgrad, dim)
         got0 = ibamd.to_host(gcfd.viscous_fluxes(gf, ibamd.hip(P), tuple(ibamd.hip(g) for g in Pgrad), dim))
         assert rel_inf(got0, exp0) <= 1e-5
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_flow_bc(nd):
+    """FlowBC call (cfd.jl:243-300): far field (sub/supersonic in/outflow), slip wall with transpiration, no-slip wall
+    with the wall-function slip scaling -- exact selects, so bit-identical to the oracle."""
+    of, gf = ocfd.Fluid(), gcfd.Fluid()
+    n = 3001
+    rng = np.random.default_rng(5)
+    P = _P(n, nd, seed=3)
+    nrm = rng.normal(size=(n, nd)).astype(f32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(f32)
+    dP, dn = ibamd.hip(P), ibamd.hip(nrm)
+    for uinf in ([250.0, 30.0, -10.0][:nd], [420.0, 0.0, 0.0][:nd]):   # subsonic and supersonic free stream
+        state = [1.0e5, 288.15] + list(uinf)
+        exp = ocfd.FlowBC(of, f32(state))(P, nrm)
+        got = ibamd.to_host(gcfd.FlowBC(gf, state)(dP, dn))
+        assert np.array_equal(got, exp)
+    # slip wall: normal velocity imposed, with and without transpiration (scalar and per ghost)
+    tr = (0.1 * rng.uniform(-1, 1, n)).astype(f32)
+    for transp, dtr in ((f32(0.0), 0.0), (f32(0.25), 0.25), (tr, ibamd.hip(tr))):
+        exp = ocfd.FlowBC(of, f32([1.0e5, 288.15, 0.0]), normal_flow=True)(P, nrm, transpiration=transp)
+        got = ibamd.to_host(gcfd.FlowBC(gf, [1.0e5, 288.15, 0.0], normal_flow=True)(dP, dn, transpiration=dtr))
+        assert rel_inf(got, exp) <= 1e-6
+    # wall function: du/dn and image distances together
+    imd = (1e-3 * (1 + rng.uniform(0, 1, n))).astype(f32)
+    dudn = (1e4 * rng.uniform(0, 1, n)).astype(f32)
+    exp = ocfd.FlowBC(of, f32([1.0e5, 288.15, 0.0]), normal_flow=True)(P, nrm, image_distances=imd, dudn=dudn)
+    got = ibamd.to_host(gcfd.FlowBC(gf, [1.0e5, 288.15, 0.0], normal_flow=True)(
+        dP, dn, image_distances=ibamd.hip(imd), du_dn=ibamd.hip(dudn)))
+    assert rel_inf(got, exp) <= 1e-6
+    with pytest.raises(ValueError):
+        gcfd.FlowBC(gf, [1.0e5, 288.15, 0.0], normal_flow=True)(dP, dn, du_dn=ibamd.hip(dudn))

@@ -202,3 +202,31 @@ def test_fas_multigrid_matches_oracle(adv_mesh_coarse):
     assert rel_inf(ibamd.to_host(Qg), Qo) <= 1e-5
     assert abs(rg - float(ro)) <= 1e-4 * max(1.0, float(ro))
     assert not np.array_equal(Qo, Q0)
+
+
+def test_flow_bc_in_impose_bc(rae_domains):
+    """FlowBC closures (cfd.jl:160-300) inside impose_bc! on the immersed wall and the far field of the RAE2822
+    case, device-resident, against the oracle's impose_bc with the oracle's FlowBC."""
+    from ibamd import cfd as gcfd
+    from oracle import cfd as ocfd
+    dp, do = rae_domains
+    n = len(dp)
+    rng = np.random.default_rng(8)
+    P = np.empty((n, 4), dtype=f32)
+    P[:, 0] = 1e5 * (1 + 0.05 * rng.uniform(-1, 1, n))
+    P[:, 1] = 288.15 * (1 + 0.05 * rng.uniform(-1, 1, n))
+    P[:, 2] = 230.0 * (1 + 0.1 * rng.uniform(-1, 1, n))
+    P[:, 3] = 20.0 * rng.uniform(-1, 1, n)
+    Po, Pg = P.copy(), ibamd.hip(P)
+    far = [1.0e5, 288.15, 230.0, 10.0]
+    o_far, g_far = ocfd.FlowBC(ocfd.Fluid(), f32(far)), gcfd.FlowBC(gcfd.Fluid(), far)
+    o_wall = ocfd.FlowBC(ocfd.Fluid(), f32([1.0e5, 288.15, 0.0]), normal_flow=True)
+    g_wall = gcfd.FlowBC(gcfd.Fluid(), [1.0e5, 288.15, 0.0], normal_flow=True)
+    od.impose_bc(lambda b, ia: o_far(ia, b.normals), do, "farfield", Po)
+    ibamd.impose_bc(lambda b, ia: g_far(ia, b.normals), dp, "farfield", Pg)
+    od.impose_bc(lambda b, ia: o_wall(ia, b.normals), do, "wall", Po)
+    ibamd.impose_bc(lambda b, ia: g_wall(ia, b.normals), dp, "wall", Pg)
+    got = ibamd.to_host(Pg)
+    assert not np.array_equal(got, P)
+    for v in range(4):
+        assert rel_inf(got[:, v], Po[:, v]) <= 1e-5
