@@ -347,7 +347,8 @@ def main():
     # partitions with skirt blocks: eligible blocks in the single kernel, the rest in the two-kernel form
     mixed = (not euler and not is3d and flags == 0 and not fused
              and 0 < inf["fusable_blocks"] and 4 * inf["fusable_blocks"] >= inf["full_blocks"])
-    if fused:
+    fused_e = euler and not is3d and flags == 0 and inf["irregular_cells"] == 0 and inf["fusable_blocks"] == inf["full_blocks"] > 0
+    if fused or fused_e:
         tB, tA = time_pass(0, reps), None
     elif mixed:
         tB, tA = time_pass(ibamd.IBH_SWEEP_ONLY, reps), None
@@ -361,7 +362,8 @@ def main():
     # HBM-side traffic of one launch of the dominant kernel from the committed PMC passes of this build (separate
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
     # calibrated against the kernel's known tile loads); null if not profiled.
-    kernel = ("k_passB_euler<3>" if (euler and is3d) else "k_passB_euler_blk" if euler else "k_passB3_adv_blk" if is3d else
+    kernel = ("k_passB3e_blk" if (euler and is3d) else "k_sweep_euler" if fused_e else "k_passB_euler_blk" if euler else
+              "k_passB3_adv_blk" if is3d else
               "k_sweep_adv" if (fused or mixed) else "k_passB_adv<2,false>")
     traffic = None
     try:
@@ -392,7 +394,7 @@ def main():
                                f"{'R2 Euler HLL' if euler else 'R1 advection'}-JST-MUSCL residual, fields resident in HBM",
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
                    "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else
-                            "block-fast-path, single kernel" if fused else
+                            "block-fast-path, single kernel" if (fused or fused_e) else
                             "block-fast-path, single kernel on %d of %d blocks" % (inf["fusable_blocks"], inf["full_blocks"])
                             if mixed else "block-fast-path, two kernels"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",

@@ -282,6 +282,261 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Single-kernel Euler sweep (R2: P = [p T u v], MUSCL(high_order) with the pressure sensor, HLL, Green-Gauss;
+// cfd.jl:459-508 over ImmersedBoundary.jl:1077-1157): the scheme of sweep_adv with four variables.  Slopes of the
+// halo cells need the value one step deeper for every variable; the sensor (pressure only) also the lateral
+// neighbours / end table.  HLL combine in Float32 like the tuned two-kernel form.
+// LDS per wave (floats): P 4x128 | D 128 | SX 4x128 | SY 4x128 | ex 4x64 | ext 80
+// ------------------------------------------------------------------------------------------
+#define BLK2_SWEEP_EULER_LDS (4 * 128 + 128 + 8 * 128 + 4 * 64 + 80)
+
+// MUSCL states from undivided slopes (see flux_w), then the HLL flux of blk2::euler_flux
+__device__ __forceinline__ void euler_flux_w(const float* Pa, const float* Pb, const float* Sa, const float* Sb, float Da,
+                                             float Db, float wa, int dn, const Gas& gas, float* F) {
+    float PL[4], PR[4];
+    const float Df = fmaxf(fmaxf(Da, Db), 1e-7f);
+    const float wb = 1.0f - wa;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float d = Pb[v] - Pa[v];
+        const float gu = Sa[v] - d * wa;
+        const float Du = Sb[v] - d * wb;
+        const float s = __builtin_amdgcn_fmed3f(Du, gu, 0.0f);
+        const float t16 = (Sa[v] - Sb[v]) * 0.0625f;
+        const float uf = (Pa[v] + wa * d) + t16;
+        PL[v] = uf + Df * ((s - wa * d) - t16);   // (Pa + s) - uf
+        PR[v] = uf + Df * ((wb * d - s) - t16);   // (Pb - s) - uf
+    }
+    float QL[4], FL[4], QR[4], FR[4], uL, aL, uR, aR;
+    euler_side(PL, dn, gas, QL, FL, uL, aL);
+    euler_side(PR, dn, gas, QR, FR, uR, aR);
+    const float SR = fminf(uR - aR, 0.0f);
+    const float SL = fmaxf(uL + aL, 0.0f);
+    const float rs = __builtin_amdgcn_rcpf(SL - SR);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) F[v] = (SL * FL[v] - SR * FR[v] + SR * SL * (QR[v] - QL[v])) * rs;
+}
+
+struct SweepPreE {
+    BlockDesc2 bb;
+    uint32_t hidx, eidx;
+    float Pc[4];
+    int ty;
+    float qs;
+};
+__device__ __forceinline__ SweepPreE sweep_prefetch_e(const BlockDesc2* __restrict__ blocks,
+                                                      const int32_t* __restrict__ htab,
+                                                      const int32_t* __restrict__ etab, int32_t blk,
+                                                      const float* __restrict__ P, uint32_t ldp, int lane) {
+    SweepPreE T;
+    T.bb = blocks[blk];
+    T.hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
+    T.eidx = (uint32_t)etab[(size_t)blk * 16 + (lane & 15)];
+    const int32_t* bw = (const int32_t*)(blocks + blk);
+    T.ty = bw[1 + (lane >> 4)];
+    T.qs = __int_as_float(bw[21 + (lane >> 4)]);
+    const uint32_t c = (uint32_t)T.bb.base + lane;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) T.Pc[v] = ldg(P + (size_t)v * ldp, c);
+    return T;
+}
+
+__device__ __forceinline__ void sweep_euler(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                            const int32_t* __restrict__ etab, int32_t blk0, int32_t stride, int32_t nb,
+                                            const float* __restrict__ P, uint32_t ldp, float* __restrict__ Rr,
+                                            uint32_t ldr, Gas gas, float* lds, int lane) {
+    float* fP = lds;           // [4][128]
+    float* fD = lds + 512;     // [128]
+    float* fSX = lds + 640;    // [4][128]
+    float* fSY = lds + 1152;   // [4][128]
+    float* ex = lds + 1664;    // [4][64]
+    float* ext = lds + 1920;   // [80]
+    // ---- lane-only geometry (as in sweep_adv)
+    const int s = lane >> 4, dn = lane >> 5, p = lane & 15, t = p >> 1;
+    const int delta = seli4(s, -1, 1, -8, 8);
+    const int pos0 = (dn ? t : 8 * t) + ((s & 1) ? (dn ? 56 : 7) : 0);
+    const int posx = pos0 ^ (dn ? 1 : 8);
+    float* extw = ext + s * 20 + 2 + p;
+    float* exte = ext + ((lane >> 2) & 3) * 20 + ((lane >> 1) & 1) * 18 + (lane & 1);
+    const float* el = ext + s * 20;
+    const float* fSn = dn ? fSY : fSX;
+    const int i = lane & 7, j = lane >> 3;
+    const bool e0 = i == 0, e1 = i == 7, e2 = j == 0, e3 = j == 7;
+    const int n0 = e0 ? 64 + j * 2 : lane - 1;
+    const int n1 = e1 ? 80 + j * 2 : lane + 1;
+    const int n2 = e2 ? 96 + i * 2 : lane - 8;
+    const int n3 = e3 ? 112 + i * 2 : lane + 8;
+    const int n0b = n0 + (e0 ? 1 : 0), n1b = n1 + (e1 ? 1 : 0), n2b = n2 + (e2 ? 1 : 0), n3b = n3 + (e3 ? 1 : 0);
+    const int xg = (lane >> 3) & 3, xt = lane & 7, xd = xg & 1;
+    const int xpos = xd ? xt : 8 * xt;
+    const int xslot = 64 + (xd * 16 + xt) * 2 + (xg >> 1);
+    const float* xS = xd ? fSY : fSX;
+
+    SweepPreE N = sweep_prefetch_e(blocks, htab, etab, blk0, P, ldp, lane);
+    for (int32_t it = 0; it < nb; ++it) {
+        const SweepPreE T = N;
+        if (it + 1 < nb) N = sweep_prefetch_e(blocks, htab, etab, blk0 + (it + 1) * stride, P, ldp, lane);
+        const BlockDesc2& bb = T.bb;
+        const bool mirror = T.ty == SIDE_MIRROR, isC = T.ty == SIDE_COARSE, isF = T.ty == SIDE_FINE;
+        const uint32_t didx = mirror ? T.hidx : T.hidx + (uint32_t)delta;
+        float hP[4], hdeep[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            hP[v] = ldg(P + (size_t)v * ldp, T.hidx);
+            hdeep[v] = ldg(P + (size_t)v * ldp, didx);
+        }
+        const float eu = ldg(P, T.eidx);  // pressure across the ends of the sides (sensor only)
+        if (it) wave_lds_sync();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            fP[v * 128 + lane] = T.Pc[v];
+            fP[v * 128 + 64 + lane] = hP[v];
+        }
+        *extw = hP[0];
+        *exte = eu;
+        const float q0 = e0 ? bb.q[0] : 0.5f, q1 = e1 ? bb.q[1] : 0.5f;
+        const float q2 = e2 ? bb.q[2] : 0.5f, q3 = e3 ? bb.q[3] : 0.5f;
+        wave_lds_sync();
+        // ---- own cells: undivided slopes of the four primitives, pressure sensor
+        float Sx[4], Sy[4], Dc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float* f = fP + v * 128;
+            const v2f l0 = v2(f[n0], f[n2]), l1 = v2(f[n0b], f[n2b]);
+            const v2f r0 = v2(f[n1], f[n3]), r1 = v2(f[n1b], f[n3b]);
+            const v2f c = v2(T.Pc[v]);
+            const v2f dR = 0.5f * (r0 + r1) - c, dL = c - 0.5f * (l0 + l1);
+            const v2f S = v2(q1, q3) * dR + v2(q0, q2) * dL;
+            Sx[v] = S.x;
+            Sy[v] = S.y;
+            fSX[v * 128 + lane] = S.x;
+            fSY[v * 128 + lane] = S.y;
+            if (v == 0) {
+                const v2f nu = sensor2(T.Pc[0], l0, l1, r0, r1, v2(bb.rh[0], bb.rh[1]));
+                Dc = fmaxf(fmaxf(nu.x, nu.y), 1e-7f);
+            }
+        }
+        fD[lane] = Dc;
+        // ---- halo cells
+        float Sh[4], Dh;
+        {
+            const int pm1 = isC ? posx : pos0;
+            const float omq = 1.0f - T.qs;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float m0 = fP[v * 128 + pos0], m1 = fP[v * 128 + pm1];
+                const float din = 0.5f * (m0 + m1) - hP[v];
+                const float dde = hdeep[v] - hP[v];
+                const float x = omq * din - 0.5f * dde;
+                Sh[v] = (s & 1) ? -x : x;
+                if (v == 0) {
+                    const float irt = isC ? 0.5f : isF ? 2.0f : 1.0f;
+                    const float ihn = (dn ? bb.rh[1] : bb.rh[0]) * irt;
+                    const float iht = (dn ? bb.rh[0] : bb.rh[1]) * irt;
+                    const int mask = isF ? 15 : isC ? 12 : 14;
+                    const int pm = p & mask, w = 16 - mask, e0i = pm + 2;
+                    const bool single = mask == 15;
+                    const int lo0 = pm == 0 ? 0 : e0i - w;
+                    const int lo1 = lo0 + ((pm == 0 || !single) ? 1 : 0);
+                    const int hi0 = e0i + w;
+                    const int hi1 = hi0 + ((hi0 == 18 || !single) ? 1 : 0);
+                    const v2f nu = sensor2(hP[0], v2(m0, el[lo0]), v2(m1, el[lo1]), v2(hdeep[0], el[hi0]),
+                                           v2(hdeep[0], el[hi1]), v2(ihn, iht));
+                    Dh = fmaxf(fmaxf(nu.x, nu.y), 1e-7f);
+                }
+            }
+        }
+        wave_lds_sync();
+        {
+            const float Dm = fD[pos0];
+            Dh = mirror ? Dm : Dh;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float Sm = fSn[v * 128 + pos0];
+                Sh[v] = mirror ? Sm : Sh[v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            fSX[v * 128 + 64 + lane] = Sh[v];
+            fSY[v * 128 + 64 + lane] = Sh[v];
+        }
+        fD[64 + lane] = Dh;
+        wave_lds_sync();
+        // ---- fluxes: right (x+) and top (y+) face of every cell
+        float FR[4], FT[4], FR1[4], FT1[4];
+        {
+            float Pb[4], Sb[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Pb[v] = fP[v * 128 + n1];
+                Sb[v] = fSX[v * 128 + n1];
+            }
+            euler_flux_w(T.Pc, Pb, Sx, Sb, Dc, fD[n1], q1, 0, gas, FR);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Pb[v] = fP[v * 128 + n3];
+                Sb[v] = fSY[v * 128 + n3];
+            }
+            euler_flux_w(T.Pc, Pb, Sy, Sb, Dc, fD[n3], q3, 1, gas, FT);
+        }
+        {   // low sides: the halo cell is the owner, this block's cell the neighbour
+            float Pa[4], Pb[4], Sa[4], Sb[4], X[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Pa[v] = fP[v * 128 + xslot];
+                Pb[v] = fP[v * 128 + xpos];
+                Sa[v] = xS[v * 128 + xslot];
+                Sb[v] = xS[v * 128 + xpos];
+            }
+            euler_flux_w(Pa, Pb, Sa, Sb, fD[xslot], fD[xpos], 1.0f - (xd ? bb.q[2] : bb.q[0]), xd, gas, X);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ex[v * 64 + lane] = X[v];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            FR1[v] = FR[v];
+            FT1[v] = FT[v];
+        }
+        if (bb.type[1] == SIDE_FINE) {  // second sub-faces of the HIGH sides: wave-uniform
+            float Pb[4], Sb[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Pb[v] = fP[v * 128 + n1 + 1];
+                Sb[v] = fSX[v * 128 + n1 + 1];
+            }
+            euler_flux_w(T.Pc, Pb, Sx, Sb, Dc, fD[n1 + 1], bb.q[1], 0, gas, FR1);
+        }
+        if (bb.type[3] == SIDE_FINE) {
+            float Pb[4], Sb[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Pb[v] = fP[v * 128 + n3 + 1];
+                Sb[v] = fSY[v * 128 + n3 + 1];
+            }
+            euler_flux_w(T.Pc, Pb, Sy, Sb, Dc, fD[n3 + 1], bb.q[3], 1, gas, FT1);
+        }
+        float FLs[4], FBs[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            FLs[v] = __shfl_up(FR[v], 1, 64);
+            FBs[v] = __shfl_up(FT[v], 8, 64);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float* e = ex + v * 64;
+            const float eL = 0.5f * (e[j] + e[16 + j]), eB = 0.5f * (e[8 + i] + e[24 + i]);
+            const float fl = e0 ? eL : FLs[v];
+            const float fb = e2 ? eB : FBs[v];
+            const float fr = e1 ? 0.5f * (FR[v] + FR1[v]) : FR[v];
+            const float ft = e3 ? 0.5f * (FT[v] + FT1[v]) : FT[v];
+            stg(Rr + (size_t)v * ldr, (uint32_t)bb.base + lane, -((fr - fl) * bb.rh[0]) - ((ft - fb) * bb.rh[1]));
+        }
+    }
+}
+
 #pragma clang fp contract(off)
 
 }  // namespace blk2

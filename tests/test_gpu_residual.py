@@ -194,3 +194,21 @@ def test_mixed_launch_matches_two_kernel_form(rae_domains):
         assert rel_inf(one, exp) <= TOL
         assert rel_inf(one, two) <= 2e-6
     assert mixed > 0
+
+
+def test_single_kernel_euler_sweep(rae_mesh_small):
+    """Euler sweep on one partition with every block eligible: one launch (blk2::sweep_euler), against the oracle and
+    against the two-kernel form."""
+    from conftest import RAE_FAMILIES, oracle_view
+    dom = ibamd.Domain(rae_mesh_small, hypercube_families=RAE_FAMILIES, max_partition_size=10 ** 9, boundaries=False)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    assert dpart.info["fusable_blocks"] == dpart.info["full_blocks"] > 0
+    P = euler_field(part.centers)
+    exp = oracle_euler_residual(oracle_view(part), P, ocfd.Fluid())
+    one = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P)))
+    two = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=ibamd.IBH_NO_FUSE))
+    for v in range(4):
+        assert rel_inf(two[:, v], exp[:, v]) <= TOL, v
+        assert rel_inf(one[:, v], exp[:, v]) <= TOL, v
+        assert rel_inf(one[:, v], two[:, v]) <= 5e-6, v
