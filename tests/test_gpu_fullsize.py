@@ -1,0 +1,81 @@
+"""Parity at the benchmark's full size (BASELINE.json configs[1]: 2-D RAE2822, 867 904 cells, one partition).
+
+The oracle here is the C restatement (oracle/csrc/residual.c: bit-identical to the numpy restatement on the small
+cases, tests/test_oracle_c.py), which does the whole mesh in a fraction of a second; plus size-independent
+properties of the closure: constant fields give exactly zero, the residual is positively homogeneous of degree one
+(minmod and the JST ratio are scale-invariant up to the 1e-7 regularisation), and all arithmetic variants of the
+library agree with each other.  Tolerance 1e-5 norm-wise (north_star)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import ibamd
+from conftest import rel_inf
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+@pytest.fixture(scope="module")
+def full():
+    import bench
+    msh = bench.build_mesh("rae2822_0.87M")
+    assert len(msh) == 867904
+    dom = ibamd.Domain(msh, max_partition_size=10 ** 9, boundaries=False)
+    (part,) = dom.partitions.values()
+    u, C = bench.synthetic_fields(part.centers)
+    return part, ibamd.to_backend(part, ibamd.hip), u, C
+
+
+def test_full_size_advection_sweep_against_the_c_oracle(full):
+    from oracle import residual_c as rc
+    part, dpart, u, C = full
+    assert dpart.info["fusable_blocks"] == dpart.info["full_blocks"] == 13561
+    Cv = np.stack([C[:, 0], f32(0.5) * C[:, 1] + f32(0.2) * np.sin(part.centers[:, 0]).astype(f32)], axis=1)
+    exp = rc.CPart(part).residual_advection(u, Cv)
+    du, dC = ibamd.hip(u), ibamd.hip(Cv)
+    one = ibamd.to_host(ibamd.residual_advection(dpart, du, dC))                              # single kernel
+    two = ibamd.to_host(ibamd.residual_advection(dpart, du, dC, flags=ibamd.IBH_NO_FUSE))     # two kernels
+    lit = ibamd.to_host(ibamd.residual_advection(dpart, du, dC, flags=ibamd.IBH_EXACT))       # literal block path
+    gen = ibamd.to_host(ibamd.residual_advection(dpart, du, dC, flags=ibamd.IBH_FORCE_GENERAL))  # face lists
+    assert np.array_equal(gen, exp)            # the literal arithmetic reproduces the oracle bit for bit
+    assert np.array_equal(lit, gen)
+    assert rel_inf(two, exp) <= 1e-5
+    assert rel_inf(one, exp) <= 1e-5
+    assert rel_inf(one, two) <= 2e-6
+
+
+def test_full_size_properties(full):
+    part, dpart, u, C = full
+    dC = ibamd.hip(C)
+    n = u.shape[0]
+    const = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(np.full(n, 3.25, dtype=f32)), dC))
+    assert np.array_equal(const, np.zeros(n, dtype=f32))                  # constant field: exactly zero
+    r1 = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), dC))
+    r4 = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(f32(4.0) * u), dC))
+    assert rel_inf(r4, f32(4.0) * r1) <= 1e-5                             # positively homogeneous, degree one
+    rm = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(f32(-1.0) * C)))
+    rf = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(-u), ibamd.hip(f32(-1.0) * C)))
+    assert rel_inf(rf, -rm) <= 1e-5                                       # odd in u for a fixed velocity field
+
+
+def test_full_size_euler_sweep_variants_agree(full):
+    import bench
+    part, dpart, _, _ = full
+    rng = np.random.default_rng(12345)
+    n = part.centers.shape[0]
+    P = np.empty((n, 4), dtype=f32)
+    P[:, 0] = 1e5 * (1 + 0.05 * rng.uniform(-1, 1, n))
+    P[:, 1] = 288.15 * (1 + 0.05 * rng.uniform(-1, 1, n))
+    P[:, 2] = 100.0 * (1 + 0.1 * rng.uniform(-1, 1, n))
+    P[:, 3] = 100.0 * (1 + 0.1 * rng.uniform(-1, 1, n))
+    dP = ibamd.hip(P)
+    one = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP))
+    two = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP, flags=ibamd.IBH_NO_FUSE))
+    gen = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP, flags=ibamd.IBH_FORCE_GENERAL))  # literal, Float64 HLL
+    for v in range(4):
+        assert rel_inf(two[:, v], gen[:, v]) <= 1e-5, v
+        assert rel_inf(one[:, v], gen[:, v]) <= 1e-5, v
