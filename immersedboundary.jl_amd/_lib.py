@@ -88,6 +88,15 @@ _SIGS = {
     "ibh_axpy_clamped": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_axpy": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_sumsq": [c_i64, c_vp, c_vp],
+    "ibh_turb_wall_function_rey": [c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ibh_turb_wall_function": [c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ibh_turb_shear_rate": [c_int, c_i64, c_vp, c_vp],
+    "ibh_turb_smagorinsky": [c_i64, c_vp, c_vp, C.c_float, c_vp],
+    "ibh_turb_k_epsilon": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ibh_turb_wray_agarwal": [c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, C.c_float, C.c_float, C.c_float, c_vp,
+                              c_vp, c_vp],
+    "ibh_turb_ducros": [c_int, c_i64, c_vp, c_vp],
+    "ibh_turb_wale": [c_i64, c_vp, c_vp, C.c_float, c_vp],
     "ibh_pi_rademacher": [c_i64, C.c_uint64, c_vp],
     "ibh_pi_perturb": [c_i64, c_vp, c_vp, C.c_float, c_vp],
     "ibh_pi_fd": [c_i64, c_vp, c_vp, C.c_float, c_vp],

@@ -247,6 +247,30 @@ int ibh_cfd_flow_bc(const ibh_fluid* f, int nd, int64_t n, const float* P, int64
                     float p_inf, float T_inf, const float* u_inf, int normal_flow, const float* image_distances,
                     const float* dudn, float transpiration, const float* transpiration_v, float* out, int64_t ldo);
 
+/* ---- turbulence closures (src/turbulence.jl), pointwise, Float32 ------------------------------------------------
+ * params8 (host) = {kappa, C, A, beta, betastar, D, Aplus, omega_fixed_point}; velocity gradients g: host table of
+ * nd*nd device pointers, g[i*nd + j] = d u_i / d x_j. */
+/* wall_function(Rey) :27-70 -> y+, u+, mu+, k+, du+/dy+ */
+int ibh_turb_wall_function_rey(int64_t n, const float* Rey, const float* params8, int n_iter, float* yplus, float* uplus,
+                               float* muplus, float* kplus, float* dudy);
+/* wall_function(y, u, nu) :72-100 -> u_tau, nu_t, k, omega, epsilon, du/dn */
+int ibh_turb_wall_function(int64_t n, const float* y, const float* u, const float* nu, const float* params8, int n_iter,
+                           float* utau, float* nut, float* k, float* omega, float* eps, float* dudn);
+/* shear_rate :110-124 = sqrt(2 Sij Sij) */
+int ibh_turb_shear_rate(int nd, int64_t n, const float* const* g, float* S);
+/* Smagorinsky_nuSGS :135-138 = (Cs Delta)^2 S */
+int ibh_turb_smagorinsky(int64_t n, const float* Delta, const float* S, float Cs, float* out);
+/* standard_k-epsilon :176-196; params5 (host) = {Cmu, sigma_k, sigma_eps, C1eps, C2eps} */
+int ibh_turb_k_epsilon(int64_t n, const float* k, const float* eps, const float* S, const float* params5, float* nuk,
+                       float* nue, float* Sk, float* Se, float* nut);
+/* Wray_Agarwal :222-241; gradR, gradS (n, nd) column-major */
+int ibh_turb_wray_agarwal(int nd, int64_t n, const float* R, const float* S, const float* gradR, int64_t ldr,
+                          const float* gradS, int64_t lds, float sigmaR, float C1, float kappa, float* nut, float* nuR,
+                          float* Sout);
+/* Ducros_sensor :252-282; WALE_nuSGS :291-337 (3-D only) */
+int ibh_turb_ducros(int nd, int64_t n, const float* const* g, float* out);
+int ibh_turb_wale(int64_t n, const float* Delta, const float* const* g, float Cw, float* out);
+
 /* ---- point-implicit smoother (reference: the orphan file src/point_implicit.jl) ------------------------------
  * Arrays are dense column-major (n points, nv variables) with leading dimension n, i.e. n*nv contiguous floats;
  * the block diagonal D is (n, nv, nv) column-major: D[p + n*(k + nv*i)] = d f_k / d x_i at point p (:56-91). */

@@ -1,0 +1,89 @@
+"""Turbulence closures (reference: /root/reference/src/turbulence.jl): oracle known answers on the CPU, device
+kernels against the oracle on the GPU."""
+import numpy as np
+import pytest
+
+from oracle import turbulence as ot
+
+f32 = np.float32
+
+
+def _grads(n, nd, seed=0):
+    rng = np.random.default_rng(seed)
+    return [[rng.uniform(-50, 50, n).astype(f32) for _ in range(nd)] for _ in range(nd)]
+
+
+def test_oracle_known_answers():
+    # law of the wall: viscous sublayer u+ = y+ (Rey = y+^2), log layer u+ = ln(y+)/kappa + C
+    lam = ot.wall_function_rey(f32([1.0, 4.0, 9.0]))
+    assert np.allclose(lam["yplus"], [1.0, 2.0, 3.0], rtol=1e-5) and np.allclose(lam["uplus"], lam["yplus"], rtol=1e-5)
+    yp = f32(200.0)
+    up = np.log(yp) / f32(0.41) + f32(4.9)
+    log = ot.wall_function_rey(f32([yp * up]), n_iter=200)
+    assert abs(log["yplus"][0] - yp) <= 1e-2 * yp
+    # pure shear du/dy = g: S = |g|; solid-body rotation: S = 0 and the Ducros sensor -> 0; pure dilatation -> 1
+    n = 7
+    g = f32(3.0) * np.ones(n, f32)
+    z = np.zeros(n, f32)
+    assert np.allclose(ot.shear_rate([[z, g], [z, z]]), 3.0)
+    assert np.allclose(ot.shear_rate([[z, g], [-g, z]]), 0.0)
+    assert np.all(ot.Ducros_sensor([[z, g], [-g, z]]) < 1e-6)
+    assert np.allclose(ot.Ducros_sensor([[g, z], [z, g]]), 1.0)
+    # k-epsilon: nu_t = Cmu k^2 / eps, equilibrium Pk = eps gives Sk = 0
+    k, e = f32([2.0]), f32([0.5])
+    ke = ot.standard_k_epsilon(k, e, np.sqrt(e / (f32(0.09) * k ** 2 / e)))
+    assert np.allclose(ke["nut"], 0.09 * 4 / 0.5) and abs(ke["Sk"][0]) < 1e-5
+    # Wray-Agarwal: no gradients -> S = C1 R S, capped at 10 R
+    wa = ot.Wray_Agarwal(f32([1.0, 1.0]), f32([2.0, 1000.0]), np.zeros((2, 2), f32), np.zeros((2, 2), f32))
+    assert np.allclose(wa["S"], [0.0829 * 2.0, 10.0], rtol=1e-6) and np.allclose(wa["nuR"], 0.72)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd", [2, 3])
+def test_gpu_closures_match_oracle(nd):
+    import ibamd
+    from ibamd import turbulence as gt
+    from conftest import rel_inf
+    n = 5003
+    rng = np.random.default_rng(nd)
+    g = _grads(n, nd, seed=nd)
+    dg = [[ibamd.hip(a) for a in row] for row in g]
+    assert rel_inf(ibamd.to_host(gt.shear_rate(dg)), ot.shear_rate(g)) <= 1e-6
+    assert rel_inf(ibamd.to_host(gt.Ducros_sensor(dg)), ot.Ducros_sensor(g)) <= 1e-5
+    Delta = rng.uniform(1e-3, 1e-1, n).astype(f32)
+    S = ot.shear_rate(g)
+    assert rel_inf(ibamd.to_host(gt.Smagorinsky_nuSGS(ibamd.hip(Delta), ibamd.hip(S))), ot.Smagorinsky_nuSGS(Delta, S)) <= 1e-6
+    if nd == 3:
+        assert rel_inf(ibamd.to_host(gt.WALE_nuSGS(ibamd.hip(Delta), dg)), ot.WALE_nuSGS(Delta, g)) <= 1e-5
+    k = rng.uniform(0.1, 5, n).astype(f32)
+    e = rng.uniform(0.1, 5, n).astype(f32)
+    gke, oke = gt.standard_k_epsilon(ibamd.hip(k), ibamd.hip(e), ibamd.hip(S)), ot.standard_k_epsilon(k, e, S)
+    for key in oke:
+        assert rel_inf(ibamd.to_host(gke[key]), oke[key]) <= 1e-5, key
+    R = rng.uniform(1e-6, 1e-3, n).astype(f32)
+    gR = rng.uniform(-1, 1, (n, nd)).astype(f32)
+    gS = rng.uniform(-100, 100, (n, nd)).astype(f32)
+    gwa = gt.Wray_Agarwal(ibamd.hip(R), ibamd.hip(S), ibamd.hip(gR), ibamd.hip(gS))
+    owa = ot.Wray_Agarwal(R, S, gR, gS)
+    for key in owa:
+        assert rel_inf(ibamd.to_host(gwa[key]), owa[key]) <= 1e-5, key
+
+
+@pytest.mark.gpu
+def test_gpu_wall_function_matches_oracle():
+    import ibamd
+    from ibamd import turbulence as gt
+    from conftest import rel_inf
+    n = 4099
+    rng = np.random.default_rng(4)
+    Rey = (10.0 ** rng.uniform(-3, 6, n)).astype(f32)
+    Rey[:3] = [0.0, -5.0, 1e-12]
+    gw, ow = gt.wall_function(ibamd.hip(Rey)), ot.wall_function_rey(Rey)
+    for key in ow:
+        assert rel_inf(ibamd.to_host(gw[key]), ow[key]) <= 1e-5, key
+    y = (10.0 ** rng.uniform(-6, -2, n)).astype(f32)
+    u = rng.uniform(0.1, 300, n).astype(f32)
+    nu = np.full(n, 1.5e-5, f32)
+    gw3, ow3 = gt.wall_function(ibamd.hip(y), ibamd.hip(u), ibamd.hip(nu)), ot.wall_function(y, u, nu)
+    for key in ow3:
+        assert rel_inf(ibamd.to_host(gw3[key]), ow3[key]) <= 2e-5, key
