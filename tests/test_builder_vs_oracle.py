@@ -96,3 +96,32 @@ def test_multigrid_structure(adv_mesh_coarse):
         assert co.n_output == len(cd) and pr.n_input == len(cd)
         # IDW coarsener = mean of the 4 children: 4 equal weights
         assert np.all(np.diff(co.off) == 4) and np.allclose(co.w, 0.25, atol=1e-6)
+
+
+def test_partition_pack_round_trip(tmp_path):
+    """save_partition / load_partition (ibamd.pack): every array of the Partition and of its Boundary chunks comes
+    back identical, accumulators included (weights 1/len are implicit in the file)."""
+    from ibamd.pack import load_partition, save_partition
+    from conftest import ADV_FAMILIES, advection_mesh
+    dom = ibamd.Domain(advection_mesh(2e-2), hypercube_families=ADV_FAMILIES, max_partition_size=2048)
+    part = dom.partitions[2]
+    path = str(tmp_path / "p2.npz")
+    save_partition(path, part, dom.boundaries)
+    back, bnd = load_partition(path)
+    assert back.id == part.id and back.block_size == part.block_size
+    for name in ("centers", "spacing", "domain", "image", "image_in_domain"):
+        assert np.array_equal(getattr(back, name), getattr(part, name)), name
+    for d in (1, 2):
+        for a, b in zip(back.face_owners_neighbors[d], part.face_owners_neighbors[d]):
+            assert np.array_equal(a, b)
+        for right in (False, True):
+            x, y = back.face_accumulators[(d, right)], part.face_accumulators[(d, right)]
+            assert np.array_equal(x.off, y.off) and np.array_equal(x.idx, y.idx) and np.array_equal(x.w, y.w)
+    assert set(bnd) == set(dom.boundaries)
+    for name, chunks in dom.boundaries.items():
+        assert set(bnd[name]) == set(chunks)
+        for x, y in ((bnd[name][c], chunks[c]) for c in chunks):
+            for f in ("ghost_indices", "projections", "normals", "image_distances", "ghost_distances", "image_domain"):
+                assert np.array_equal(getattr(x, f), getattr(y, f)), f
+            assert np.array_equal(x.image_interpolator.idx, y.image_interpolator.idx)
+            assert np.array_equal(x.image_interpolator.w, y.image_interpolator.w)
