@@ -6,6 +6,7 @@
 // jumps, ImmersedBoundary.jl:85,114-116).  Everything else falls back to the face-list kernels.
 //
 // Cell numbering inside a block is x-fastest (mesher.jl:1064-1112): local = i + 8*j.
+#include <array>
 #include <unordered_map>
 
 #include "ibh_common.h"
@@ -56,6 +57,7 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
     };
 
     std::vector<char> cell_irr(nc, 0);
+    std::vector<std::array<int32_t, 64>> halos;  // halo cell ids per block, in the order blocks are found
     for (int32_t c = 0; c < nc; ++c) cell_irr[c] = !in_full[c];
     int64_t counts[5] = {0, 0, 0, 0, 0};
 
@@ -88,7 +90,10 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
         b.h[1] = hy[base];
         b.rh[0] = 1.0f / b.h[0];
         b.rh[1] = 1.0f / b.h[1];
-        // 3. sides
+        // 3. sides.  The class of a side follows from the geometry of the faces the reference registered (global
+        //    ids give block and position of every neighbour cell); the neighbour block itself need not be complete
+        //    in this partition (skirt): the halo table takes the local ids of the cells that are there.
+        std::array<int32_t, 64> hal;
         for (int s = 0; s < 4; ++s) {
             const int d = s / 2;
             const bool low = (s % 2) == 0;
@@ -97,7 +102,8 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
             const std::vector<int32_t>& off = low ? v.loff[d] : v.roff[d];
             const std::vector<int32_t>& idx = low ? v.lidx[d] : v.ridx[d];
             int type = -1;
-            int32_t nb[2] = {-1, -1};
+            int64_t nbg[2] = {-1, -1};   // global block id of the neighbour block(s)
+            bool nbfull[2] = {true, true};
             int sub = -1;
             bool ok = true;
             for (int t = 0; t < 8 && ok; ++t) {
@@ -113,54 +119,67 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
                 }
                 if (!ok) break;
                 int ty;
+                int32_t* slot = &hal[(s * 8 + t) * 2];
                 if (nfc == 1 && other[0] == c) {
                     ty = SIDE_MIRROR;
+                    slot[0] = slot[1] = c;
                 } else if (nfc == 1) {
                     int32_t o = other[0];
-                    if (!in_full[o]) { ok = false; break; }
                     int64_t g = gid(o);
-                    int32_t ob = blockbase[g / NPB];
+                    int64_t gb = g / NPB;
                     int pos = (int)(g % NPB);
                     if (!on_opp_edge(s, pos)) { ok = false; break; }
                     int tt = tang_of_pos(s, pos);
                     if (h[o] == hc) {
                         ty = SIDE_SAME;
                         if (tt != t) { ok = false; break; }
-                        if (t == 0) nb[0] = ob; else if (nb[0] != ob) { ok = false; break; }
+                        if (t == 0) nbg[0] = gb; else if (nbg[0] != gb) { ok = false; break; }
                     } else if (h[o] == hc * 2.0f) {
                         ty = SIDE_COARSE;
                         int q = (tt - t / 2);
                         if (q != 0 && q != 4) { ok = false; break; }
                         q /= 4;
-                        if (t == 0) { nb[0] = ob; sub = q; } else if (nb[0] != ob || sub != q) { ok = false; break; }
+                        if (t == 0) { nbg[0] = gb; sub = q; } else if (nbg[0] != gb || sub != q) { ok = false; break; }
                     } else { ok = false; break; }
+                    nbfull[0] = nbfull[0] && in_full[o];
+                    slot[0] = slot[1] = o;
                 } else {
                     ty = SIDE_FINE;
-                    int32_t obk = -1;
+                    int64_t gbk = -1;
                     bool seen[2] = {false, false};
                     for (int k = 0; k < 2; ++k) {
                         int32_t o = other[k];
-                        if (o == c || !in_full[o] || h[o] != hc * 0.5f) { ok = false; break; }
+                        if (o == c || h[o] != hc * 0.5f) { ok = false; break; }
                         int64_t g = gid(o);
-                        int32_t ob = blockbase[g / NPB];
+                        int64_t gb = g / NPB;
                         int pos = (int)(g % NPB);
                         if (!on_opp_edge(s, pos)) { ok = false; break; }
                         int tt = tang_of_pos(s, pos) - 2 * (t & 3);
                         if (tt != 0 && tt != 1) { ok = false; break; }
                         if (seen[tt]) { ok = false; break; }
                         seen[tt] = true;
-                        if (obk < 0) obk = ob; else if (obk != ob) { ok = false; break; }
+                        slot[tt] = o;
+                        if (gbk < 0) gbk = gb; else if (gbk != gb) { ok = false; break; }
+                        nbfull[t >> 2] = nbfull[t >> 2] && in_full[o];
                     }
                     if (!ok) break;
                     int kb = t >> 2;
-                    if ((t & 3) == 0) nb[kb] = obk; else if (nb[kb] != obk) { ok = false; break; }
+                    if ((t & 3) == 0) nbg[kb] = gbk; else if (nbg[kb] != gbk) { ok = false; break; }
                 }
                 if (t == 0) type = ty; else if (type != ty) { ok = false; break; }
             }
-            if (!ok) type = SIDE_GENERAL;
+            if (!ok) {
+                type = SIDE_GENERAL;
+                for (int t = 0; t < 8; ++t) hal[(s * 8 + t) * 2] = hal[(s * 8 + t) * 2 + 1] = base + pos_own(s, t);
+            }
             b.type[s] = type;
-            b.nb[s][0] = nb[0];
-            b.nb[s][1] = nb[1];
+            for (int k = 0; k < 2; ++k) {  // local base of the neighbour block, -1 when it is not complete here
+                b.nb[s][k] = -1;
+                if (type != SIDE_GENERAL && nbg[k] >= 0 && nbfull[k]) {
+                    auto it = blockbase.find(nbg[k]);
+                    if (it != blockbase.end()) b.nb[s][k] = it->second;
+                }
+            }
             b.sub[s] = sub < 0 ? 0 : sub;
             b.q[s] = type == SIDE_COARSE ? (1.0f / 3.0f) : type == SIDE_FINE ? (2.0f / 3.0f) : 0.5f;
             b.rt[s] = type == SIDE_COARSE ? 2.0f : type == SIDE_FINE ? 0.5f : 1.0f;
@@ -168,6 +187,7 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
             if (type == SIDE_GENERAL)
                 for (int t = 0; t < 8; ++t) cell_irr[base + pos_own(s, t)] = 1;
         }
+        halos.push_back(hal);
         blocks.push_back(b);
     }
     for (int32_t c = 0; c < nc; ++c)
@@ -211,30 +231,23 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
             b1[b] = ok;
         }
         std::vector<BlockDesc2> ordered;
+        std::vector<std::array<int32_t, 64>> hordered;
         ordered.reserve(blocks.size());
-        for (size_t b = 0; b < blocks.size(); ++b) if (b1[b]) ordered.push_back(blocks[b]);
+        hordered.reserve(blocks.size());
+        auto take = [&](size_t b) { ordered.push_back(blocks[b]); hordered.push_back(halos[b]); };
+        for (size_t b = 0; b < blocks.size(); ++b) if (b1[b]) take(b);
         n_phase1[1] = (int32_t)ordered.size();
-        for (size_t b = 0; b < blocks.size(); ++b) if (a1[b] && !b1[b]) ordered.push_back(blocks[b]);
+        for (size_t b = 0; b < blocks.size(); ++b) if (a1[b] && !b1[b]) take(b);
         n_phase1[0] = (int32_t)ordered.size();
-        for (size_t b = 0; b < blocks.size(); ++b) if (!a1[b]) ordered.push_back(blocks[b]);
+        for (size_t b = 0; b < blocks.size(); ++b) if (!a1[b]) take(b);
         blocks.swap(ordered);
+        halos.swap(hordered);
     }
-    // 5. halo cell table in the final block order
+    // 5. halo cell table in the final block order: the local ids found in step 3 (for complete neighbour blocks
+    //    these are base + position; MIRROR and GENERAL sides name the boundary cell itself)
     htab.resize(blocks.size() * 64);
-    for (size_t bi = 0; bi < blocks.size(); ++bi) {
-        const BlockDesc2& b = blocks[bi];
-        for (int s = 0; s < 4; ++s)
-            for (int t = 0; t < 8; ++t)
-                for (int k = 0; k < 2; ++k) {
-                    int32_t cell;
-                    const int ty = b.type[s];
-                    if (ty == SIDE_SAME) cell = b.nb[s][0] + pos_opp(s, t);
-                    else if (ty == SIDE_COARSE) cell = b.nb[s][0] + pos_opp(s, 4 * b.sub[s] + (t >> 1));
-                    else if (ty == SIDE_FINE) cell = b.nb[s][t >> 2] + pos_opp(s, 2 * (t & 3) + k);
-                    else cell = b.base + pos_own(s, t);
-                    htab[bi * 64 + (s * 8 + t) * 2 + k] = cell;
-                }
-    }
+    for (size_t bi = 0; bi < blocks.size(); ++bi)
+        for (int k = 0; k < 64; ++k) htab[bi * 64 + k] = halos[bi][k];
     // 6. single-kernel sweep (blk2::sweep_adv): the wave of a block also computes gradient + sensor of its 64
     //    halo cells, from (a) the halo values, (b) the cell one step deeper inside the neighbour block
     //    (halo id -/+ 1 or 8: interior to a verified block), (c) the lateral neighbours along the side = the
