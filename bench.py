@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general", action="store_true", help="force the face-list kernels (no block fast path)")
     ap.add_argument("--exact", action="store_true", help="block path with the literal IEEE arithmetic")
+    ap.add_argument("--all-cells", action="store_true",
+                    help="N > 1: compute the residual on skirt cells too (default: image cells only)")
     ap.add_argument("--no-fuse", action="store_true", help="keep the two-kernel sweep where one kernel could do it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -194,6 +196,12 @@ def main():
         Rres = torch.zeros((nvp, dpart.nc), dtype=torch.float32, device=P.device).T
     flags = (ibamd.IBH_FORCE_GENERAL if args.general else 0) | (ibamd.IBH_EXACT if args.exact else 0)
     flags |= ibamd.IBH_NO_FUSE if args.no_fuse else 0
+    # a rank of a multi-GPU run needs the residual on its image cells only (what dom(f, args...) scatters back,
+    # ImmersedBoundary.jl:842-845): with every image block eligible that is one launch per overlap phase
+    image_only = (world > 1 and not euler and flags == 0 and dpart.info["image_blocks_all_eligible"]
+                  and not args.all_cells)
+    if image_only:
+        flags |= ibamd.IBH_IMAGE_ONLY
 
     hx = None
     comm_stream = None
@@ -342,13 +350,18 @@ def main():
         raise SystemExit("3-D workloads: one GPU only (secondary measurement)")
     # single-kernel sweep: every block eligible, no face-list cells (2-D scalar sweep on one partition)
     inf = dpart.info
-    fused = (not euler and not is3d and flags == 0 and inf["irregular_cells"] == 0
+    base_flags = flags & ~ibamd.IBH_IMAGE_ONLY
+    fused = (not euler and not is3d and base_flags == 0 and inf["irregular_cells"] == 0
              and inf["fusable_blocks"] == inf["full_blocks"] > 0)
-    # partitions with skirt blocks: eligible blocks in the single kernel, the rest in the two-kernel form
-    mixed = (not euler and not is3d and flags == 0 and not fused
-             and 0 < inf["fusable_blocks"] and 4 * inf["fusable_blocks"] >= inf["full_blocks"])
+    # partitions with skirt fragments: image-only single-kernel sweeps, or eligible blocks in the single kernel and
+    # the rest in the two-kernel form (only where that saves more than the extra launch)
+    mixed = (not euler and not is3d and base_flags == 0 and not fused and not image_only
+             and inf["fusable_blocks"] >= 12000 and 4 * inf["fusable_blocks"] >= inf["full_blocks"])
     fused_e = euler and not is3d and flags == 0 and inf["irregular_cells"] == 0 and inf["fusable_blocks"] == inf["full_blocks"] > 0
-    if fused or fused_e:
+    if image_only:
+        tB, tA = time_pass(0, reps), None
+        cells_launch = n_image
+    elif fused or fused_e:
         tB, tA = time_pass(0, reps), None
     elif mixed:
         tB, tA = time_pass(ibamd.IBH_SWEEP_ONLY, reps), None
@@ -364,7 +377,7 @@ def main():
     # calibrated against the kernel's known tile loads); null if not profiled.
     kernel = ("k_passB3e_blk" if (euler and is3d) else "k_sweep_euler" if fused_e else "k_passB_euler_blk" if euler else
               "k_passB3_adv_blk" if is3d else
-              "k_sweep_adv" if (fused or mixed) else "k_passB_adv<2,false>")
+              "k_sweep_adv" if (fused or mixed or image_only) else "k_passB_adv<2,false>")
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "current_pmc.json")) as f:
@@ -394,6 +407,7 @@ def main():
                                f"{'R2 Euler HLL' if euler else 'R1 advection'}-JST-MUSCL residual, fields resident in HBM",
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
                    "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else
+                            "block-fast-path, single kernel on the image blocks" if image_only else
                             "block-fast-path, single kernel" if (fused or fused_e) else
                             "block-fast-path, single kernel on %d of %d blocks" % (inf["fusable_blocks"], inf["full_blocks"])
                             if mixed else "block-fast-path, two kernels"),

@@ -25,7 +25,7 @@ inline bool on_opp_edge(int s, int pos) {
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks, std::vector<int32_t>& irr,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
                          std::vector<int32_t>& htab, std::vector<int32_t>& etab, std::vector<char>& fus,
-                         std::vector<char>& needg) {
+                         std::vector<char>& needg, std::vector<int32_t>& dtab) {
     const int32_t nc = v.nc;
     const int NPB = 64;
     const float* hx = v.spacing;
@@ -248,62 +248,90 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
     htab.resize(blocks.size() * 64);
     for (size_t bi = 0; bi < blocks.size(); ++bi)
         for (int k = 0; k < 64; ++k) htab[bi * 64 + k] = halos[bi][k];
-    // 6. single-kernel sweep (blk2::sweep_adv): the wave of a block also computes gradient + sensor of its 64
-    //    halo cells, from (a) the halo values, (b) the cell one step deeper inside the neighbour block
-    //    (halo id -/+ 1 or 8: interior to a verified block), (c) the lateral neighbours along the side = the
-    //    adjacent halo slots, and (d) at the two ends of every side the cells across the neighbour block's
-    //    perpendicular side: etab[blk][(s*2 + end)*2 + k], taken from that block's own (verified) halo row.
-    //    A block is eligible when none of its sides is GENERAL, every neighbour block is in the table with a
-    //    verified side facing back, the perpendicular sides used at the ends are not GENERAL, and the two fine
-    //    blocks of a FINE side are SAME-level neighbours of each other.
+    // 6. single-kernel sweep (blk2::sweep_adv / sweep_euler): the wave of a block also computes slope + sensor of
+    //    its 64 halo cells.  For a halo cell h across side s (normal dim d, tangential dim td) that takes
+    //      (a) its faces towards this block: this block's boundary cells (verified in step 3, re-checked from h's side),
+    //      (b) the cell one step deeper: h's single far face along d, same level       -> dtab[blk][slot]
+    //      (c) its lateral neighbours along td: the adjacent halo cells of the side,
+    //      (d) at the two ends of the side whatever h's outer lateral faces name (one or two cells, h itself on a
+    //          mirror face)                                                            -> etab[blk][(s*2 + end)*2 + k]
+    //    all read off the face lists of h itself, so the neighbour block may be a skirt fragment.  A block is
+    //    eligible when every halo cell passes.  `dt` of the descriptor: -1 when the deeper cells are simply
+    //    halo id -/+ 1 (x sides) or -/+ 8 (y sides) -- complete neighbour blocks -- else the row of dtab to read.
     etab.assign(blocks.size() * 16, 0);
     fus.assign(blocks.size(), 0);
+    dtab.clear();
     {
-        std::unordered_map<int32_t, int32_t> base2idx;
-        for (size_t bi = 0; bi < blocks.size(); ++bi) base2idx[blocks[bi].base] = (int32_t)bi;
-        auto find = [&](int32_t base) -> int32_t {
-            auto it = base2idx.find(base);
-            return it == base2idx.end() ? -1 : it->second;
+        auto faces_of = [&](int32_t c, int dim, bool right, int32_t* out) -> int {  // cells across the faces of c
+            const std::vector<int32_t>& off = right ? v.roff[dim] : v.loff[dim];
+            const std::vector<int32_t>& idx = right ? v.ridx[dim] : v.lidx[dim];
+            const int n = off[c + 1] - off[c];
+            if (n < 1 || n > 2) return -1;
+            for (int k = 0; k < n; ++k) {
+                const int32_t f = idx[off[c] + k];
+                const int32_t o = v.owners[dim][f], nn = v.neighbors[dim][f];
+                if ((right ? o : nn) != c) return -1;
+                out[k] = right ? nn : o;
+            }
+            return n;
         };
         int64_t nfus = 0;
         for (size_t bi = 0; bi < blocks.size(); ++bi) {
-            const BlockDesc2& b = blocks[bi];
+            BlockDesc2& b = blocks[bi];
+            b.dt = -1;
             bool ok = true;
             for (int k = 0; k < NPB && ok; ++k) ok = !cell_irr[b.base + k];
+            int32_t deep[64];
+            bool arithmetic = true;
             for (int s = 0; s < 4; ++s) {
                 int32_t* e = &etab[bi * 16 + s * 4];
                 e[0] = e[1] = e[2] = e[3] = b.base + pos_own(s, 0);
+                for (int k = 0; k < 16; ++k) deep[s * 16 + k] = halos[bi][s * 16 + k];
                 if (!ok) continue;
                 const int ty = b.type[s];
                 if (ty == SIDE_MIRROR) continue;
                 if (ty == SIDE_GENERAL) { ok = false; continue; }
-                const int td = 1 - s / 2, s_lo = 2 * td, s_hi = s_lo + 1, opp = s ^ 1;
-                const int tp = (s % 2 == 0) ? 7 : 0;  // index of the halo line along the neighbour's perpendicular sides
-                auto edge_ids = [&](int32_t ni, int side, int32_t* out) -> bool {
-                    if (blocks[ni].type[side] == SIDE_GENERAL) return false;
-                    out[0] = htab[(size_t)ni * 64 + (side * 8 + tp) * 2];
-                    out[1] = htab[(size_t)ni * 64 + (side * 8 + tp) * 2 + 1];
-                    return true;
-                };
-                const int32_t n0 = find(b.nb[s][0]);
-                if (n0 < 0 || blocks[n0].type[opp] == SIDE_GENERAL) { ok = false; continue; }
-                if (ty == SIDE_SAME) {
-                    ok = edge_ids(n0, s_lo, e) && edge_ids(n0, s_hi, e + 2);
-                } else if (ty == SIDE_COARSE) {
-                    const int sub = b.sub[s];
-                    if (sub == 0) ok = edge_ids(n0, s_lo, e);
-                    else e[0] = e[1] = blocks[n0].base + pos_opp(s, 3);
-                    if (ok) {
-                        if (sub == 1) ok = edge_ids(n0, s_hi, e + 2);
-                        else e[2] = e[3] = blocks[n0].base + pos_opp(s, 4);
+                const int d = s / 2, td = 1 - d;
+                const bool low = (s % 2) == 0;
+                const float* hn = d == 0 ? hx : hy;
+                const float* ht = d == 0 ? hy : hx;
+                const float rt = b.rt[s];
+                const int delta = s == 0 ? -1 : s == 1 ? 1 : s == 2 ? -8 : 8;
+                // the distinct halo cells of the side in order: 8 (SAME), 4 (COARSE), 16 (FINE)
+                const int step = ty == SIDE_FINE ? 1 : ty == SIDE_COARSE ? 4 : 2;
+                const int ncell = 16 / step;
+                const int near_expected = ty == SIDE_COARSE ? 2 : 1;
+                for (int q = 0; q < ncell && ok; ++q) {
+                    const int32_t h = halos[bi][s * 16 + q * step];
+                    if (hn[h] != hn[b.base] * rt || ht[h] != ht[b.base] * rt) { ok = false; break; }
+                    int32_t cells[2];
+                    // (a) faces towards this block
+                    int n = faces_of(h, d, low, cells);
+                    if (n != near_expected) { ok = false; break; }
+                    for (int k = 0; k < n; ++k)
+                        if (cells[k] < b.base || cells[k] >= b.base + NPB) ok = false;
+                    // (b) the deeper cell
+                    n = faces_of(h, d, !low, cells);
+                    if (!ok || n != 1 || cells[0] == h || hn[cells[0]] != hn[h]) { ok = false; break; }
+                    for (int k = 0; k < step; ++k) deep[s * 16 + q * step + k] = cells[0];
+                    if (cells[0] != h + delta) arithmetic = false;
+                    // (c), (d) lateral neighbours
+                    for (int side = 0; side < 2 && ok; ++side) {
+                        n = faces_of(h, td, side == 1, cells);
+                        if (n < 1) { ok = false; break; }
+                        const int qn = q + (side ? 1 : -1);
+                        if (qn >= 0 && qn < ncell) {
+                            if (n != 1 || cells[0] != halos[bi][s * 16 + qn * step]) ok = false;
+                        } else {
+                            e[side * 2] = cells[0];
+                            e[side * 2 + 1] = n == 2 ? cells[1] : cells[0];
+                        }
                     }
-                } else {  // FINE
-                    const int32_t n1 = find(b.nb[s][1]);
-                    if (n1 < 0 || blocks[n1].type[opp] == SIDE_GENERAL) { ok = false; continue; }
-                    ok = blocks[n0].type[s_hi] == SIDE_SAME && blocks[n0].nb[s_hi][0] == blocks[n1].base &&
-                         blocks[n1].type[s_lo] == SIDE_SAME && blocks[n1].nb[s_lo][0] == blocks[n0].base &&
-                         edge_ids(n0, s_lo, e) && edge_ids(n1, s_hi, e + 2);
                 }
+            }
+            if (ok && !arithmetic) {
+                b.dt = (int32_t)(dtab.size() / 64);
+                dtab.insert(dtab.end(), deep, deep + 64);
             }
             fus[bi] = ok;
             nfus += ok;

@@ -145,17 +145,35 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         std::vector<BlockDesc2> blocks;
         std::vector<int32_t> irr;
         int32_t nph[2] = {0, 0};
-        std::vector<int32_t> htab, etab;
+        std::vector<int32_t> htab, etab, dtab;
         std::vector<char> fus, needg;
         if (n_image > 0 && image_in_domain)
-            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph, htab, etab, fus, needg);
+            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph, htab, etab, fus, needg, dtab);
         else {  // no image information: everything is "boundary"
             std::vector<int32_t> none;
-            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph, htab, etab, fus, needg);
+            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph, htab, etab, fus, needg, dtab);
         }
         if ((rc = ibh_upload(&p->htab, htab.data(), htab.size()))) return rc;
         if ((rc = ibh_upload(&p->etab, etab.data(), etab.size()))) return rc;
+        if ((rc = ibh_upload(&p->dtab, dtab.data(), dtab.size()))) return rc;
         p->fuse_all = !blocks.empty() && irr.empty() && p->info[8] == (int64_t)blocks.size();
+        if (n_image > 0 && image_in_domain) {  // image blocks: eligible, all of them?
+            std::vector<char> is_img(nc, 0);
+            for (int32_t k = 0; k < n_image; ++k) is_img[image_in_domain[k] - index_base] = 1;
+            std::vector<int32_t> img;
+            bool all = true;
+            for (int32_t b = 0; b < (int32_t)blocks.size(); ++b)
+                if (is_img[blocks[b].base]) {
+                    img.push_back(b);
+                    p->n_img_int += b < nph[1];
+                    all = all && fus[b];
+                }
+            p->n_img = (int32_t)img.size();
+            p->img_all_fz = all && (int64_t)img.size() * 64 == (int64_t)n_image;
+            if (p->img_all_fz && (rc = ibh_upload(&p->img_list, img.data(), img.size()))) return rc;
+            p->info[10] = p->img_all_fz;
+            p->info[11] = p->n_img;
+        }
         if (!p->fuse_all && p->info[8] > 0) {
             std::vector<int32_t> fz, ng, nf;
             for (int32_t b = 0; b < (int32_t)blocks.size(); ++b) {
@@ -244,6 +262,8 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->blocks2);
     hipFree(p->htab);
     hipFree(p->etab);
+    hipFree(p->dtab);
+    hipFree(p->img_list);
     hipFree(p->fz_list);
     hipFree(p->ng_list);
     hipFree(p->nf_list);
@@ -259,7 +279,7 @@ int ibh_partition_destroy(ibh_part* p) {
 
 int ibh_partition_info(const ibh_part* p, int64_t* info, int n) {
     IBH_REQUIRE(p && info, "ibh_partition_info: null argument");
-    for (int i = 0; i < n && i < 10; ++i) info[i] = p->info[i];
+    for (int i = 0; i < n && i < 12; ++i) info[i] = p->info[i];
     return 0;
 }
 

@@ -27,6 +27,7 @@ struct BlockDesc2 {  // 2-D
     float rh[2];   // 1/h
     float q[4];    // per side: 1/(1 + h_nb/h) = 1/2 (same, mirror), 1/3 (coarse), 2/3 (fine)
     float rt[4];   // per side: h_nb/h = 1, 2, 1/2
+    int32_t dt;    // single-kernel sweep: row of the deeper-cell table, or -1 (deeper cell = halo id -/+ 1 or 8)
 };
 // Per block: 64 halo slots, slot = (side*8 + t)*2 + k -> local id of the k-th neighbour cell across `side`
 // of boundary cell t.  Always a valid cell: single-face sides repeat sub-face 0 in slot k=1 (so that
@@ -73,6 +74,10 @@ struct ibh_part {
     BlockDesc2* blocks2 = nullptr;
     int32_t* htab = nullptr;     // [nblk][64] halo cell table, same order as blocks2
     int32_t* etab = nullptr;     // [nblk][16] end table of the single-kernel sweep (see ibh_analyze.cpp step 6)
+    int32_t* dtab = nullptr;     // [..][64] deeper-cell rows for blocks next to skirt fragments (BlockDesc2::dt)
+    // image-only sweeps (IBH_IMAGE_ONLY): every image block eligible -> one launch per phase, nothing else
+    int32_t* img_list = nullptr; // image blocks, ascending, the first n_img_int of them < nB1
+    int32_t n_img = 0, n_img_int = 0, img_all_fz = 0;
     int32_t fuse_all = 0;        // 1: every block is eligible for the single-kernel sweep and there are no face-list cells
     // mixed launches (fuse_all == 0): ascending block indices, interior-phase entries first
     int32_t* fz_list = nullptr;  // eligible blocks                       [n_fz], the first n_fz_int of them < nB1
@@ -89,7 +94,7 @@ struct ibh_part {
     // rec[(q*5 + 1 + k)*n_irr + t] = the cell across its k-th face (accumulator order).  One coalesced read
     // replaces the offsets -> face ids -> owner/neighbour chain of the CSR walk.
     int32_t* irr_rec = nullptr;
-    int64_t info[10] = {0};
+    int64_t info[12] = {0};
     // workspace for per-cell gradients + sensor (pass A output)
     float* G = nullptr;
     size_t G_bytes = 0;
@@ -142,7 +147,8 @@ struct HostPartView {
 void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
                          std::vector<int32_t>& irr_cells, int64_t* info, const int32_t* image_in_domain,
                          int32_t n_image, int32_t* n_phase1, std::vector<int32_t>& htab,
-                         std::vector<int32_t>& etab, std::vector<char>& fusable, std::vector<char>& needg);
+                         std::vector<int32_t>& etab, std::vector<char>& fusable, std::vector<char>& needg,
+                         std::vector<int32_t>& dtab);
 
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,

@@ -576,14 +576,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(IBH_SW
                                                         uint32_t ldc, float* __restrict__ ud,
                                                         const BlockDesc2* __restrict__ blocks,
                                                         const int32_t* __restrict__ htab,
-                                                        const int32_t* __restrict__ etab, int32_t nblk, int32_t nwg,
+                                                        const int32_t* __restrict__ etab,
+                                                        const int32_t* __restrict__ dtab, int32_t nblk, int32_t nwg,
                                                         int32_t iters, const int32_t* __restrict__ blist) {
     __shared__ float lds[WPB * BLK2_SWEEP_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform LDS base
     const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * (WPB * iters) + wave);
     if (first >= nblk) return;
     const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPB - 1) / WPB));
-    blk2::sweep_adv(blocks, htab, etab, blist, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
+    blk2::sweep_adv(blocks, htab, etab, dtab, blist, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
 }
 
 // Single-kernel Euler sweep (blk2::sweep_euler); 1 / 2 / 4 waves per workgroup measured equal within 2 %
@@ -594,14 +595,15 @@ __global__ __launch_bounds__(64 * WPBE) void k_sweep_euler(const float* __restri
                                                            float* __restrict__ R, uint32_t ldr, float Rgas, float gamma,
                                                            const BlockDesc2* __restrict__ blocks,
                                                            const int32_t* __restrict__ htab,
-                                                           const int32_t* __restrict__ etab, int32_t nblk, int32_t nwg,
+                                                           const int32_t* __restrict__ etab,
+                                                           const int32_t* __restrict__ dtab, int32_t nblk, int32_t nwg,
                                                            int32_t iters) {
     __shared__ float lds[WPBE * BLK2_SWEEP_EULER_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * (WPBE * iters) + wave);
     if (first >= nblk) return;
     const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPBE - 1) / WPBE));
-    blk2::sweep_euler(blocks, htab, etab, first, WPBE, nb, P, ldp, R, ldr, blk2::Gas{Rgas, gamma},
+    blk2::sweep_euler(blocks, htab, etab, dtab, first, WPBE, nb, P, ldp, R, ldr, blk2::Gas{Rgas, gamma},
                       lds + wave * BLK2_SWEEP_EULER_LDS, lane);
 }
 
@@ -777,12 +779,22 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         const int32_t nwg = (count + WPB * iters - 1) / (WPB * iters);
         if (list)
             hipLaunchKernelGGL(k_sweep_adv, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
-                               p->blocks2, p->htab, p->etab, count, nwg, iters, list + first);
+                               p->blocks2, p->htab, p->etab, p->dtab, count, nwg, iters, list + first);
         else
             hipLaunchKernelGGL(k_sweep_adv, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
-                               p->blocks2 + first, p->htab + (size_t)first * 64, p->etab + (size_t)first * 16, count,
-                               nwg, iters, (const int32_t*)nullptr);
+                               p->blocks2 + first, p->htab + (size_t)first * 64, p->etab + (size_t)first * 16, p->dtab,
+                               count, nwg, iters, (const int32_t*)nullptr);
     };
+    if (tuned2 && (flags & IBH_IMAGE_ONLY) && p->img_all_fz && !p->fuse_all) {
+        // only the image cells are wanted (a rank of a multi-GPU run) and every image block is eligible: one launch
+        // per phase over the image blocks, no workspace, nothing for the skirt fragments
+        const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
+        IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
+        const int32_t i0 = ph2 ? p->n_img_int : 0, i1 = ph1 ? p->n_img_int : p->n_img;
+        launch_sweep(p->img_list, i0, i1 - i0);
+        IBH_LAUNCH_CHECK();
+        return 0;
+    }
     if (tuned2 && p->fuse_all) {
         // every block is eligible: the whole sweep (or one overlap phase of it) is one launch
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
@@ -893,7 +905,7 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
         const int32_t iters = ibh_sweep_iters > 0 ? ibh_sweep_iters : std::min(4, std::max(1, p->nblk / 6000));
         const int32_t nwg = (p->nblk + WPBE * iters - 1) / (WPBE * iters);
         hipLaunchKernelGGL(k_sweep_euler, dim3(nwg), dim3(64 * WPBE), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,
-                           fluid->R, fluid->gamma, p->blocks2, p->htab, p->etab, p->nblk, nwg, iters);
+                           fluid->R, fluid->gamma, p->blocks2, p->htab, p->etab, p->dtab, p->nblk, nwg, iters);
         IBH_LAUNCH_CHECK();
         return 0;
     }

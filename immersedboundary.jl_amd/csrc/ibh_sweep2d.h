@@ -95,18 +95,22 @@ struct SweepPre {
     uint32_t hidx, eidx;    // halo table / end table entries of this lane
     float uc, cxc, cyc;     // own cell
     int ty;                 // class of this lane's side (lane >> 4)
+    uint32_t dix;           // deeper cell of this lane's halo slot when the block has a table row (bb.dt >= 0)
     float qs;               // at_faces weight of this lane's side
 };
 
 __device__ __forceinline__ SweepPre sweep_prefetch(const BlockDesc2* __restrict__ blocks,
                                                    const int32_t* __restrict__ htab,
-                                                   const int32_t* __restrict__ etab, int32_t blk,
+                                                   const int32_t* __restrict__ etab,
+                                                   const int32_t* __restrict__ dtab, int32_t blk,
                                                    const float* __restrict__ u, const float* __restrict__ C,
                                                    uint32_t ldc, int lane) {
     SweepPre P;
     P.bb = blocks[blk];
     P.hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
     P.eidx = (uint32_t)etab[(size_t)blk * 16 + (lane & 15)];
+    P.dix = 0;
+    if (P.bb.dt >= 0) P.dix = (uint32_t)dtab[(size_t)P.bb.dt * 64 + lane];  // wave-uniform: blocks next to skirt fragments
     // per-side constants of this lane's halo slot straight from the descriptor (16 lanes share an address):
     // one load instead of a select chain over four scalar registers
     const int32_t* bw = (const int32_t*)(blocks + blk);
@@ -125,7 +129,7 @@ struct SweepGat {
 __device__ __forceinline__ SweepGat sweep_gather(const SweepPre& P, int delta, bool dn, const float* __restrict__ u,
                                                  const float* __restrict__ C, uint32_t ldc) {
     SweepGat G;
-    const uint32_t didx = P.ty == SIDE_MIRROR ? P.hidx : P.hidx + (uint32_t)delta;
+    const uint32_t didx = P.bb.dt >= 0 ? P.dix : (P.ty == SIDE_MIRROR ? P.hidx : P.hidx + (uint32_t)delta);
     G.hu = ldg(u, P.hidx);
     G.hdeep = ldg(u, didx);
     G.hc = ldg(C + (dn ? ldc : 0u), P.hidx);
@@ -138,7 +142,8 @@ static_assert(offsetof(BlockDesc2, type) == 4 && offsetof(BlockDesc2, q) == 84, 
 // lane-only index arithmetic is shared by all of them and the loads of the next blocks are in flight while a
 // block is computed
 __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
-                                          const int32_t* __restrict__ etab, const int32_t* __restrict__ blist,
+                                          const int32_t* __restrict__ etab, const int32_t* __restrict__ dtab,
+                                          const int32_t* __restrict__ blist,
                                           int32_t blk0, int32_t stride, int32_t nb,
                                           const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
                                           float* __restrict__ ud, float* lds, int lane) {
@@ -177,10 +182,10 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
 
     // two-stage pipeline: while block k is computed, the gathers of block k+1 and the tables of block k+2 are in flight
     auto at = [&](int32_t pos) { return blist ? blist[pos] : pos; };
-    SweepPre T1 = sweep_prefetch(blocks, htab, etab, at(blk0), u, C, ldc, lane);
+    SweepPre T1 = sweep_prefetch(blocks, htab, etab, dtab, at(blk0), u, C, ldc, lane);
     SweepGat G1 = sweep_gather(T1, delta, dn != 0, u, C, ldc);
     SweepPre T2 = T1;
-    if (nb > 1) T2 = sweep_prefetch(blocks, htab, etab, at(blk0 + stride), u, C, ldc, lane);
+    if (nb > 1) T2 = sweep_prefetch(blocks, htab, etab, dtab, at(blk0 + stride), u, C, ldc, lane);
     for (int32_t it = 0; it < nb; ++it) {
         const SweepPre P = T1;
         const SweepGat G = G1;
@@ -188,7 +193,7 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
             T1 = T2;
             G1 = sweep_gather(T1, delta, dn != 0, u, C, ldc);
         }
-        if (it + 2 < nb) T2 = sweep_prefetch(blocks, htab, etab, at(blk0 + (it + 2) * stride), u, C, ldc, lane);
+        if (it + 2 < nb) T2 = sweep_prefetch(blocks, htab, etab, dtab, at(blk0 + (it + 2) * stride), u, C, ldc, lane);
         const BlockDesc2& bb = P.bb;
         const float uc = P.uc, cxc = P.cxc, cyc = P.cyc;
         const bool mirror = P.ty == SIDE_MIRROR, isC = P.ty == SIDE_COARSE, isF = P.ty == SIDE_FINE;
@@ -324,15 +329,19 @@ struct SweepPreE {
     float Pc[4];
     int ty;
     float qs;
+    uint32_t dix;
 };
 __device__ __forceinline__ SweepPreE sweep_prefetch_e(const BlockDesc2* __restrict__ blocks,
                                                       const int32_t* __restrict__ htab,
-                                                      const int32_t* __restrict__ etab, int32_t blk,
+                                                      const int32_t* __restrict__ etab,
+                                                      const int32_t* __restrict__ dtab, int32_t blk,
                                                       const float* __restrict__ P, uint32_t ldp, int lane) {
     SweepPreE T;
     T.bb = blocks[blk];
     T.hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
     T.eidx = (uint32_t)etab[(size_t)blk * 16 + (lane & 15)];
+    T.dix = 0;
+    if (T.bb.dt >= 0) T.dix = (uint32_t)dtab[(size_t)T.bb.dt * 64 + lane];
     const int32_t* bw = (const int32_t*)(blocks + blk);
     T.ty = bw[1 + (lane >> 4)];
     T.qs = __int_as_float(bw[21 + (lane >> 4)]);
@@ -343,7 +352,8 @@ __device__ __forceinline__ SweepPreE sweep_prefetch_e(const BlockDesc2* __restri
 }
 
 __device__ __forceinline__ void sweep_euler(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
-                                            const int32_t* __restrict__ etab, int32_t blk0, int32_t stride, int32_t nb,
+                                            const int32_t* __restrict__ etab, const int32_t* __restrict__ dtab,
+                                            int32_t blk0, int32_t stride, int32_t nb,
                                             const float* __restrict__ P, uint32_t ldp, float* __restrict__ Rr,
                                             uint32_t ldr, Gas gas, float* lds, int lane) {
     float* fP = lds;           // [4][128]
@@ -373,13 +383,13 @@ __device__ __forceinline__ void sweep_euler(const BlockDesc2* __restrict__ block
     const int xslot = 64 + (xd * 16 + xt) * 2 + (xg >> 1);
     const float* xS = xd ? fSY : fSX;
 
-    SweepPreE N = sweep_prefetch_e(blocks, htab, etab, blk0, P, ldp, lane);
+    SweepPreE N = sweep_prefetch_e(blocks, htab, etab, dtab, blk0, P, ldp, lane);
     for (int32_t it = 0; it < nb; ++it) {
         const SweepPreE T = N;
-        if (it + 1 < nb) N = sweep_prefetch_e(blocks, htab, etab, blk0 + (it + 1) * stride, P, ldp, lane);
+        if (it + 1 < nb) N = sweep_prefetch_e(blocks, htab, etab, dtab, blk0 + (it + 1) * stride, P, ldp, lane);
         const BlockDesc2& bb = T.bb;
         const bool mirror = T.ty == SIDE_MIRROR, isC = T.ty == SIDE_COARSE, isF = T.ty == SIDE_FINE;
-        const uint32_t didx = mirror ? T.hidx : T.hidx + (uint32_t)delta;
+        const uint32_t didx = bb.dt >= 0 ? T.dix : (mirror ? T.hidx : T.hidx + (uint32_t)delta);
         float hP[4], hdeep[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {

@@ -90,7 +90,8 @@ int ibh_partition_destroy(ibh_part* part);
  * [2..6] = number of block sides classified SAME, MIRROR, COARSE, FINE, GENERAL,
  * [7] = blocks whose whole sweep is independent of skirt cells (IBH_PHASE_INTERIOR),
  * [8] = blocks eligible for the single-kernel sweep, [9] = blocks whose gradients go through the workspace
- *       in a mixed launch (0 when every block is eligible). */
+ *       in a mixed launch (0 when every block is eligible), [10] = 1 when every image block is eligible (IBH_IMAGE_ONLY
+ *       sweeps are then one launch per phase), [11] = image blocks. */
 int ibh_partition_info(const ibh_part* part, int64_t* info, int n);
 
 /* ---- grid operators on a Partition (ImmersedBoundary.jl:873-1157) ----------

@@ -1,5 +1,6 @@
 """Single-process timing of the sweep on partition 1 of N of the benchmark mesh (no exchange): mixed launch
-(single kernel on the eligible blocks + two-kernel form on the rest) vs the pure two-kernel form, whole and in phases.
+(single kernel on the eligible blocks + two-kernel form on the rest) vs the pure two-kernel form vs the image-only
+single-kernel sweep (IBH_IMAGE_ONLY), whole and in phases.
    python scripts/mixed_ab.py [nparts]"""
 import os, sys, time
 import numpy as np, torch
@@ -20,8 +21,8 @@ u = ibamd.hip(rng.uniform(-1, 1, nc).astype(np.float32))
 C = ibamd.hip(np.ones((nc, 2), dtype=np.float32))
 ud = torch.zeros(nc, dtype=torch.float32, device="cuda")
 side = torch.cuda.Stream()
-for phases, nofuse in ((False, False), (True, False), (False, True), (True, True)):
-    fl = ibamd.IBH_NO_FUSE if nofuse else ibamd.IBH_FORCE_MIXED
+for phases, nofuse in ((False, False), (True, False), (False, True), (True, True), (False, 'image-only'), (True, 'image-only')):
+    fl = ibamd.IBH_IMAGE_ONLY if nofuse == 'image-only' else ibamd.IBH_NO_FUSE if nofuse else ibamd.IBH_FORCE_MIXED
 
     def step():
         if phases:

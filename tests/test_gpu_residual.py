@@ -176,7 +176,7 @@ def test_mixed_launch_matches_two_kernel_form(rae_domains):
     for k in dp.partitions:
         dpart, opart = ibamd.to_backend(dp.partitions[k], ibamd.hip), do.partitions[k]
         info = dpart.info
-        if 0 < info["fusable_blocks"] < info["full_blocks"] and 4 * info["fusable_blocks"] >= info["full_blocks"]:
+        if info["fusable_blocks"] > 0 and info["irregular_cells"] > 0:   # skirt fragments: face-list cells
             mixed += 1
             assert 0 < info["workspace_blocks"] < info["full_blocks"]
         u = seeded_field(opart.centers, kind="step")
@@ -212,3 +212,45 @@ def test_single_kernel_euler_sweep(rae_mesh_small):
         assert rel_inf(two[:, v], exp[:, v]) <= TOL, v
         assert rel_inf(one[:, v], exp[:, v]) <= TOL, v
         assert rel_inf(one[:, v], two[:, v]) <= 5e-6, v
+
+
+def test_image_only_sweep_on_partitions(rae_domains):
+    """IBH_IMAGE_ONLY on a partition with skirt fragments: every image block is eligible for the single kernel (halo
+    cells in skirt fragments included, deeper cells from the table), so the sweep is one launch per phase; image
+    cells agree with the oracle and with the default sweep, phases reproduce the whole sweep bit for bit and the
+    interior phase reads no skirt cell."""
+    import torch
+    dp, do = rae_domains
+    IO = ibamd.IBH_IMAGE_ONLY
+    used = 0
+    for k in dp.partitions:
+        part, opart = dp.partitions[k], do.partitions[k]
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        info = dpart.info
+        if not info["image_blocks_all_eligible"] or info["irregular_cells"] == 0:
+            continue
+        used += 1
+        assert info["image_blocks"] * 64 == part.image_in_domain.size
+        img = part.image_in_domain
+        u = seeded_field(opart.centers, kind="step")
+        C = np.stack([np.ones_like(u), f32(0.5) + seeded_field(opart.centers, seed=3) * f32(0.1)], axis=1)
+        exp = oracle_advection_residual(opart, u, C)
+        full = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C)))
+        out = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out, flags=IO)
+        one = ibamd.to_host(out)
+        assert np.isnan(one).sum() == u.shape[0] - img.size          # nothing written outside the image
+        assert rel_inf(one[img], exp[img]) <= TOL
+        assert rel_inf(one[img], full[img]) <= 2e-6
+        skirt = np.ones(u.shape[0], dtype=bool)
+        skirt[img] = False
+        up = u.copy()
+        up[skirt] = np.nan
+        out2 = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+        ibamd.residual_advection(dpart, ibamd.hip(up), ibamd.hip(C), out=out2, flags=IO | ibamd.IBH_PHASE_INTERIOR)
+        got1 = ibamd.to_host(out2)
+        done = ~np.isnan(got1)
+        assert done.sum() == 64 * info["interior_blocks"] and np.array_equal(got1[done], one[done])
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out2, flags=IO | ibamd.IBH_PHASE_BOUNDARY)
+        assert np.array_equal(ibamd.to_host(out2)[img], one[img])
+    assert used > 0
