@@ -186,10 +186,11 @@ class XgmiHalo:
     """Direct peer-write halo exchange over xGMI (same start/finish/exchange interface as HaloExchange).
 
     Every rank owns a fine-grained receive buffer (two parities) and a flag word per peer, exported through
-    HIP IPC and mapped by the peers.  ``start`` is ONE kernel (``ibh_halo_push``): it stores the skirt values of
-    all peers straight into their buffers and its last workgroup to finish bumps the sequence number in the
-    peers' flag words.  ``finish`` is ONE kernel (``ibh_halo_pull``): bounded-spin wait on the local flag words,
-    then the unpack.  (A strong-scaled step is a handful of ~3 us launches, so every launch counts.)  No host
+    HIP IPC and mapped by the peers.  The exchange is ONE kernel (``ibh_halo_exchange``): it stores the skirt values
+    of all peers straight into their buffers, its last workgroup to finish bumps the sequence number in the peers'
+    flag words, then every workgroup waits (bounded spin) for the local flag words and unpacks its share.  (A
+    strong-scaled step is a handful of ~3 us launches, so every launch counts; ``ibh_halo_push`` / ``ibh_halo_pull``
+    are the same two halves as separate launches.)  No host
     synchronisation and no library call besides kernel launches, so a whole sweep (exchange included) can be
     captured in a HIP graph.  Double buffering makes the protocol race-free: a rank can only overwrite
     parity p of a peer after that peer signalled step n+1, which it does after unpacking step n.
@@ -273,6 +274,7 @@ class XgmiHalo:
         dist.barrier(group=group)
 
     def start(self, field):
+        """The whole exchange, one launch (``ibh_halo_exchange``); ``finish`` has nothing left to do."""
         B, C, nv = self.B, self.C, self.nv
         f, fnv, ld = B._field(field)
         if fnv != nv:
@@ -280,21 +282,16 @@ class XgmiHalo:
         par = self.step & 1
         self.step += 1
         B._stream()
-        if self.peers_send:
-            B.call("ibh_halo_push", B._ptr(f), nv, ld, B._ptr(self.send_all), len(self.peers_send),
+        if self.peers_send or self.peers_recv:
+            B.call("ibh_halo_exchange", B._ptr(f), nv, ld, B._ptr(self.send_all), len(self.peers_send),
                    C.cast(self._sseg, B.c_vp), C.cast(self._dst[par], B.c_vp), C.cast(self._sflags, B.c_vp),
-                   B.c_vp(self.state.data_ptr()))
+                   B._ptr(self.recv_all), B.c_vp(self._recv.value + 4 * par * self.n_recv_f), len(self.peers_recv),
+                   C.cast(self._rseg, B.c_vp), C.cast(self._rflags, B.c_vp), B.c_vp(self.state.data_ptr()),
+                   self.max_spins)
         return (f, ld, par)
 
     def finish(self, handle):
-        B, C, nv = self.B, self.C, self.nv
-        f, ld, par = handle
-        if not self.peers_recv:
-            return
-        B._stream()
-        B.call("ibh_halo_pull", B._ptr(f), nv, ld, B._ptr(self.recv_all), B.c_vp(self._recv.value + 4 * par * self.n_recv_f),
-               len(self.peers_recv), C.cast(self._rseg, B.c_vp), C.cast(self._rflags, B.c_vp),
-               B.c_vp(self.state.data_ptr()), self.max_spins)
+        return None
 
     def exchange(self, field):
         self.finish(self.start(field))
