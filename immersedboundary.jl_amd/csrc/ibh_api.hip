@@ -156,6 +156,7 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         if ((rc = ibh_upload(&p->htab, htab.data(), htab.size()))) return rc;
         if ((rc = ibh_upload(&p->etab, etab.data(), etab.size()))) return rc;
         if ((rc = ibh_upload(&p->dtab, dtab.data(), dtab.size()))) return rc;
+        p->n_dt = (int32_t)(dtab.size() / 64);
         p->fuse_all = !blocks.empty() && irr.empty() && p->info[8] == (int64_t)blocks.size();
         if (n_image > 0 && image_in_domain) {  // image blocks: eligible, all of them?
             std::vector<char> is_img(nc, 0);

@@ -74,7 +74,8 @@ struct ibh_part {
     BlockDesc2* blocks2 = nullptr;
     int32_t* htab = nullptr;     // [nblk][64] halo cell table, same order as blocks2
     int32_t* etab = nullptr;     // [nblk][16] end table of the single-kernel sweep (see ibh_analyze.cpp step 6)
-    int32_t* dtab = nullptr;     // [..][64] deeper-cell rows for blocks next to skirt fragments (BlockDesc2::dt)
+    int32_t* dtab = nullptr;     // [n_dt][64] deeper-cell rows for blocks next to skirt fragments (BlockDesc2::dt)
+    int32_t n_dt = 0;
     // image-only sweeps (IBH_IMAGE_ONLY): every image block eligible -> one launch per phase, nothing else
     int32_t* img_list = nullptr; // image blocks, ascending, the first n_img_int of them < nB1
     int32_t n_img = 0, n_img_int = 0, img_all_fz = 0;

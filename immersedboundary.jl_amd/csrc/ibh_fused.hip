@@ -572,6 +572,7 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_adv(PartView p, const float*
 #ifndef IBH_SWEEP_WAVES
 #define IBH_SWEEP_WAVES 5
 #endif
+template <bool DT>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(IBH_SWEEP_WAVES, IBH_SWEEP_WAVES))) void k_sweep_adv(const float* __restrict__ u, const float* __restrict__ C,
                                                         uint32_t ldc, float* __restrict__ ud,
                                                         const BlockDesc2* __restrict__ blocks,
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(IBH_SW
     const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * (WPB * iters) + wave);
     if (first >= nblk) return;
     const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPB - 1) / WPB));
-    blk2::sweep_adv(blocks, htab, etab, dtab, blist, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
+    blk2::sweep_adv<DT>(blocks, htab, etab, dtab, blist, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
 }
 
 // Single-kernel Euler sweep (blk2::sweep_euler); 1 / 2 / 4 waves per workgroup measured equal within 2 %
@@ -777,13 +778,16 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         // (measured on 13.5 k and 54 k blocks, scripts/sweep_iters.sh: 2-3 and 4-6 blocks per wave are best)
         const int32_t iters = ibh_sweep_iters > 0 ? ibh_sweep_iters : std::min(6, std::max(1, count / 6000));
         const int32_t nwg = (count + WPB * iters - 1) / (WPB * iters);
-        if (list)
-            hipLaunchKernelGGL(k_sweep_adv, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
-                               p->blocks2, p->htab, p->etab, p->dtab, count, nwg, iters, list + first);
+        const BlockDesc2* bl = list ? p->blocks2 : p->blocks2 + first;
+        const int32_t* ht = list ? p->htab : p->htab + (size_t)first * 64;
+        const int32_t* et = list ? p->etab : p->etab + (size_t)first * 16;
+        const int32_t* ls = list ? list + first : nullptr;
+        if (p->n_dt > 0)  // some blocks take their deeper cells from the table (skirt fragments)
+            hipLaunchKernelGGL(k_sweep_adv<true>, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud, bl, ht,
+                               et, p->dtab, count, nwg, iters, ls);
         else
-            hipLaunchKernelGGL(k_sweep_adv, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
-                               p->blocks2 + first, p->htab + (size_t)first * 64, p->etab + (size_t)first * 16, p->dtab,
-                               count, nwg, iters, (const int32_t*)nullptr);
+            hipLaunchKernelGGL(k_sweep_adv<false>, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud, bl, ht,
+                               et, p->dtab, count, nwg, iters, ls);
     };
     if (tuned2 && (flags & IBH_IMAGE_ONLY) && p->img_all_fz && !p->fuse_all) {
         // only the image cells are wanted (a rank of a multi-GPU run) and every image block is eligible: one launch

@@ -99,6 +99,7 @@ struct SweepPre {
     float qs;               // at_faces weight of this lane's side
 };
 
+template <bool DT>
 __device__ __forceinline__ SweepPre sweep_prefetch(const BlockDesc2* __restrict__ blocks,
                                                    const int32_t* __restrict__ htab,
                                                    const int32_t* __restrict__ etab,
@@ -110,7 +111,8 @@ __device__ __forceinline__ SweepPre sweep_prefetch(const BlockDesc2* __restrict_
     P.hidx = (uint32_t)htab[(size_t)blk * 64 + lane];
     P.eidx = (uint32_t)etab[(size_t)blk * 16 + (lane & 15)];
     P.dix = 0;
-    if (P.bb.dt >= 0) P.dix = (uint32_t)dtab[(size_t)P.bb.dt * 64 + lane];  // wave-uniform: blocks next to skirt fragments
+    if constexpr (DT)  // partitions with skirt fragments only (0.2 us of 9 on the one-partition headline otherwise)
+        if (P.bb.dt >= 0) P.dix = (uint32_t)dtab[(size_t)P.bb.dt * 64 + lane];  // wave-uniform
     // per-side constants of this lane's halo slot straight from the descriptor (16 lanes share an address):
     // one load instead of a select chain over four scalar registers
     const int32_t* bw = (const int32_t*)(blocks + blk);
@@ -126,10 +128,11 @@ __device__ __forceinline__ SweepPre sweep_prefetch(const BlockDesc2* __restrict_
 struct SweepGat {
     float hu, hdeep, hc, eu;
 };
+template <bool DT>
 __device__ __forceinline__ SweepGat sweep_gather(const SweepPre& P, int delta, bool dn, const float* __restrict__ u,
                                                  const float* __restrict__ C, uint32_t ldc) {
     SweepGat G;
-    const uint32_t didx = P.bb.dt >= 0 ? P.dix : (P.ty == SIDE_MIRROR ? P.hidx : P.hidx + (uint32_t)delta);
+    const uint32_t didx = (DT && P.bb.dt >= 0) ? P.dix : (P.ty == SIDE_MIRROR ? P.hidx : P.hidx + (uint32_t)delta);
     G.hu = ldg(u, P.hidx);
     G.hdeep = ldg(u, didx);
     G.hc = ldg(C + (dn ? ldc : 0u), P.hidx);
@@ -141,6 +144,7 @@ static_assert(offsetof(BlockDesc2, type) == 4 && offsetof(BlockDesc2, q) == 84, 
 // `nb` blocks at positions blk0, blk0 + stride, ... (block indices, or entries of `blist`) by this wave; the
 // lane-only index arithmetic is shared by all of them and the loads of the next blocks are in flight while a
 // block is computed
+template <bool DT>
 __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
                                           const int32_t* __restrict__ etab, const int32_t* __restrict__ dtab,
                                           const int32_t* __restrict__ blist,
@@ -182,18 +186,18 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
 
     // two-stage pipeline: while block k is computed, the gathers of block k+1 and the tables of block k+2 are in flight
     auto at = [&](int32_t pos) { return blist ? blist[pos] : pos; };
-    SweepPre T1 = sweep_prefetch(blocks, htab, etab, dtab, at(blk0), u, C, ldc, lane);
-    SweepGat G1 = sweep_gather(T1, delta, dn != 0, u, C, ldc);
+    SweepPre T1 = sweep_prefetch<DT>(blocks, htab, etab, dtab, at(blk0), u, C, ldc, lane);
+    SweepGat G1 = sweep_gather<DT>(T1, delta, dn != 0, u, C, ldc);
     SweepPre T2 = T1;
-    if (nb > 1) T2 = sweep_prefetch(blocks, htab, etab, dtab, at(blk0 + stride), u, C, ldc, lane);
+    if (nb > 1) T2 = sweep_prefetch<DT>(blocks, htab, etab, dtab, at(blk0 + stride), u, C, ldc, lane);
     for (int32_t it = 0; it < nb; ++it) {
         const SweepPre P = T1;
         const SweepGat G = G1;
         if (it + 1 < nb) {
             T1 = T2;
-            G1 = sweep_gather(T1, delta, dn != 0, u, C, ldc);
+            G1 = sweep_gather<DT>(T1, delta, dn != 0, u, C, ldc);
         }
-        if (it + 2 < nb) T2 = sweep_prefetch(blocks, htab, etab, dtab, at(blk0 + (it + 2) * stride), u, C, ldc, lane);
+        if (it + 2 < nb) T2 = sweep_prefetch<DT>(blocks, htab, etab, dtab, at(blk0 + (it + 2) * stride), u, C, ldc, lane);
         const BlockDesc2& bb = P.bb;
         const float uc = P.uc, cxc = P.cxc, cyc = P.cyc;
         const bool mirror = P.ty == SIDE_MIRROR, isC = P.ty == SIDE_COARSE, isF = P.ty == SIDE_FINE;

@@ -12,6 +12,13 @@ python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload rae2822_3.
 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --residual euler > $O/bench_euler.json 2>>$O/bench.err
 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload sphere3d_1.6M > $O/bench_3d_1.6M.json 2>>$O/bench.err
 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload sphere3d_4.6M > $O/bench_3d_4.6M.json 2>>$O/bench.err
+python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --residual euler --workload rae2822_3.47M > $O/bench_euler_3.47M.json 2>>$O/bench.err
+python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --residual euler --workload sphere3d_1.6M > $O/bench_3d_euler_1.6M.json 2>>$O/bench.err
+python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-fuse > $O/bench_two_kernel.json 2>>$O/bench.err
+python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline --workload rae2822_37k > $O/bench_37k.json 2>>$O/bench.err
+for n in 2 8; do python3 scripts/mixed_ab.py $n 2>/dev/null; done > $O/per_rank_sweeps.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kte -o kte -- $BENCH --residual euler > $O/kte.log 2>&1
+cp $(find $O/kte -name '*kernel_stats.csv' | head -1) $O/kernel_stats_euler.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $BENCH > $O/kt.log 2>&1
 cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 fi
@@ -20,5 +27,5 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_IN
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$t -o pmc -- $BENCH > $O/pmc_$t.log 2>&1
 done
 python3 scripts/summarize_pmc.py $O > $O/pmc_summary.json
-rm -rf $O/kt $O/pmc_*/ 
+rm -rf $O/kt $O/kte $O/pmc_*/ 
 echo done $N
