@@ -255,8 +255,10 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
                                    v2(ihn, iht));
             Dh = fmaxf(fmaxf(nu.x, nu.y), 1e-7f);
         }
-        wave_lds_sync();
-        {
+        // MIRROR sides (domain boundary: a handful of blocks) take slope and sensor of the boundary cell itself
+        if (bb.type[0] == SIDE_MIRROR || bb.type[1] == SIDE_MIRROR || bb.type[2] == SIDE_MIRROR ||
+            bb.type[3] == SIDE_MIRROR) {  // wave-uniform
+            wave_lds_sync();
             const float Sm = fSn[pos0], Dm = fD[pos0];
             Sh = mirror ? Sm : Sh;
             Dh = mirror ? Dm : Dh;
