@@ -379,11 +379,13 @@ def main():
               "k_passB3_adv_blk" if is3d else
               "k_sweep_adv" if (fused or mixed or image_only) else "k_passB_adv<2,false>")
     traffic = None
+    pmc_extra = {}
     try:
         with open(os.path.join(ROOT, "profiles", "current_pmc.json")) as f:
             pm = json.load(f)
         if pm.get("workload") == args.workload and pm.get("kernel") == kernel and world == 1:
             traffic = round((2.0 * pm["fetch_kb"] + pm["write_kb"]) * 1024.0)
+            pmc_extra = {k: pm[k] for k in ("valu_insts_per_block", "valu_busy_frac", "lds_insts_per_block") if k in pm}
     except (OSError, KeyError, ValueError):
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -391,6 +393,10 @@ def main():
                 "kernel_us": round(tB * 1e6, 3), "passA_us": None if tA is None else round(tA * 1e6, 3),
                 "alg_bytes_per_cell": b_alg, "cells_per_launch": cells_launch,
                 "sweep_frac": round(b_alg * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    if pmc_extra:
+        # the sweep sits at the FP32-vector ridge (~11 flop/B): the committed PMC passes show the vector ALUs issuing
+        # most of the time -- the binding limit is VALU issue, the HBM figure above prices algorithmic bytes
+        roofline["binding_limit"] = dict(pmc_extra, what="VALU issue (profiles/current_pmc.json)")
     if bw:
         roofline.update(measured_copy_gbs=round(bw["copy"], 1), measured_triad_gbs=round(bw["triad"], 1),
                         frac_of_measured_triad=round(achieved / bw["triad"], 4))
