@@ -598,13 +598,13 @@ __global__ __launch_bounds__(64 * WPBE) void k_sweep_euler(const float* __restri
                                                            const int32_t* __restrict__ htab,
                                                            const int32_t* __restrict__ etab,
                                                            const int32_t* __restrict__ dtab, int32_t nblk, int32_t nwg,
-                                                           int32_t iters) {
+                                                           int32_t iters, const int32_t* __restrict__ blist) {
     __shared__ float lds[WPBE * BLK2_SWEEP_EULER_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * (WPBE * iters) + wave);
     if (first >= nblk) return;
     const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPBE - 1) / WPBE));
-    blk2::sweep_euler(blocks, htab, etab, dtab, first, WPBE, nb, P, ldp, R, ldr, blk2::Gas{Rgas, gamma},
+    blk2::sweep_euler(blocks, htab, etab, dtab, blist, first, WPBE, nb, P, ldp, R, ldr, blk2::Gas{Rgas, gamma},
                       lds + wave * BLK2_SWEEP_EULER_LDS, lane);
 }
 
@@ -903,13 +903,26 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
     const int nv = p->nd + 2;
     int rc = ensure_G(p, (size_t)(p->nd * nv + 1) * p->nc);
     if (rc) return rc;
-    if (p->nd == 2 && p->bs == 8 && p->fuse_all &&
-        !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY))) {
-        // every block eligible: the whole Euler sweep is one launch, nothing goes through the workspace
-        const int32_t iters = ibh_sweep_iters > 0 ? ibh_sweep_iters : std::min(4, std::max(1, p->nblk / 6000));
-        const int32_t nwg = (p->nblk + WPBE * iters - 1) / (WPBE * iters);
-        hipLaunchKernelGGL(k_sweep_euler, dim3(nwg), dim3(64 * WPBE), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,
-                           fluid->R, fluid->gamma, p->blocks2, p->htab, p->etab, p->dtab, p->nblk, nwg, iters);
+    const bool tuned2e = p->nd == 2 && p->bs == 8 && p->nblk > 0 &&
+                         !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY));
+    if (tuned2e && (p->fuse_all || ((flags & IBH_IMAGE_ONLY) && p->img_all_fz))) {
+        // every block eligible (or only the image blocks wanted and all of them eligible: a rank of a multi-GPU run):
+        // the Euler sweep is one launch per phase, nothing goes through the workspace
+        const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
+        IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
+        const int32_t* list = p->fuse_all ? nullptr : p->img_list;
+        const int32_t nall = p->fuse_all ? p->nblk : p->n_img, nint = p->fuse_all ? p->nB1 : p->n_img_int;
+        const int32_t i0 = ph2 ? nint : 0, i1 = ph1 ? nint : nall;
+        const int32_t count = i1 - i0;
+        if (count > 0) {
+            const int32_t iters = ibh_sweep_iters > 0 ? ibh_sweep_iters : std::min(4, std::max(1, count / 6000));
+            const int32_t nwg = (count + WPBE * iters - 1) / (WPBE * iters);
+            const BlockDesc2* bl = list ? p->blocks2 : p->blocks2 + i0;
+            const int32_t* ht = list ? p->htab : p->htab + (size_t)i0 * 64;
+            const int32_t* et = list ? p->etab : p->etab + (size_t)i0 * 16;
+            hipLaunchKernelGGL(k_sweep_euler, dim3(nwg), dim3(64 * WPBE), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,
+                               fluid->R, fluid->gamma, bl, ht, et, p->dtab, count, nwg, iters, list ? list + i0 : nullptr);
+        }
         IBH_LAUNCH_CHECK();
         return 0;
     }

@@ -359,7 +359,7 @@ __device__ __forceinline__ SweepPreE sweep_prefetch_e(const BlockDesc2* __restri
 
 __device__ __forceinline__ void sweep_euler(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
                                             const int32_t* __restrict__ etab, const int32_t* __restrict__ dtab,
-                                            int32_t blk0, int32_t stride, int32_t nb,
+                                            const int32_t* __restrict__ blist, int32_t blk0, int32_t stride, int32_t nb,
                                             const float* __restrict__ P, uint32_t ldp, float* __restrict__ Rr,
                                             uint32_t ldr, Gas gas, float* lds, int lane) {
     float* fP = lds;           // [4][128]
@@ -389,10 +389,11 @@ __device__ __forceinline__ void sweep_euler(const BlockDesc2* __restrict__ block
     const int xslot = 64 + (xd * 16 + xt) * 2 + (xg >> 1);
     const float* xS = xd ? fSY : fSX;
 
-    SweepPreE N = sweep_prefetch_e(blocks, htab, etab, dtab, blk0, P, ldp, lane);
+    auto at = [&](int32_t pos) { return blist ? blist[pos] : pos; };
+    SweepPreE N = sweep_prefetch_e(blocks, htab, etab, dtab, at(blk0), P, ldp, lane);
     for (int32_t it = 0; it < nb; ++it) {
         const SweepPreE T = N;
-        if (it + 1 < nb) N = sweep_prefetch_e(blocks, htab, etab, dtab, blk0 + (it + 1) * stride, P, ldp, lane);
+        if (it + 1 < nb) N = sweep_prefetch_e(blocks, htab, etab, dtab, at(blk0 + (it + 1) * stride), P, ldp, lane);
         const BlockDesc2& bb = T.bb;
         const bool mirror = T.ty == SIDE_MIRROR, isC = T.ty == SIDE_COARSE, isF = T.ty == SIDE_FINE;
         const uint32_t didx = bb.dt >= 0 ? T.dix : (mirror ? T.hidx : T.hidx + (uint32_t)delta);

@@ -254,3 +254,34 @@ def test_image_only_sweep_on_partitions(rae_domains):
         ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out2, flags=IO | ibamd.IBH_PHASE_BOUNDARY)
         assert np.array_equal(ibamd.to_host(out2)[img], one[img])
     assert used > 0
+
+
+def test_image_only_euler_sweep_on_partitions(rae_domains):
+    """Euler sweep with IBH_IMAGE_ONLY on partitions with skirt fragments: one launch per phase over the image blocks;
+    image cells agree with the oracle and the default (two-kernel) sweep; phases == whole."""
+    import torch
+    dp, do = rae_domains
+    IO = ibamd.IBH_IMAGE_ONLY
+    used = 0
+    for k in dp.partitions:
+        part, opart = dp.partitions[k], do.partitions[k]
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        if not dpart.info["image_blocks_all_eligible"] or dpart.info["irregular_cells"] == 0:
+            continue
+        used += 1
+        img = part.image_in_domain
+        P = euler_field(opart.centers)
+        exp = oracle_euler_residual(opart, P, ocfd.Fluid())
+        full = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P)))
+        out = torch.full((4, P.shape[0]), float("nan"), dtype=torch.float32, device="cuda").T
+        ibamd.residual_euler_hll(dpart, ibamd.hip(P), out=out, flags=IO)
+        one = ibamd.to_host(out)
+        out2 = torch.full((4, P.shape[0]), float("nan"), dtype=torch.float32, device="cuda").T
+        ibamd.residual_euler_hll(dpart, ibamd.hip(P), out=out2, flags=IO | ibamd.IBH_PHASE_INTERIOR)
+        ibamd.residual_euler_hll(dpart, ibamd.hip(P), out=out2, flags=IO | ibamd.IBH_PHASE_BOUNDARY)
+        assert np.array_equal(ibamd.to_host(out2)[img], one[img])
+        for v in range(4):
+            assert np.isnan(one[:, v]).sum() == P.shape[0] - img.size
+            assert rel_inf(one[img, v], exp[img, v]) <= TOL, v
+            assert rel_inf(one[img, v], full[img, v]) <= 5e-6, v
+    assert used > 0
