@@ -310,15 +310,6 @@ __device__ __forceinline__ int32_t xcd_remap(int32_t wg, int32_t nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 #endif
 }
-#ifndef IBH_BPW
-#define IBH_BPW 1  // blocks per wave in the tuned block path (2-4 measured: no gain, see profiles/r1_v1)
-#endif
-
-struct Nb {  // data of one neighbour direction for one lane
-    float v0, v1;  // neighbour value(s)
-    float hn;      // neighbour spacing along the face normal
-    bool two;      // two faces (FINE side)
-};
 
 // Fetch the neighbour across direction s (0:x- 1:x+ 2:y- 3:y+) of the field staged in `tile`/`halo`.
 __device__ __forceinline__ void nb_fetch(const float* tile, const float* halo, int lane, int i, int j, int s, float self,
