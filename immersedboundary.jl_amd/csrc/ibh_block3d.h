@@ -6,12 +6,14 @@
 // boundary cell has exactly one face.  LDS field layout: [tile 512 | halo 384], halo slot = side*64 + t.
 #pragma once
 #include "ibh_block2d.h"
+#include "ibh_sweep2d.h"
 
 namespace blk3 {
 
 #pragma clang fp contract(fast)
 
 using blk2::adv_flux;
+using blk2::flux_w;
 using blk2::ldg;
 using blk2::stg;
 
@@ -148,12 +150,9 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
     const Lane3 L = lane_info(bb, tid);
     __syncthreads();
 
-    float dBs[6], invs[6];
+    float hnb[6];  // width of the neighbour across each side (wave-uniform)
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        dBs[s] = 0.5f * bb.h[s >> 1] * bb.rt[s];
-        invs[s] = 2.0f * bb.rh[s >> 1] * bb.q[s];
-    }
+    for (int s = 0; s < 6; ++s) hnb[s] = bb.h[s >> 1] * bb.rt[s];
     // ---- main pass: the +x, +y, +z face of every cell
     const int tth[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
     float F[3];
@@ -164,8 +163,10 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
         const int ni = L.nidx[s];
         const float gb = e ? hG[ni - 512] : tG[d * 512 + ni];
         const float Cb = e ? hC[ni - 512] : tC[d * 512 + ni];
-        const float hd = 0.5f * bb.h[d];
-        F[d] = adv_flux(uc, fU[ni], gc[d], gb, Dc, fD[ni], cc[d], Cb, hd, e ? dBs[s] : hd, e ? invs[s] : bb.rh[d]);
+        // undivided slopes S = g*h and the weight wa = h_a/(h_a+h_b) = q: the 19-operation flux of ibh_sweep2d.h
+        const float Sa = gc[d] * bb.h[d];
+        const float hb = e ? hnb[s] : bb.h[d];
+        F[d] = flux_w(uc, fU[ni], Sa, gb * hb, Dc, fD[ni], cc[d], Cb, L.q[s]);
         if (bb.type[s] == SIDE_FINE) {  // wave-uniform: 3 more sub-faces, straight from global memory
             if (e) {
                 const int32_t* ft = ftab + (((size_t)bb.fine * 6 + s) * 64 + tth[d]) * 3;
@@ -173,8 +174,8 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const uint32_t cl = (uint32_t)ft[k];
-                    acc += adv_flux(uc, ldg(u, cl), gc[d], ldg(G + (size_t)d * nc, cl), Dc, ldg(Gs, cl), cc[d],
-                                    ldg(C + (size_t)d * ldc, cl), hd, dBs[s], invs[s]);
+                    acc += flux_w(uc, ldg(u, cl), Sa, ldg(G + (size_t)d * nc, cl) * hnb[s], Dc, ldg(Gs, cl), cc[d],
+                                  ldg(C + (size_t)d * ldc, cl), bb.q[s]);
                 }
                 F[d] = 0.25f * acc;
             }
@@ -187,19 +188,20 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
         const int t1 = t & 7, t2 = t >> 3;
         const int pos = dn == 0 ? 8 * t1 + 64 * t2 : dn == 1 ? t1 + 64 * t2 : t;
         const int slot = dn * 128 + t;  // side 2*dn
-        const float hd = 0.5f * (dn == 0 ? bb.h[0] : dn == 1 ? bb.h[1] : bb.h[2]);
-        const float dB = dn == 0 ? dBs[0] : dn == 1 ? dBs[2] : dBs[4];
-        const float inv = dn == 0 ? invs[0] : dn == 1 ? invs[2] : invs[4];
-        float X = adv_flux(fU[512 + slot], fU[pos], hG[slot], tG[dn * 512 + pos], fD[512 + slot], fD[pos], hC[slot],
-                           tC[dn * 512 + pos], dB, hd, inv);
+        const float hme = dn == 0 ? bb.h[0] : dn == 1 ? bb.h[1] : bb.h[2];
+        const float hha = dn == 0 ? hnb[0] : dn == 1 ? hnb[2] : hnb[4];          // width of the halo (owner) cell
+        const float wha = 1.0f - (dn == 0 ? bb.q[0] : dn == 1 ? bb.q[2] : bb.q[4]);  // h_halo / (h_halo + h)
+        const float Sme = tG[dn * 512 + pos] * hme;
+        float X = flux_w(fU[512 + slot], fU[pos], hG[slot] * hha, Sme, fD[512 + slot], fD[pos], hC[slot],
+                         tC[dn * 512 + pos], wha);
         const int tyl = dn == 0 ? bb.type[0] : dn == 1 ? bb.type[2] : bb.type[4];  // uniform per 64-thread role group
         if (tyl == SIDE_FINE && tid < 192) {
             const int32_t* ft = ftab + (((size_t)bb.fine * 6 + 2 * dn) * 64 + t) * 3;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const uint32_t cl = (uint32_t)ft[k];
-                X += adv_flux(ldg(u, cl), fU[pos], ldg(G + (size_t)dn * nc, cl), tG[dn * 512 + pos], ldg(Gs, cl), fD[pos],
-                              ldg(C + (size_t)dn * ldc, cl), tC[dn * 512 + pos], dB, hd, inv);
+                X += flux_w(ldg(u, cl), fU[pos], ldg(G + (size_t)dn * nc, cl) * hha, Sme, ldg(Gs, cl), fD[pos],
+                            ldg(C + (size_t)dn * ldc, cl), tC[dn * 512 + pos], wha);
             }
             X *= 0.25f;
         }
