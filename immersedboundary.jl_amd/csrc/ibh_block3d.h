@@ -48,6 +48,48 @@ __device__ __forceinline__ Lane3 lane_info(const BlockDesc3& b, int tid) {
     return L;
 }
 
+// Halo cell of slot `tid` (side = tid >> 6 = this wavefront's index, boundary cell t = tid & 63).  The 3-D kernels are
+// latency-bound (load -> LDS -> barrier chains of a 512-thread workgroup), so the id is computed from the
+// descriptor instead of read from the table -- one dependent memory trip less: SAME / COARSE sides are pure
+// arithmetic on the neighbour block's base (ibh_analyze3.cpp step 5), MIRROR / GENERAL name the boundary cell
+// itself; only sides facing finer blocks read the table (wave-uniform branch).
+__device__ __forceinline__ uint32_t halo_cell3(const BlockDesc3& bb, const int32_t* __restrict__ htab, int32_t blk,
+                                               int tid) {
+    const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (sw >= 6) return (uint32_t)bb.base;
+    int ty, nb, sub;
+    switch (sw) {  // scalar registers, no dynamic indexing
+        case 0: ty = bb.type[0]; nb = bb.nb[0]; sub = bb.sub[0]; break;
+        case 1: ty = bb.type[1]; nb = bb.nb[1]; sub = bb.sub[1]; break;
+        case 2: ty = bb.type[2]; nb = bb.nb[2]; sub = bb.sub[2]; break;
+        case 3: ty = bb.type[3]; nb = bb.nb[3]; sub = bb.sub[3]; break;
+        case 4: ty = bb.type[4]; nb = bb.nb[4]; sub = bb.sub[4]; break;
+        default: ty = bb.type[5]; nb = bb.nb[5]; sub = bb.sub[5]; break;
+    }
+    if (ty == SIDE_FINE) return (uint32_t)htab[(size_t)blk * 384 + tid];
+    const int d = sw >> 1;
+    const bool low = (sw & 1) == 0;
+    const int sd = d == 0 ? 1 : d == 1 ? 8 : 64;   // stride of the normal dim
+    const int sa = d == 0 ? 8 : 1;                 // strides of the two tangential dims (increasing order)
+    const int sb = d == 2 ? 8 : 64;
+    const int t = tid & 63;
+    int t1 = t & 7, t2 = t >> 3;
+    int n, base;
+    if (ty == SIDE_SAME) {
+        n = low ? 7 : 0;
+        base = nb;
+    } else if (ty == SIDE_COARSE) {
+        n = low ? 7 : 0;
+        base = nb;
+        t1 = 4 * (sub & 1) + (t1 >> 1);
+        t2 = 4 * (sub >> 1) + (t2 >> 1);
+    } else {  // MIRROR, GENERAL: the boundary cell itself
+        n = low ? 0 : 7;
+        base = bb.base;
+    }
+    return (uint32_t)(base + n * sd + t1 * sa + t2 * sb);
+}
+
 // ------------------------------------------------------------------------------------------
 // pass A (scalar field): gradients along x, y, z + JST sensor.  LDS: 896 floats.
 // ------------------------------------------------------------------------------------------
@@ -56,7 +98,7 @@ __device__ __forceinline__ void passA(const BlockDesc3* __restrict__ blocks, con
                                       const float* __restrict__ u, float* __restrict__ G, float* lds, int tid) {
     const BlockDesc3 bb = blocks[blk];
     const uint32_t c = (uint32_t)bb.base + tid;
-    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
+    const uint32_t hidx = halo_cell3(bb, htab, blk, tid);
     const float uc = ldg(u, c);
     const float hv = ldg(u, hidx);
     lds[tid] = uc;
@@ -121,7 +163,7 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
     float* ex = hC + 384;            // [192]
     float* FF = ex + 192;            // [3][512]
     const float* Gs = G + (size_t)3 * nc;
-    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
+    const uint32_t hidx = halo_cell3(bb, htab, blk, tid);
     const float uc = ldg(u, c), Dc = ldg(Gs, c);
     float gc[3], cc[3];
 #pragma unroll
@@ -237,7 +279,7 @@ __device__ __forceinline__ void passA_nv(const BlockDesc3* __restrict__ blocks, 
                                          int tid) {
     const BlockDesc3 bb = blocks[blk];
     const uint32_t c = (uint32_t)bb.base + tid;
-    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
+    const uint32_t hidx = halo_cell3(bb, htab, blk, tid);
     float self[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -370,7 +412,7 @@ __device__ __forceinline__ void passB_euler(const BlockDesc3* __restrict__ block
     float* ex = gbuf + 2 * 3200;     // [3][5][64]
     float* FF = ex + 5 * 192;        // [5][512]
     const float* Gs = G + (size_t)15 * nc;
-    const uint32_t hidx = (uint32_t)htab[(size_t)blk * 384 + (tid < 384 ? tid : 0)];
+    const uint32_t hidx = halo_cell3(bb, htab, blk, tid);
     float Pc[5];
 #pragma unroll
     for (int v = 0; v < 5; ++v) Pc[v] = ldg(P + (size_t)v * ldp, c);
@@ -403,7 +445,7 @@ __device__ __forceinline__ void passB_euler(const BlockDesc3* __restrict__ block
         const int t1 = t & 7, t2 = t >> 3;
         const int pos = dn == 0 ? 8 * t1 + 64 * t2 : dn == 1 ? t1 + 64 * t2 : t;
         const int slot = 512 + dn * 128 + t;  // side 2*dn
-        const uint32_t ch = (uint32_t)htab[(size_t)blk * 384 + dn * 128 + t], cp = (uint32_t)bb.base + pos;
+        const uint32_t ch = halo_cell3(bb, htab, blk, dn * 128 + t), cp = (uint32_t)bb.base + pos;
         const float hd = 0.5f * (dn == 0 ? bb.h[0] : dn == 1 ? bb.h[1] : bb.h[2]);
         const float dB = dn == 0 ? dBs[0] : dn == 1 ? dBs[2] : dBs[4];
         const float inv = dn == 0 ? invs[0] : dn == 1 ? invs[2] : invs[4];
