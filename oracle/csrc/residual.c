@@ -6,7 +6,10 @@
  *   at_faces :899-910, green_gauss :918-926, unsigned_green_gauss :934-942, cell_gradient :965-972,
  *   JST_sensor :1077-1097, minmod :1099, MUSCL :1113-1157 (D given, high_order = true),
  *   Accumulator call src/accumulator.jl:78-111 (face accumulators: weights 1/len, sequential reduce).
- * Two forms:
+ * The Euler sweep (R2 of SURVEY.md 8d) is here too: ibo_residual_euler_faithful = JST_sensor(p) + per dim cell_gradient,
+ * MUSCL(D, high_order), CFD.inviscid_fluxes (HLL, /root/reference/src/cfd.jl:459-508, Float64 result) and green_gauss,
+ * one array pass per broadcast; bit-identical to the numpy composition of oracle/domain.py + oracle/cfd.py.
+ * Two forms of the scalar sweep:
  *   ibo_residual_advection_faithful -- one array pass per reference broadcast (same pass structure and the same
  *       Float32 evaluation order as the Julia code; bit-identical to oracle/domain.py), loops split over OpenMP threads;
  *   ibo_residual_advection_fused    -- one loop over cells, everything of a cell's faces recomputed in registers
@@ -218,5 +221,84 @@ int ibo_residual_advection_fused(const ibo_part* p, const float* u, const float*
         ud[c] = r;
     }
     free(G);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Euler sweep: P = [p T u v (w)] (n, nv = nd + 2) column-major with leading dimension ldp; R likewise (ldr).
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* CFD.primitive2state + the flux of one side, cfd.jl:106-123 and :470-500 (Float32) */
+static inline void side_flux(int nd, const float* P, int dim, float Rg, float gamma, float* Q, float* F, float* un,
+                             float* a) {
+    const int nv = nd + 2;
+    const float p = P[0];
+    const float T = fmaxf(P[1], 10.0f);
+    float k = P[2] * P[2];
+    for (int j = 1; j < nd; ++j) k = k + P[2 + j] * P[2 + j];
+    k = k / 2.0f;
+    const float rho = p / (Rg * T);
+    Q[0] = rho;
+    Q[1] = rho * (Rg / (gamma - 1.0f) * T + k);
+    for (int j = 0; j < nd; ++j) Q[2 + j] = rho * P[2 + j];
+    for (int v = 0; v < nv; ++v) F[v] = Q[v];
+    F[1] = F[1] + p;
+    *un = P[2 + dim];
+    *a = sqrtf(gamma * Rg * fmaxf(P[1], 10.0f));
+    for (int v = 0; v < nv; ++v) F[v] = F[v] * (*un);
+    F[2 + dim] = F[2 + dim] + p;
+}
+
+static inline double acc_mean_d(const int32_t* off, const int32_t* idx, int32_t c, const double* v) {
+    const int32_t a = off[c], b = off[c + 1];
+    if (b == a) return 0.0;
+    const float w = 1.0f / (float)(b - a);
+    double s = v[idx[a]] * (double)w;
+    for (int32_t k = a + 1; k < b; ++k) s = s + v[idx[k]] * (double)w;
+    return s;
+}
+
+int ibo_residual_euler_faithful(const ibo_part* p, const float* P, int64_t ldp, float Rg, float gamma, float* R,
+                                int64_t ldr) {
+    const int nd = p->nd, nv = nd + 2;
+    const size_t nf = max_nf(p), nc = (size_t)p->nc;
+    float* w = (float*)malloc(sizeof(float) * ((size_t)(2 + 2 * nv) * nf + 4 * nc));
+    double* F = (double*)malloc(sizeof(double) * (size_t)nv * nf);
+    if (!w || !F) { free(w); free(F); return -1; }
+    float *f0 = w, *f1 = f0 + nf, *PL = f1 + nf, *PR = PL + (size_t)nv * nf;
+    float *D = PR + (size_t)nv * nf, *g = D + nc, *t1 = g + nc, *t2 = t1 + nc;
+    for (int v = 0; v < nv; ++v) memset(R + (size_t)v * ldr, 0, sizeof(float) * nc);
+    ibo_jst_sensor(p, P, f0, f1, t1, t2, D);  /* pressure sensor */
+    for (int d = 0; d < nd; ++d) {
+        for (int v = 0; v < nv; ++v) {
+            ibo_cell_gradient(p, P + (size_t)v * ldp, d, f0, g);
+            ibo_muscl(p, P + (size_t)v * ldp, g, d, D, PL + (size_t)v * nf, PR + (size_t)v * nf);
+        }
+#pragma omp parallel for schedule(static)
+        for (int32_t f = 0; f < p->nf[d]; ++f) {  /* CFD.inviscid_fluxes, HLL: the combine is Float64 (cfd.jl:504-507) */
+            float pl[5], pr[5], QL[5], FL[5], QR[5], FR[5], uL, aL, uR, aR;
+            for (int v = 0; v < nv; ++v) {
+                pl[v] = PL[(size_t)v * nf + f];
+                pr[v] = PR[(size_t)v * nf + f];
+            }
+            side_flux(nd, pl, d, Rg, gamma, QL, FL, &uL, &aL);
+            side_flux(nd, pr, d, Rg, gamma, QR, FR, &uR, &aR);
+            const double SR = fmin((double)(uR - aR), 0.0), SL = fmax((double)(uL + aL), 0.0);
+            for (int v = 0; v < nv; ++v)
+                F[(size_t)v * nf + f] = (SL * (double)FL[v] - SR * (double)FR[v] + SR * SL * (double)(QR[v] - QL[v])) / (SL - SR);
+        }
+        const float* h = p->spacing + (size_t)d * nc;
+        for (int v = 0; v < nv; ++v) {
+            const double* Fv = F + (size_t)v * nf;
+            float* Rv = R + (size_t)v * ldr;
+#pragma omp parallel for schedule(static)
+            for (int32_t c = 0; c < p->nc; ++c) {
+                const double gg = (acc_mean_d(p->roff[d], p->ridx[d], c, Fv) - acc_mean_d(p->loff[d], p->lidx[d], c, Fv)) /
+                                  (double)h[c];
+                Rv[c] = (float)((double)Rv[c] - gg);
+            }
+        }
+    }
+    free(w);
+    free(F);
     return 0;
 }

@@ -40,6 +40,9 @@ def lib():
         for f in (_lib.ibo_residual_advection_faithful, _lib.ibo_residual_advection_fused):
             f.restype = C.c_int
             f.argtypes = [C.POINTER(_Part), _f32p, _f32p, C.c_int64, _f32p]
+        _lib.ibo_residual_euler_faithful.restype = C.c_int
+        _lib.ibo_residual_euler_faithful.argtypes = [C.POINTER(_Part), _f32p, C.c_int64, C.c_float, C.c_float, _f32p,
+                                                     C.c_int64]
     return _lib
 
 
@@ -93,6 +96,20 @@ class CPart:
         if rc:
             raise MemoryError("oracle C sweep failed")
         return ud
+
+
+    def residual_euler(self, P, R=283.0, gamma=1.4, threads=None):
+        """R of the Euler sweep: P (nc, nd+2) = [p T u v (w)]; returns (nc, nd+2)."""
+        L = lib()
+        if threads:
+            L.ibo_set_threads(int(threads))
+        Pf = np.asfortranarray(P, dtype=np.float32)
+        out = np.empty(Pf.shape, dtype=np.float32, order="F")
+        rc = L.ibo_residual_euler_faithful(C.byref(self.c), Pf.ctypes.data_as(_f32p), self.nc, C.c_float(R),
+                                           C.c_float(gamma), out.ctypes.data_as(_f32p), self.nc)
+        if rc:
+            raise MemoryError("oracle C sweep failed")
+        return out
 
 
 def max_threads():

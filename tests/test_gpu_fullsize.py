@@ -76,6 +76,9 @@ def test_full_size_euler_sweep_variants_agree(full):
     one = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP))
     two = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP, flags=ibamd.IBH_NO_FUSE))
     gen = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP, flags=ibamd.IBH_FORCE_GENERAL))  # literal, Float64 HLL
+    from oracle import residual_c as rc
+    exp = rc.CPart(part).residual_euler(P)          # the C restatement on the whole mesh
+    assert np.array_equal(gen, exp)                 # literal arithmetic: bit for bit, Float64 HLL combine included
     for v in range(4):
-        assert rel_inf(two[:, v], gen[:, v]) <= 1e-5, v
-        assert rel_inf(one[:, v], gen[:, v]) <= 1e-5, v
+        assert rel_inf(two[:, v], exp[:, v]) <= 1e-5, v
+        assert rel_inf(one[:, v], exp[:, v]) <= 1e-5, v

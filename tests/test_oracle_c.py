@@ -43,3 +43,19 @@ def test_c_restatement_3d():
     exp = oracle_advection_residual(op, u, C)
     got = rc.CPart(part).residual_advection(u, C, threads=2)
     assert np.array_equal(got, exp)
+
+
+def test_c_euler_restatement_equals_numpy_restatement(adv_domains, rae_domains):
+    """Euler sweep (R2): the C restatement reproduces the numpy composition (JST sensor, cell_gradient, MUSCL,
+    HLL with its Float64 combine, green_gauss) bit for bit."""
+    from conftest import euler_field
+    from oracle import cfd as ocfd
+    from test_gpu_residual import oracle_euler_residual
+    for _, do in (adv_domains, rae_domains):
+        for k, opart in do.partitions.items():
+            P = euler_field(opart.centers)
+            exp = oracle_euler_residual(opart, P, ocfd.Fluid())
+            cp = rc.CPart(opart)
+            for threads in (1, 3):
+                got = cp.residual_euler(P, threads=threads)
+                assert np.array_equal(got, exp), (k, threads)
