@@ -644,6 +644,28 @@ __global__ __launch_bounds__(512) void k_passB3_adv_blk(PartView p, const float*
     }
 }
 
+// wave-per-block form of the 3-D scalar pass A (blk3::passA_wave): 4 blocks per 256-thread workgroup
+__global__ __launch_bounds__(256) void k_passA3_wave(PartView p, const float* __restrict__ u, float* __restrict__ G,
+                                                     const BlockDesc3* __restrict__ blocks,
+                                                     const int32_t* __restrict__ htab,
+                                                     const int32_t* __restrict__ ftab, int32_t nblk, int32_t nwg,
+                                                     const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
+    __shared__ float lds[4 * BLK3W_PASSA_LDS];
+    const int32_t gI = (ncells + 255) / 256;
+    if ((int32_t)blockIdx.x >= gI) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x - gI, nwg) * 4 + wave);
+        if (blk < nblk)
+            blk3::passA_wave(blocks, htab, ftab, blk, (uint32_t)p.nc, u, G, lds + wave * BLK3W_PASSA_LDS, lane);
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ncells) {
+        if (flat.rec) passA_flat<3, 1>(p, flat, (int32_t)t, cells[t], u, (int64_t)p.nc, G);
+        else passA_cell<3, 1>(p, u, (int64_t)p.nc, G, cells[t]);
+    }
+}
+
 // 3-D Euler block kernels (5 primitives): same launch layout as the scalar 3-D kernels
 __global__ __launch_bounds__(512) void k_passA3e_blk(PartView p, const float* __restrict__ P, int64_t ldp,
                                                      float* __restrict__ G, const BlockDesc3* __restrict__ blocks,
@@ -700,6 +722,8 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_euler(PartView p, const floa
     passB_euler_cell<ND>(p, P, ldp, G, R, ldr, Rgas, gamma, c);
 }
 
+// 1: wave-per-block form of the 3-D scalar pass A (IBH_3D_WAVE=0 for the 512-thread form, A/B)
+const int ibh_3d_wave = getenv("IBH_3D_WAVE") ? atoi(getenv("IBH_3D_WAVE")) : 1;
 // blocks per wave of the single-kernel sweep; 0 = automatic (IBH_SWEEP_ITERS overrides, for tuning)
 const int ibh_sweep_iters = getenv("IBH_SWEEP_ITERS") ? atoi(getenv("IBH_SWEEP_ITERS")) : 0;
 
@@ -751,7 +775,12 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         PartView v = view(p);
         const bool doA = !(flags & IBH_PASS_B_ONLY), doB = !(flags & IBH_PASS_A_ONLY);
         const int32_t gI = (nI + 511) / 512;
-        if (doA && (a1 > a0 || gI))
+        if (doA && (a1 > a0 || gI) && ibh_3d_wave) {
+            const int32_t nwgA = (a1 - a0 + 3) / 4, gIw = (nI + 255) / 256;
+            hipLaunchKernelGGL(k_passA3_wave, dim3(nwgA + gIw), dim3(256), 0, ibh_stream, v, u, p->G, p->blocks3 + a0,
+                               p->htab3 + (size_t)a0 * 384, p->ftab3, a1 - a0, nwgA, p->irr_cells, nI,
+                               flat_of(p, p->irr_cells));
+        } else if (doA && (a1 > a0 || gI))
             hipLaunchKernelGGL(k_passA3_blk, dim3(a1 - a0 + gI), dim3(512), 0, ibh_stream, v, u, p->G, p->blocks3 + a0,
                                p->htab3 + (size_t)a0 * 384, p->ftab3, a1 - a0, p->irr_cells, nI, flat_of(p, p->irr_cells));
         if (doB && (b1 > b0 || gI))
