@@ -690,6 +690,117 @@ __device__ __forceinline__ void passA_wave(const BlockDesc3* __restrict__ blocks
     }
 }
 
+// the same for NV variables (Euler: 5 primitives), one variable after the other through the same LDS region;
+// G layout of the face-list kernels: grad of var v along dim d at G[(d*NV + v)*nc + c], sensor of var 0 at G[3*NV*nc + c]
+template <int NV>
+__device__ __forceinline__ void passA_wave_nv(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                              const int32_t* __restrict__ ftab, int32_t blk, uint32_t nc,
+                                              const float* __restrict__ P, uint32_t ldp, float* __restrict__ G,
+                                              float* lds, int lane) {
+    const BlockDesc3 bb = blocks[blk];
+    float* tile = lds;          // [k][lane]
+    float* Hm = lds + 512;      // [side][t]: mean neighbour value across the side
+    float* Ha = lds + 896;      // [side][t]: mean |neighbour - boundary cell|
+    // this lane loads slot t = lane of every side
+    uint32_t hid[6];
+    hid[0] = halo_cell3s<0>(bb, htab, blk, lane);
+    hid[1] = halo_cell3s<1>(bb, htab, blk, lane);
+    hid[2] = halo_cell3s<2>(bb, htab, blk, lane);
+    hid[3] = halo_cell3s<3>(bb, htab, blk, lane);
+    hid[4] = halo_cell3s<4>(bb, htab, blk, lane);
+    hid[5] = halo_cell3s<5>(bb, htab, blk, lane);
+    const int i = lane & 7, j = lane >> 3;
+    const bool e0 = i == 0, e1 = i == 7, e2 = j == 0, e3 = j == 7;
+    const bool general = (e0 && bb.type[0] == SIDE_GENERAL) || (e1 && bb.type[1] == SIDE_GENERAL) ||
+                         (e2 && bb.type[2] == SIDE_GENERAL) || (e3 && bb.type[3] == SIDE_GENERAL);
+    const float q0 = e0 ? bb.q[0] : 0.5f, q1 = e1 ? bb.q[1] : 0.5f, q2 = e2 ? bb.q[2] : 0.5f, q3 = e3 ? bb.q[3] : 0.5f;
+    // all loads of the block up front (one memory trip), then one variable after the other through the LDS region
+    float uka[NV][8], hva[NV][6];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float* Pv = P + (size_t)v * ldp;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) uka[v][k] = ldg(Pv, (uint32_t)bb.base + lane + 64 * k);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) hva[v][s] = ldg(Pv, hid[s]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+    const float* u = P + (size_t)v * ldp;
+    float uk[8], hv[6];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) uk[k] = uka[v][k];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) hv[s] = hva[v][s];
+    if (v) blk2::wave_lds_sync();  // the previous variable's LDS reads are done
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[k * 64 + lane] = uk[k];
+    blk2::wave_lds_sync();
+    // reduce every slot to (mean value, mean |difference|) against its boundary cell: slot t of side s belongs to
+    // cell pos(s, t) = n*sd + t1*sa + t2*sb of the tile
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int d = s >> 1;
+        const bool low = (s & 1) == 0;
+        const int sd = d == 0 ? 1 : d == 1 ? 8 : 64, sa = d == 0 ? 8 : 1, sb = d == 2 ? 8 : 64;
+        const int pos = (low ? 0 : 7) * sd + (lane & 7) * sa + (lane >> 3) * sb;
+        const float ub = tile[pos];
+        float vm = hv[s], am = fabsf(hv[s] - ub);
+        if (bb.type[s] == SIDE_FINE) {  // wave-uniform: three more fine cells behind this slot
+            const int32_t* ft = ftab + (((size_t)bb.fine * 6 + s) * 64 + lane) * 3;
+            const float v1 = ldg(u, (uint32_t)ft[0]), v2 = ldg(u, (uint32_t)ft[1]), v3 = ldg(u, (uint32_t)ft[2]);
+            vm = 0.25f * (hv[s] + v1 + v2 + v3);
+            am = 0.25f * (fabsf(hv[s] - ub) + fabsf(v1 - ub) + fabsf(v2 - ub) + fabsf(v3 - ub));
+        }
+        Hm[s * 64 + lane] = vm;
+        Ha[s * 64 + lane] = am;
+    }
+    blk2::wave_lds_sync();
+    const float zlm = Hm[4 * 64 + lane], zla = Ha[4 * 64 + lane], zhm = Hm[5 * 64 + lane], zha = Ha[5 * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float uc = uk[k];
+        const float* tk = tile + k * 64;
+        // x, y: inside the plane or the side's reduced slot (x sides: t = j + 8k, y sides: t = i + 8k)
+        float vm[6], am[6];
+        vm[0] = e0 ? Hm[0 * 64 + j + 8 * k] : tk[lane - 1];
+        vm[1] = e1 ? Hm[1 * 64 + j + 8 * k] : tk[lane + 1];
+        vm[2] = e2 ? Hm[2 * 64 + i + 8 * k] : tk[lane - 8];
+        vm[3] = e3 ? Hm[3 * 64 + i + 8 * k] : tk[lane + 8];
+        am[0] = e0 ? Ha[0 * 64 + j + 8 * k] : fabsf(vm[0] - uc);
+        am[1] = e1 ? Ha[1 * 64 + j + 8 * k] : fabsf(vm[1] - uc);
+        am[2] = e2 ? Ha[2 * 64 + i + 8 * k] : fabsf(vm[2] - uc);
+        am[3] = e3 ? Ha[3 * 64 + i + 8 * k] : fabsf(vm[3] - uc);
+        // z: registers
+        vm[4] = k == 0 ? zlm : uk[k > 0 ? k - 1 : 0];
+        am[4] = k == 0 ? zla : fabsf(vm[4] - uc);
+        vm[5] = k == 7 ? zhm : uk[k < 7 ? k + 1 : 7];
+        am[5] = k == 7 ? zha : fabsf(vm[5] - uc);
+        const float ql[3] = {q0, q2, k == 0 ? bb.q[4] : 0.5f}, qh[3] = {q1, q3, k == 7 ? bb.q[5] : 0.5f};
+        float D = 1e-7f, g[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float rh = bb.rh[d];
+            const float fr = uc + qh[d] * (vm[2 * d + 1] - uc);
+            const float fl = uc + ql[d] * (vm[2 * d] - uc);
+            g[d] = (fr - fl) * rh;
+            const float gg = ((vm[2 * d + 1] - uc) - (uc - vm[2 * d])) * rh;
+            const float ugg = (am[2 * d + 1] + am[2 * d]) * rh;
+            D = fmaxf(D, (1e-7f + fabsf(gg)) * __builtin_amdgcn_rcpf(1e-7f + ugg));
+        }
+        const bool gen = general || (k == 0 && bb.type[4] == SIDE_GENERAL) || (k == 7 && bb.type[5] == SIDE_GENERAL);
+        if (!gen) {
+            const uint32_t c = (uint32_t)bb.base + lane + 64 * k;
+            stg(G + (size_t)(0 * NV + v) * nc, c, g[0]);
+            stg(G + (size_t)(1 * NV + v) * nc, c, g[1]);
+            stg(G + (size_t)(2 * NV + v) * nc, c, g[2]);
+            if (v == 0) stg(G + (size_t)(3 * NV) * nc, c, D);
+        }
+    }
+    }
+}
+
+
 #pragma clang fp contract(off)
 
 }  // namespace blk3

@@ -666,6 +666,29 @@ __global__ __launch_bounds__(256) void k_passA3_wave(PartView p, const float* __
     }
 }
 
+// wave-per-block form of the 3-D Euler pass A (blk3::passA_wave_nv<5>)
+__global__ __launch_bounds__(256) void k_passA3e_wave(PartView p, const float* __restrict__ P, int64_t ldp,
+                                                      float* __restrict__ G, const BlockDesc3* __restrict__ blocks,
+                                                      const int32_t* __restrict__ htab,
+                                                      const int32_t* __restrict__ ftab, int32_t nblk, int32_t nwg,
+                                                      const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
+    __shared__ float lds[4 * BLK3W_PASSA_LDS];
+    const int32_t gI = (ncells + 255) / 256;
+    if ((int32_t)blockIdx.x >= gI) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x - gI, nwg) * 4 + wave);
+        if (blk < nblk)
+            blk3::passA_wave_nv<5>(blocks, htab, ftab, blk, (uint32_t)p.nc, P, (uint32_t)ldp, G,
+                                   lds + wave * BLK3W_PASSA_LDS, lane);
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ncells) {
+        if (flat.rec) passA_flat<3, 5>(p, flat, (int32_t)t, cells[t], P, ldp, G);
+        else passA_cell<3, 5>(p, P, ldp, G, cells[t]);
+    }
+}
+
 // 3-D Euler block kernels (5 primitives): same launch layout as the scalar 3-D kernels
 __global__ __launch_bounds__(512) void k_passA3e_blk(PartView p, const float* __restrict__ P, int64_t ldp,
                                                      float* __restrict__ G, const BlockDesc3* __restrict__ blocks,
@@ -978,7 +1001,11 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
         // 3-D block path: block kernels + the face-list kernels over the cells the analysis left out
         const int32_t nI = p->n_irr;
         const int32_t gI = (nI + 511) / 512;
-        if (!(flags & IBH_PASS_B_ONLY))
+        if (!(flags & IBH_PASS_B_ONLY) && ibh_3d_wave) {
+            const int32_t nwgA = (p->nblk + 3) / 4, gIw = (nI + 255) / 256;
+            hipLaunchKernelGGL(k_passA3e_wave, dim3(nwgA + gIw), dim3(256), 0, ibh_stream, v, P, ldp, p->G, p->blocks3,
+                               p->htab3, p->ftab3, p->nblk, nwgA, p->irr_cells, nI, flat_of(p, p->irr_cells));
+        } else if (!(flags & IBH_PASS_B_ONLY))
             hipLaunchKernelGGL(k_passA3e_blk, dim3(p->nblk + gI), dim3(512), 0, ibh_stream, v, P, ldp, p->G, p->blocks3,
                                p->htab3, p->ftab3, p->nblk, p->irr_cells, nI, flat_of(p, p->irr_cells));
         if (!(flags & IBH_PASS_A_ONLY)) {
