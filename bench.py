@@ -255,7 +255,6 @@ def main():
     # (N > 1: only with the xgmi exchange, which is kernels only; RCCL calls are launched eagerly.)
     graphable = world == 1 or halo_kind == "xgmi-direct"
     batch = args.graph_batch if (graphable and args.graph_batch > 0) else 0
-    batch -= batch % 2  # the xgmi exchange alternates two receive buffers: capture whole pairs
     graph = None
     side = torch.cuda.Stream()
     if batch:
@@ -280,7 +279,7 @@ def main():
         with torch.cuda.stream(side):
             for _ in range(nsteps // batch):
                 graph.replay()
-            for _ in range(nsteps % batch):  # (even remainders only when the xgmi exchange is in the graph)
+            for _ in range(nsteps % batch):  # (the exchange kernel keeps its buffer parity on the device: any mix works)
                 step()
 
     run(args.warmup)

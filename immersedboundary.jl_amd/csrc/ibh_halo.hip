@@ -134,23 +134,37 @@ __global__ void k_halo_pull(float* __restrict__ f, int nv, int64_t ld, const int
 // push and pull in ONE launch: every workgroup packs its share for the peers, the last one to finish signals;
 // then every workgroup waits for the peers' flags and unpacks its share.  All workgroups are resident (<= 64) and
 // the push part waits for nothing, so ranks running this kernel at the same time cannot block each other.
+struct XchgArgs {
+    float* dst[2][IBH_MAX_PEERS];     // peer receive buffers for the two parities (my offset applied)
+    uint32_t* sflag[IBH_MAX_PEERS];   // my slot in the peers' flag arrays
+    const uint32_t* rflag[IBH_MAX_PEERS];  // local flag slot of each source peer
+    int32_t sseg[IBH_MAX_PEERS + 1], rseg[IBH_MAX_PEERS + 1];
+    int32_t ns, nr;
+};
 __global__ void k_halo_exchange(float* __restrict__ f, int nv, int64_t ld, const int32_t* __restrict__ send_all,
-                                PushArgs P, const int32_t* __restrict__ recv_all, const float* __restrict__ src,
-                                PullArgs R, uint32_t* __restrict__ state, uint32_t max_spins) {
-    __shared__ uint32_t last, seq, exp;
-    const int32_t stotal = P.n ? P.seg[P.n] : 0;
+                                const int32_t* __restrict__ recv_all, const float* __restrict__ src0,
+                                const float* __restrict__ src1, XchgArgs A, uint32_t* __restrict__ state,
+                                uint32_t max_spins) {
+    __shared__ uint32_t last, seq, exp, par;
+    if (threadIdx.x == 0) {
+        // the parity of the double buffer comes from the device-side sequence number, so graph replays and eager
+        // launches can be mixed freely; state[0] / state[1] advance only after every workgroup has read them
+        par = state[0] & 1u;
+        exp = state[1] + 1u;
+    }
+    __syncthreads();
+    const uint32_t pp = par;
+    const int32_t stotal = A.ns ? A.sseg[A.ns] : 0;
     for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < stotal; t += gridDim.x * blockDim.x) {
-        const int q = seg_of(P.seg, P.n, t);
-        const int32_t i = t - P.seg[q], nq = P.seg[q + 1] - P.seg[q];
+        const int q = seg_of(A.sseg, A.ns, t);
+        const int32_t i = t - A.sseg[q], nq = A.sseg[q + 1] - A.sseg[q];
         const int32_t c = send_all[t];
-        for (int v = 0; v < nv; ++v) P.dst[q][i + (int64_t)v * nq] = f[c + (int64_t)v * ld];
+        float* d = pp ? A.dst[1][q] : A.dst[0][q];
+        for (int v = 0; v < nv; ++v) d[i + (int64_t)v * nq] = f[c + (int64_t)v * ld];
     }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) {
-        last = atomicAdd(&state[3], 1u) == gridDim.x - 1 ? 1u : 0u;
-        exp = state[1] + 1u;  // advanced only by the last workgroup to finish the pull part
-    }
+    if (threadIdx.x == 0) last = atomicAdd(&state[3], 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (last) {
         if (threadIdx.x == 0) {
@@ -160,11 +174,11 @@ __global__ void k_halo_exchange(float* __restrict__ f, int nv, int64_t ld, const
         }
         __syncthreads();
         __threadfence_system();
-        if ((int)threadIdx.x < P.n)
-            __hip_atomic_store(P.flag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)threadIdx.x < A.ns)
+            __hip_atomic_store(A.sflag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if ((int)threadIdx.x < R.n) {
-        const uint32_t* s = R.flag[threadIdx.x];
+    if ((int)threadIdx.x < A.nr) {
+        const uint32_t* s = A.rflag[threadIdx.x];
         uint32_t spins = 0;
         while (__hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < exp) {
             if (++spins >= max_spins) {  // bounded: every wave reaches the exit
@@ -176,11 +190,12 @@ __global__ void k_halo_exchange(float* __restrict__ f, int nv, int64_t ld, const
     }
     __syncthreads();
     __threadfence_system();
-    const int32_t rtotal = R.n ? R.seg[R.n] : 0;
+    const float* src = pp ? src1 : src0;
+    const int32_t rtotal = A.nr ? A.rseg[A.nr] : 0;
     for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < rtotal; t += gridDim.x * blockDim.x) {
-        const int q = seg_of(R.seg, R.n, t);
-        const int32_t i = t - R.seg[q], nq = R.seg[q + 1] - R.seg[q];
-        const float* sq = src + (int64_t)R.seg[q] * nv;
+        const int q = seg_of(A.rseg, A.nr, t);
+        const int32_t i = t - A.rseg[q], nq = A.rseg[q + 1] - A.rseg[q];
+        const float* sq = src + (int64_t)A.rseg[q] * nv;
         const int32_t c = recv_all[t];
         for (int v = 0; v < nv; ++v) f[c + (int64_t)v * ld] = __builtin_nontemporal_load(sq + i + (int64_t)v * nq);
     }
@@ -290,43 +305,42 @@ int ibh_halo_pull(float* f, int nv, int64_t ld, const int32_t* recv_all, const f
 }
 
 int ibh_halo_exchange(float* f, int nv, int64_t ld, const int32_t* send_all, int n_send_peers, const int32_t* send_seg,
-                      float* const* dst, uint32_t* const* send_flags, const int32_t* recv_all, const float* src,
-                      int n_recv_peers, const int32_t* recv_seg, const uint32_t* const* recv_flags, uint32_t* state,
-                      uint32_t max_spins) {
+                      float* const* dst0, float* const* dst1, uint32_t* const* send_flags, const int32_t* recv_all,
+                      const float* src0, const float* src1, int n_recv_peers, const int32_t* recv_seg,
+                      const uint32_t* const* recv_flags, uint32_t* state, uint32_t max_spins) {
     IBH_REQUIRE(n_send_peers >= 0 && n_send_peers <= IBH_MAX_PEERS && n_recv_peers >= 0 && n_recv_peers <= IBH_MAX_PEERS,
                 "ibh_halo_exchange: at most 16 peers");
     if (n_send_peers == 0 && n_recv_peers == 0) return 0;
     IBH_REQUIRE(f && state && nv >= 1, "ibh_halo_exchange: bad argument");
-    PushArgs P;
-    PullArgs R;
-    memset(&P, 0, sizeof(P));
-    memset(&R, 0, sizeof(R));
-    P.n = n_send_peers;
-    R.n = n_recv_peers;
+    XchgArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ns = n_send_peers;
+    A.nr = n_recv_peers;
     if (n_send_peers) {
-        IBH_REQUIRE(send_all && send_seg && dst && send_flags, "ibh_halo_exchange: null send argument");
+        IBH_REQUIRE(send_all && send_seg && dst0 && dst1 && send_flags, "ibh_halo_exchange: null send argument");
         for (int q = 0; q < n_send_peers; ++q) {
-            P.dst[q] = dst[q];
-            P.flag[q] = send_flags[q];
-            P.seg[q] = send_seg[q];
+            A.dst[0][q] = dst0[q];
+            A.dst[1][q] = dst1[q];
+            A.sflag[q] = send_flags[q];
+            A.sseg[q] = send_seg[q];
             IBH_REQUIRE(send_seg[q + 1] >= send_seg[q], "ibh_halo_exchange: segments must ascend");
         }
-        P.seg[n_send_peers] = send_seg[n_send_peers];
+        A.sseg[n_send_peers] = send_seg[n_send_peers];
     }
     if (n_recv_peers) {
-        IBH_REQUIRE(recv_all && src && recv_seg && recv_flags, "ibh_halo_exchange: null receive argument");
+        IBH_REQUIRE(recv_all && src0 && src1 && recv_seg && recv_flags, "ibh_halo_exchange: null receive argument");
         for (int q = 0; q < n_recv_peers; ++q) {
-            R.flag[q] = recv_flags[q];
-            R.seg[q] = recv_seg[q];
+            A.rflag[q] = recv_flags[q];
+            A.rseg[q] = recv_seg[q];
             IBH_REQUIRE(recv_seg[q + 1] >= recv_seg[q], "ibh_halo_exchange: segments must ascend");
         }
-        R.seg[n_recv_peers] = recv_seg[n_recv_peers];
+        A.rseg[n_recv_peers] = recv_seg[n_recv_peers];
     }
-    const int32_t big = std::max(P.n ? P.seg[P.n] : 0, R.n ? R.seg[R.n] : 0);
+    const int32_t big = std::max(A.ns ? A.sseg[A.ns] : 0, A.nr ? A.rseg[A.nr] : 0);
     int g = (big + 255) / 256;
     g = g < 1 ? 1 : g > 64 ? 64 : g;  // every workgroup polls the flags: few, and all resident
-    hipLaunchKernelGGL(k_halo_exchange, dim3(g), dim3(256), 0, ibh_stream, f, nv, ld, send_all, P, recv_all, src, R, state,
-                       max_spins);
+    hipLaunchKernelGGL(k_halo_exchange, dim3(g), dim3(256), 0, ibh_stream, f, nv, ld, send_all, recv_all, src0, src1, A,
+                       state, max_spins);
     IBH_LAUNCH_CHECK();
     return 0;
 }

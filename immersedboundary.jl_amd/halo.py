@@ -279,13 +279,14 @@ class XgmiHalo:
         f, fnv, ld = B._field(field)
         if fnv != nv:
             raise ValueError(f"XgmiHalo was built for nv={nv}")
-        par = self.step & 1
         self.step += 1
+        par = 0  # (the kernel picks the buffer parity from its own sequence number)
         B._stream()
         if self.peers_send or self.peers_recv:
             B.call("ibh_halo_exchange", B._ptr(f), nv, ld, B._ptr(self.send_all), len(self.peers_send),
-                   C.cast(self._sseg, B.c_vp), C.cast(self._dst[par], B.c_vp), C.cast(self._sflags, B.c_vp),
-                   B._ptr(self.recv_all), B.c_vp(self._recv.value + 4 * par * self.n_recv_f), len(self.peers_recv),
+                   C.cast(self._sseg, B.c_vp), C.cast(self._dst[0], B.c_vp), C.cast(self._dst[1], B.c_vp),
+                   C.cast(self._sflags, B.c_vp), B._ptr(self.recv_all), B.c_vp(self._recv.value),
+                   B.c_vp(self._recv.value + 4 * self.n_recv_f), len(self.peers_recv),
                    C.cast(self._rseg, B.c_vp), C.cast(self._rflags, B.c_vp), B.c_vp(self.state.data_ptr()),
                    self.max_spins)
         return (f, ld, par)

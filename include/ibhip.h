@@ -232,11 +232,13 @@ int ibh_halo_push(const float* f, int nv, int64_t ld, const int32_t* send_all, i
 int ibh_halo_pull(float* f, int nv, int64_t ld, const int32_t* recv_all, const float* src, int n_peers,
                   const int32_t* seg, const uint32_t* const* flags, uint32_t* state, uint32_t max_spins);
 /* push + pull in ONE launch (the same two steps; ranks running it concurrently cannot block each other: the push part
- * waits for nothing).  Sends rows of f, receives into other rows of f. */
+ * waits for nothing).  Sends rows of f, receives into other rows of f.  dst0/dst1, src0/src1: the two parities of
+ * the double buffer; which one a launch uses follows the device-side sequence number (state[0] & 1), so graph
+ * replays and eager launches can be mixed. */
 int ibh_halo_exchange(float* f, int nv, int64_t ld, const int32_t* send_all, int n_send_peers, const int32_t* send_seg,
-                      float* const* dst, uint32_t* const* send_flags, const int32_t* recv_all, const float* src,
-                      int n_recv_peers, const int32_t* recv_seg, const uint32_t* const* recv_flags, uint32_t* state,
-                      uint32_t max_spins);
+                      float* const* dst0, float* const* dst1, uint32_t* const* send_flags, const int32_t* recv_all,
+                      const float* src0, const float* src1, int n_recv_peers, const int32_t* recv_seg,
+                      const uint32_t* const* recv_flags, uint32_t* state, uint32_t max_spins);
 
 /* ---- small device-resident vector ops for the FAS loop (solver.jl:79-88) ---------- */
 /* q += clamp(omega,0,1) * r ; omega scalar */
