@@ -182,8 +182,8 @@ def main():
     ud = torch.zeros(dpart.nc, dtype=torch.float32, device=u.device)
     euler = args.residual == "euler"
     if euler:
-        if world > 1:
-            raise SystemExit("--residual euler is a single-GPU secondary measurement")
+        if world > 1 and msh.ndims == 3:
+            raise SystemExit("3-D workloads: one GPU only (secondary measurement)")
         rng = np.random.default_rng(12345)
         n = part.centers.shape[0]
         nvp = msh.ndims + 2
@@ -198,7 +198,7 @@ def main():
     flags |= ibamd.IBH_NO_FUSE if args.no_fuse else 0
     # a rank of a multi-GPU run needs the residual on its image cells only (what dom(f, args...) scatters back,
     # ImmersedBoundary.jl:842-845): with every image block eligible that is one launch per overlap phase
-    image_only = (world > 1 and not euler and flags == 0 and dpart.info["image_blocks_all_eligible"]
+    image_only = (world > 1 and flags == 0 and dpart.info["image_blocks_all_eligible"]
                   and not args.all_cells)
     if image_only:
         flags |= ibamd.IBH_IMAGE_ONLY
@@ -207,14 +207,16 @@ def main():
     comm_stream = None
     halo_kind = None
     if world > 1:
-        from ibamd.halo import HaloExchange, HaloPlan, XgmiHalo, sweep_overlapped, verify_exchangers
+        from ibamd.halo import (HaloExchange, HaloPlan, XgmiHalo, euler_sweep_overlapped, sweep_overlapped,
+                                verify_exchangers)
         plan = HaloPlan(dom, rank + 1)
         hx = HaloExchange(plan, u.device)
         halo_kind = "rccl" if args.backend == "nccl" else "gloo-staged"
         if args.halo in ("auto", "xgmi"):
             try:
-                xg = XgmiHalo(plan, dom, u.device, nv=1)
-                good = verify_exchangers(xg, hx, dpart.nc, 1, rounds=3) and xg.healthy()
+                nvx = (msh.ndims + 2) if euler else 1
+                xg = XgmiHalo(plan, dom, u.device, nv=nvx)
+                good = verify_exchangers(xg, hx, dpart.nc, nvx, rounds=3) and xg.healthy()
                 if good:
                     hx, halo_kind = xg, "xgmi-direct"
                 elif args.halo == "xgmi":
@@ -238,11 +240,13 @@ def main():
     def step():
         if hx is None:
             sweep()
+        elif comm_stream is not None and euler:
+            euler_sweep_overlapped(hx, dpart, P, Rres, comm_stream, flags=flags)
         elif comm_stream is not None:
             sweep_overlapped(hx, dpart, u, C, ud, comm_stream, flags=flags)
         else:
-            hx.exchange(u)
-            ibamd.residual_advection(dpart, u, C, out=ud, flags=flags)
+            hx.exchange(P if euler else u)
+            sweep()
 
     def barrier():
         torch.cuda.synchronize()
@@ -374,9 +378,9 @@ def main():
     # HBM-side traffic of one launch of the dominant kernel from the committed PMC passes of this build (separate
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
     # calibrated against the kernel's known tile loads); null if not profiled.
-    kernel = ("k_passB3e_blk" if (euler and is3d) else "k_sweep_euler" if fused_e else "k_passB_euler_blk" if euler else
+    kernel = ("k_passB3e_blk" if (euler and is3d) else "k_sweep_euler" if (fused_e or (image_only and euler)) else "k_passB_euler_blk" if euler else
               "k_passB3_adv_blk" if is3d else
-              "k_sweep_adv" if (fused or mixed or image_only) else "k_passB_adv<2,false>")
+              "k_sweep_adv" if (fused or mixed or (image_only and not euler)) else "k_passB_adv<2,false>")
     traffic = None
     pmc_extra = {}
     try:

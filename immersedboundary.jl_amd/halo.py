@@ -170,16 +170,31 @@ def sweep_overlapped(hx, dpart, u, C, ud, comm_stream, flags=0):
     after the exchange has landed (``IBH_PHASE_BOUNDARY``).  Interior blocks never read a skirt cell, so the
     unpack kernel and the interior kernels touch disjoint rows of ``u``.
     """
+    from . import backend as B
+    return overlapped(hx, u, comm_stream,
+                      lambda ph: B.residual_advection(dpart, u, C, out=ud, flags=flags | ph))
+
+
+def euler_sweep_overlapped(hx, dpart, P, R, comm_stream, flags=0, fluid=None):
+    """The same for the Euler sweep (``hx`` built for nv = nd + 2)."""
+    from . import backend as B
+    return overlapped(hx, P, comm_stream,
+                      lambda ph: B.residual_euler_hll(dpart, P, out=R, flags=flags | ph, fluid=fluid))
+
+
+def overlapped(hx, field, comm_stream, sweep_phase):
+    """Exchange ``field`` on ``comm_stream`` while ``sweep_phase(IBH_PHASE_INTERIOR)`` runs, then
+    ``sweep_phase(IBH_PHASE_BOUNDARY)``."""
     import torch
     from . import backend as B
     cur = torch.cuda.current_stream()
     comm_stream.wait_stream(cur)
     with torch.cuda.stream(comm_stream):
-        hx.finish(hx.start(u))
-    B.residual_advection(dpart, u, C, out=ud, flags=flags | B.IBH_PHASE_INTERIOR)
+        hx.finish(hx.start(field))
+    out = sweep_phase(B.IBH_PHASE_INTERIOR)
     cur.wait_stream(comm_stream)
-    B.residual_advection(dpart, u, C, out=ud, flags=flags | B.IBH_PHASE_BOUNDARY)
-    return ud
+    sweep_phase(B.IBH_PHASE_BOUNDARY)
+    return out
 
 
 class XgmiHalo:
