@@ -230,3 +230,20 @@ def test_flow_bc_in_impose_bc(rae_domains):
     assert not np.array_equal(got, P)
     for v in range(4):
         assert rel_inf(got[:, v], Po[:, v]) <= 1e-5
+
+
+def test_partition_pack_feeds_the_library(adv_domains, tmp_path):
+    """A Partition loaded from its pack (ibamd.pack) gives the same block analysis and the same sweep, bit for bit."""
+    from ibamd.pack import load_partition, save_partition
+    dp, _ = adv_domains
+    part = dp.partitions[2]
+    path = str(tmp_path / "p.npz")
+    save_partition(path, part)
+    back, _ = load_partition(path)
+    a, b = ibamd.to_backend(part, ibamd.hip), ibamd.to_backend(back, ibamd.hip)
+    assert a.info == b.info
+    u = seeded_field(part.centers)
+    C = np.ones((u.shape[0], 2), dtype=f32)
+    ra = ibamd.to_host(ibamd.residual_advection(a, ibamd.hip(u), ibamd.hip(C)))
+    rb = ibamd.to_host(ibamd.residual_advection(b, ibamd.hip(u), ibamd.hip(C)))
+    assert np.array_equal(ra, rb)
