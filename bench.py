@@ -139,7 +139,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange first, then the whole sweep")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: exchange on a second stream beside the interior blocks, boundary blocks after it. "
+                         "Off by default: inside a HIP graph the cross-stream fork/join costs ~15 us per step "
+                         "(scripts/mixed_ab.py), far more than the ~3 us it hides on partitions of this size")
+    ap.add_argument("--no-overlap", action="store_true", help="(default since the measurement above; kept for old command lines)")
     ap.add_argument("--halo", default="auto", choices=["auto", "rccl", "xgmi"],
                     help="N > 1 skirt exchange: rccl = grouped send/recv (eager launches); xgmi = direct peer writes "
                          "into IPC-mapped buffers + device flags, captured in HIP graphs; auto = xgmi if it "
@@ -228,7 +232,7 @@ def main():
                     raise
                 if rank == 0:
                     print(f"[bench] xgmi halo exchange unavailable ({e}); using {halo_kind}", file=sys.stderr)
-        overlap = not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
+        overlap = args.overlap and not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
         comm_stream = torch.cuda.Stream() if overlap else None
 
     def sweep(extra=0):

@@ -45,3 +45,48 @@ for phases, nofuse in ((False, False), (True, False), (False, True), (True, True
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 1000
     print(f"nparts={nparts} two_kernel_form={nofuse} phases={phases}: {dt * 1e6:.2f} us per sweep", dpart.info["fusable_blocks"], dpart.info["full_blocks"], dpart.info["irregular_cells"])
+
+# ---- what the cross-stream fork/join of the overlapped step costs inside a graph: a stand-in "exchange" (one small
+#      kernel: copy of the skirt rows) on a second stream beside the interior phase, vs everything on one stream
+skirt = np.ones(nc, bool); skirt[part.image_in_domain] = False
+sidx = torch.from_numpy(np.nonzero(skirt)[0].astype(np.int64)).cuda()
+buf = torch.zeros(sidx.numel(), dtype=torch.float32, device="cuda")
+comm = torch.cuda.Stream()
+IO = ibamd.IBH_IMAGE_ONLY
+
+
+def fake_exchange():
+    buf.copy_(u[sidx])          # one gather kernel standing in for ibh_halo_exchange
+
+
+def step_overlap():
+    cur = torch.cuda.current_stream()
+    comm.wait_stream(cur)
+    with torch.cuda.stream(comm):
+        fake_exchange()
+    ibamd.residual_advection(dpart, u, C, out=ud, flags=IO | ibamd.IBH_PHASE_INTERIOR)
+    cur.wait_stream(comm)
+    ibamd.residual_advection(dpart, u, C, out=ud, flags=IO | ibamd.IBH_PHASE_BOUNDARY)
+
+
+def step_serial():
+    fake_exchange()
+    ibamd.residual_advection(dpart, u, C, out=ud, flags=IO)
+
+
+for name, fn in (("exchange || interior, then boundary (two streams)", step_overlap), ("exchange, then whole sweep (one stream)", step_serial)):
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(20):
+                fn()
+        g.replay(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 1000
+    print(f"nparts={nparts} step with a stand-in exchange, {name}: {dt * 1e6:.2f} us")
