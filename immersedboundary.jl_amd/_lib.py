@@ -40,6 +40,10 @@ _SIGS = {
                              C.POINTER(c_vp), C.POINTER(c_vp), C.c_int32, c_vp, c_vp, c_int, c_int],
     "ibh_partition_destroy": [c_vp],
     "ibh_partition_info": [c_vp, C.POINTER(c_i64), c_int],
+    "ibh_analyze2_host": [C.POINTER(c_vp), C.c_int32, c_vp, c_vp, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_vp),
+                          C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_vp), C.c_int32, c_vp, c_vp, c_int],
+    "ibh_host2d_get": [c_vp, c_int, c_int, c_vp, c_i64, C.POINTER(c_i64)],
+    "ibh_host2d_destroy": [c_vp],
     "ibh_at_owners": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_at_neighbors": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_at_faces": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],

@@ -24,6 +24,99 @@ template int ibh_upload<float>(float**, const float*, size_t);
 template int ibh_upload<BlockDesc2>(BlockDesc2**, const BlockDesc2*, size_t);
 template int ibh_upload<BlockDesc3>(BlockDesc3**, const BlockDesc3*, size_t);
 
+static std::vector<int32_t> rebased(const int32_t* p, size_t n, int base) {
+    std::vector<int32_t> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = p[i] - base;
+    return v;
+}
+
+// Host-only part of ibh_partition_create for 2-D partitions: block analysis, launch lists, quads.  No HIP call in
+// here, so the CPU tests can run it through ibh_analyze2_host().
+struct Host2D {
+    std::vector<BlockDesc2> blocks;
+    std::vector<int32_t> irr, htab, etab, dtab, img, fz, ng, nf;
+    std::vector<char> fus, needg;
+    int32_t nph[2] = {0, 0};
+    int32_t n_img_int = 0, img_all_fz = 0, fuse_all = 0, n_fz_int = 0, n_ng_int = 0, n_nf_int = 0;
+    int64_t info[12] = {0};
+    QuadSet2 quads[2];  // 0: all blocks (fuse_all partitions), 1: image blocks (img_all_fz partitions)
+};
+struct ibh_host2d {
+    Host2D H;
+};
+
+static void analyze2_host(const HostPartView& v, int32_t n_image, const int32_t* image_in_domain, int index_base,
+                          Host2D& H) {
+    const int32_t nc = v.nc;
+    const bool have_img = n_image > 0 && image_in_domain;
+    std::vector<int32_t> none;
+    ibh_analyze_blocks2(v, H.blocks, H.irr, H.info, have_img ? image_in_domain : none.data(), have_img ? n_image : 0,
+                        H.nph, H.htab, H.etab, H.fus, H.needg, H.dtab);
+    const int32_t nb = (int32_t)H.blocks.size();
+    H.fuse_all = nb > 0 && H.irr.empty() && H.info[8] == (int64_t)nb;
+    std::vector<char> is_imgblk(nb, 0);
+    if (have_img) {  // image blocks: eligible, all of them?
+        std::vector<char> is_img(nc, 0);
+        for (int32_t k = 0; k < n_image; ++k) is_img[image_in_domain[k] - index_base] = 1;
+        bool all = true;
+        for (int32_t b = 0; b < nb; ++b)
+            if (is_img[H.blocks[b].base]) {
+                H.img.push_back(b);
+                is_imgblk[b] = 1;
+                H.n_img_int += b < H.nph[1];
+                all = all && H.fus[b];
+            }
+        H.img_all_fz = all && (int64_t)H.img.size() * 64 == (int64_t)n_image;
+        H.info[10] = H.img_all_fz;
+        H.info[11] = (int64_t)H.img.size();
+    }
+    if (!H.fuse_all && H.info[8] > 0)
+        for (int32_t b = 0; b < nb; ++b) {
+            if (H.fus[b]) { H.fz.push_back(b); H.n_fz_int += b < H.nph[1]; }
+            else { H.nf.push_back(b); H.n_nf_int += b < H.nph[1]; }
+            if (H.needg[b]) { H.ng.push_back(b); H.n_ng_int += b < H.nph[0]; }
+        }
+    H.info[9] = H.fuse_all ? 0 : (int64_t)H.ng.size();
+    if (H.fuse_all) ibh_build_quads2(H.blocks, H.htab, H.etab, H.fus, H.nph[1], H.quads[0]);
+    if (H.img_all_fz && !H.fuse_all) ibh_build_quads2(H.blocks, H.htab, H.etab, is_imgblk, H.nph[1], H.quads[1]);
+}
+
+static int make_view(HostPartView& v, int nd, int32_t nc, const float* spacing, const int32_t* nf,
+                     const int32_t* const* owners, const int32_t* const* neighbors, const int32_t* const* left_off,
+                     const int32_t* const* left_idx, const int32_t* const* right_off, const int32_t* const* right_idx,
+                     const int32_t* domain, int block_size, int index_base) {
+    v.nd = nd;
+    v.nc = nc;
+    v.spacing = spacing;
+    v.nf = nf;
+    v.domain = domain;
+    v.index_base = index_base;
+    v.bs = block_size;
+    v.owners.resize(nd); v.neighbors.resize(nd);
+    v.loff.resize(nd); v.lidx.resize(nd); v.roff.resize(nd); v.ridx.resize(nd);
+    for (int d = 0; d < nd; ++d) {
+        IBH_REQUIRE(nf[d] >= 0, "ibh_partition_create: negative face count");
+        v.owners[d] = rebased(owners[d], nf[d], index_base);
+        v.neighbors[d] = rebased(neighbors[d], nf[d], index_base);
+        // offsets: accept either base (first entry tells)
+        int32_t ob = left_off[d][0];
+        v.loff[d] = rebased(left_off[d], (size_t)nc + 1, ob);
+        v.lidx[d] = rebased(left_idx[d], v.loff[d][nc], index_base);
+        ob = right_off[d][0];
+        v.roff[d] = rebased(right_off[d], (size_t)nc + 1, ob);
+        v.ridx[d] = rebased(right_idx[d], v.roff[d][nc], index_base);
+        for (int32_t f = 0; f < nf[d]; ++f)
+            IBH_REQUIRE(v.owners[d][f] >= 0 && v.owners[d][f] < nc && v.neighbors[d][f] >= 0 && v.neighbors[d][f] < nc,
+                        "ibh_partition_create: owner/neighbour index out of range");
+        for (int32_t c = 0; c < nc; ++c)
+            IBH_REQUIRE(v.loff[d][c + 1] >= v.loff[d][c] && v.roff[d][c + 1] >= v.roff[d][c],
+                        "ibh_partition_create: CSR offsets not monotone");
+        for (int32_t x : v.lidx[d]) IBH_REQUIRE(x >= 0 && x < nf[d], "ibh_partition_create: left face id out of range");
+        for (int32_t x : v.ridx[d]) IBH_REQUIRE(x >= 0 && x < nf[d], "ibh_partition_create: right face id out of range");
+    }
+    return 0;
+}
+
 extern "C" {
 
 int ibh_version(void) { return 100; }
@@ -73,11 +166,6 @@ int ibh_memset(void* dst, int value, size_t bytes) {
     return 0;
 }
 
-static std::vector<int32_t> rebased(const int32_t* p, size_t n, int base) {
-    std::vector<int32_t> v(n);
-    for (size_t i = 0; i < n; ++i) v[i] = p[i] - base;
-    return v;
-}
 
 int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacing, const float* centers,
                          const int32_t* nf, const int32_t* const* owners, const int32_t* const* neighbors,
@@ -89,39 +177,12 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
     IBH_REQUIRE(nd == 2 || nd == 3, "ibh_partition_create: nd must be 2 or 3");
     IBH_REQUIRE(nc >= 0 && (index_base == 0 || index_base == 1), "ibh_partition_create: bad nc/index_base");
     HostPartView v;
-    v.nd = nd;
-    v.nc = nc;
-    v.spacing = spacing;
-    v.nf = nf;
-    v.domain = domain;
-    v.index_base = index_base;
-    v.bs = block_size;
-    v.owners.resize(nd); v.neighbors.resize(nd);
-    v.loff.resize(nd); v.lidx.resize(nd); v.roff.resize(nd); v.ridx.resize(nd);
-    for (int d = 0; d < nd; ++d) {
-        IBH_REQUIRE(nf[d] >= 0, "ibh_partition_create: negative face count");
-        v.owners[d] = rebased(owners[d], nf[d], index_base);
-        v.neighbors[d] = rebased(neighbors[d], nf[d], index_base);
-        // offsets: accept either base (first entry tells)
-        int32_t ob = left_off[d][0];
-        v.loff[d] = rebased(left_off[d], (size_t)nc + 1, ob);
-        v.lidx[d] = rebased(left_idx[d], v.loff[d][nc], index_base);
-        ob = right_off[d][0];
-        v.roff[d] = rebased(right_off[d], (size_t)nc + 1, ob);
-        v.ridx[d] = rebased(right_idx[d], v.roff[d][nc], index_base);
-        for (int32_t f = 0; f < nf[d]; ++f)
-            IBH_REQUIRE(v.owners[d][f] >= 0 && v.owners[d][f] < nc && v.neighbors[d][f] >= 0 && v.neighbors[d][f] < nc,
-                        "ibh_partition_create: owner/neighbour index out of range");
-        for (int32_t c = 0; c < nc; ++c)
-            IBH_REQUIRE(v.loff[d][c + 1] >= v.loff[d][c] && v.roff[d][c + 1] >= v.roff[d][c],
-                        "ibh_partition_create: CSR offsets not monotone");
-        for (int32_t x : v.lidx[d]) IBH_REQUIRE(x >= 0 && x < nf[d], "ibh_partition_create: left face id out of range");
-        for (int32_t x : v.ridx[d]) IBH_REQUIRE(x >= 0 && x < nf[d], "ibh_partition_create: right face id out of range");
-    }
+    int rc = make_view(v, nd, nc, spacing, nf, owners, neighbors, left_off, left_idx, right_off, right_idx, domain,
+                       block_size, index_base);
+    if (rc) return rc;
     ibh_part* p = new ibh_part();
     p->nd = nd;
     p->nc = nc;
-    int rc = 0;
     if ((rc = ibh_upload(&p->spacing, spacing, (size_t)nc * nd))) return rc;
     if (centers && (rc = ibh_upload(&p->centers, centers, (size_t)nc * nd))) return rc;
     for (int d = 0; d < nd; ++d) {
@@ -142,61 +203,46 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
     }
     p->bs = 0;
     if (domain && block_size > 0 && nd == 2 && block_size == 8) {
-        std::vector<BlockDesc2> blocks;
-        std::vector<int32_t> irr;
-        int32_t nph[2] = {0, 0};
-        std::vector<int32_t> htab, etab, dtab;
-        std::vector<char> fus, needg;
-        if (n_image > 0 && image_in_domain)
-            ibh_analyze_blocks2(v, blocks, irr, p->info, image_in_domain, n_image, nph, htab, etab, fus, needg, dtab);
-        else {  // no image information: everything is "boundary"
-            std::vector<int32_t> none;
-            ibh_analyze_blocks2(v, blocks, irr, p->info, none.data(), 0, nph, htab, etab, fus, needg, dtab);
+        Host2D H;
+        analyze2_host(v, n_image, image_in_domain, index_base, H);
+        for (int i = 0; i < 12; ++i) p->info[i] = H.info[i];
+        if ((rc = ibh_upload(&p->htab, H.htab.data(), H.htab.size()))) return rc;
+        if ((rc = ibh_upload(&p->etab, H.etab.data(), H.etab.size()))) return rc;
+        if ((rc = ibh_upload(&p->dtab, H.dtab.data(), H.dtab.size()))) return rc;
+        p->n_dt = (int32_t)(H.dtab.size() / 64);
+        p->fuse_all = H.fuse_all;
+        p->n_img = (int32_t)H.img.size();
+        p->n_img_int = H.n_img_int;
+        p->img_all_fz = H.img_all_fz;
+        if (p->img_all_fz && (rc = ibh_upload(&p->img_list, H.img.data(), H.img.size()))) return rc;
+        if (!p->fuse_all && H.info[8] > 0) {
+            p->n_fz = (int32_t)H.fz.size();
+            p->n_ng = (int32_t)H.ng.size();
+            p->n_nf = (int32_t)H.nf.size();
+            p->n_fz_int = H.n_fz_int;
+            p->n_ng_int = H.n_ng_int;
+            p->n_nf_int = H.n_nf_int;
+            if ((rc = ibh_upload(&p->fz_list, H.fz.data(), H.fz.size()))) return rc;
+            if ((rc = ibh_upload(&p->ng_list, H.ng.data(), H.ng.size()))) return rc;
+            if ((rc = ibh_upload(&p->nf_list, H.nf.data(), H.nf.size()))) return rc;
         }
-        if ((rc = ibh_upload(&p->htab, htab.data(), htab.size()))) return rc;
-        if ((rc = ibh_upload(&p->etab, etab.data(), etab.size()))) return rc;
-        if ((rc = ibh_upload(&p->dtab, dtab.data(), dtab.size()))) return rc;
-        p->n_dt = (int32_t)(dtab.size() / 64);
-        p->fuse_all = !blocks.empty() && irr.empty() && p->info[8] == (int64_t)blocks.size();
-        if (n_image > 0 && image_in_domain) {  // image blocks: eligible, all of them?
-            std::vector<char> is_img(nc, 0);
-            for (int32_t k = 0; k < n_image; ++k) is_img[image_in_domain[k] - index_base] = 1;
-            std::vector<int32_t> img;
-            bool all = true;
-            for (int32_t b = 0; b < (int32_t)blocks.size(); ++b)
-                if (is_img[blocks[b].base]) {
-                    img.push_back(b);
-                    p->n_img_int += b < nph[1];
-                    all = all && fus[b];
-                }
-            p->n_img = (int32_t)img.size();
-            p->img_all_fz = all && (int64_t)img.size() * 64 == (int64_t)n_image;
-            if (p->img_all_fz && (rc = ibh_upload(&p->img_list, img.data(), img.size()))) return rc;
-            p->info[10] = p->img_all_fz;
-            p->info[11] = p->n_img;
+        for (int k = 0; k < 2; ++k) {
+            const QuadSet2& Q = H.quads[k];
+            p->nq[k] = (int32_t)Q.qd.size();
+            p->nq_int[k] = Q.nq_int;
+            p->nqs[k] = (int32_t)Q.singles.size();
+            p->nqs_int[k] = Q.ns_int;
+            if ((rc = ibh_upload(&p->qd[k], Q.qd.data(), Q.qd.size()))) return rc;
+            if ((rc = ibh_upload(&p->qtab[k], Q.qtab.data(), Q.qtab.size()))) return rc;
+            if ((rc = ibh_upload(&p->qsingles[k], Q.singles.data(), Q.singles.size()))) return rc;
         }
-        if (!p->fuse_all && p->info[8] > 0) {
-            std::vector<int32_t> fz, ng, nf;
-            for (int32_t b = 0; b < (int32_t)blocks.size(); ++b) {
-                if (fus[b]) { fz.push_back(b); p->n_fz_int += b < nph[1]; }
-                else { nf.push_back(b); p->n_nf_int += b < nph[1]; }
-                if (needg[b]) { ng.push_back(b); p->n_ng_int += b < nph[0]; }
-            }
-            p->n_fz = (int32_t)fz.size();
-            p->n_ng = (int32_t)ng.size();
-            p->n_nf = (int32_t)nf.size();
-            if ((rc = ibh_upload(&p->fz_list, fz.data(), fz.size()))) return rc;
-            if ((rc = ibh_upload(&p->ng_list, ng.data(), ng.size()))) return rc;
-            if ((rc = ibh_upload(&p->nf_list, nf.data(), nf.size()))) return rc;
-        }
-        p->info[9] = p->fuse_all ? 0 : p->n_ng;
-        p->nA1 = nph[0];
-        p->nB1 = nph[1];
+        p->nA1 = H.nph[0];
+        p->nB1 = H.nph[1];
         p->bs = block_size;
-        p->nblk = (int32_t)blocks.size();
-        p->n_irr = (int32_t)irr.size();
-        if ((rc = ibh_upload(&p->blocks2, blocks.data(), blocks.size()))) return rc;
-        if ((rc = ibh_upload(&p->irr_cells, irr.data(), irr.size()))) return rc;
+        p->nblk = (int32_t)H.blocks.size();
+        p->n_irr = (int32_t)H.irr.size();
+        if ((rc = ibh_upload(&p->blocks2, H.blocks.data(), H.blocks.size()))) return rc;
+        if ((rc = ibh_upload(&p->irr_cells, H.irr.data(), H.irr.size()))) return rc;
     } else if (domain && block_size == 8 && nd == 3) {
         std::vector<BlockDesc3> blocks;
         std::vector<int32_t> irr, htab, ftab;
@@ -250,6 +296,56 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
     return 0;
 }
 
+// ---- host-only introspection of the 2-D block analysis (no HIP call: runs without a GPU) ----
+int ibh_analyze2_host(ibh_host2d** out, int32_t nc, const float* spacing, const int32_t* nf,
+                      const int32_t* const* owners, const int32_t* const* neighbors, const int32_t* const* left_off,
+                      const int32_t* const* left_idx, const int32_t* const* right_off, const int32_t* const* right_idx,
+                      int32_t n_image, const int32_t* image_in_domain, const int32_t* domain, int index_base) {
+    IBH_REQUIRE(out && spacing && nf && owners && neighbors && left_off && left_idx && right_off && right_idx && domain,
+                "ibh_analyze2_host: null argument");
+    HostPartView v;
+    int rc = make_view(v, 2, nc, spacing, nf, owners, neighbors, left_off, left_idx, right_off, right_idx, domain, 8,
+                       index_base);
+    if (rc) return rc;
+    ibh_host2d* h = new ibh_host2d();
+    analyze2_host(v, n_image, image_in_domain, index_base, h->H);
+    *out = h;
+    return 0;
+}
+
+int ibh_host2d_get(const ibh_host2d* h, int what, int set, void* dst, int64_t cap_bytes, int64_t* nbytes) {
+    IBH_REQUIRE(h && nbytes && (set == 0 || set == 1), "ibh_host2d_get: bad argument");
+    const Host2D& H = h->H;
+    const QuadSet2& Q = H.quads[set];
+    const void* src = nullptr;
+    int64_t n = 0;
+    int64_t counts[8] = {(int64_t)H.blocks.size(), (int64_t)Q.qd.size(), Q.nq_int, (int64_t)Q.singles.size(), Q.ns_int,
+                         H.fuse_all, H.img_all_fz, H.nph[1]};
+    switch (what) {
+        case IBH_H2D_BLOCKS: src = H.blocks.data(); n = (int64_t)(H.blocks.size() * sizeof(BlockDesc2)); break;
+        case IBH_H2D_HTAB: src = H.htab.data(); n = (int64_t)(H.htab.size() * 4); break;
+        case IBH_H2D_ETAB: src = H.etab.data(); n = (int64_t)(H.etab.size() * 4); break;
+        case IBH_H2D_FUSABLE: src = H.fus.data(); n = (int64_t)H.fus.size(); break;
+        case IBH_H2D_QUAD_DESC: src = Q.qd.data(); n = (int64_t)(Q.qd.size() * sizeof(QuadDesc2)); break;
+        case IBH_H2D_QUAD_TAB: src = Q.qtab.data(); n = (int64_t)(Q.qtab.size() * 4); break;
+        case IBH_H2D_SINGLES: src = Q.singles.data(); n = (int64_t)(Q.singles.size() * 4); break;
+        case IBH_H2D_COUNTS: src = counts; n = (int64_t)sizeof(counts); break;
+        case IBH_H2D_INFO: src = H.info; n = (int64_t)sizeof(H.info); break;
+        default: return ibh_fail(-1, "ibh_host2d_get: unknown item", __FILE__, __LINE__);
+    }
+    *nbytes = n;
+    if (dst) {
+        IBH_REQUIRE(cap_bytes >= n, "ibh_host2d_get: destination too small");
+        if (n) memcpy(dst, src, (size_t)n);
+    }
+    return 0;
+}
+
+int ibh_host2d_destroy(ibh_host2d* h) {
+    delete h;
+    return 0;
+}
+
 int ibh_partition_destroy(ibh_part* p) {
     if (!p) return 0;
     hipFree(p->spacing);
@@ -265,6 +361,11 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->etab);
     hipFree(p->dtab);
     hipFree(p->img_list);
+    for (int k = 0; k < 2; ++k) {
+        hipFree(p->qd[k]);
+        hipFree(p->qtab[k]);
+        hipFree(p->qsingles[k]);
+    }
     hipFree(p->fz_list);
     hipFree(p->ng_list);
     hipFree(p->nf_list);

@@ -34,6 +34,27 @@ struct BlockDesc2 {  // 2-D
 // averaging the two sub-faces is exact), MIRROR sides name the boundary cell itself, GENERAL sides too
 // (their lanes are handled by the face-list body and never stored).
 
+// A "quad": 2x2 same-level complete blocks with consecutive bases (base, +64, +128, +192 = lower-left, lower-right,
+// upper-left, upper-right: the sibling order of the quadtree, mesher.jl:845-861) whose 8 outer half-sides are SAME /
+// COARSE / FINE.  One wavefront sweeps the 16x16 tile with 4 cells per lane (ibh_quad2d.h).
+// cls: 4 bits per outer half-side, index l = 2*g + half with g = 0 left (side 0), 1 bottom (side 2), 2 top (side 3),
+// 3 right (side 1) -- g is the 16-lane row that owns the side's halo slots -- and half = 0 for boundary cells 0..7.
+struct QuadDesc2 {
+    int32_t base;
+    uint32_t cls;
+    float rh[2];
+};
+// Per quad one row of IBH_QROW ints: [0,128) halo cell ids, entry 2*lane + k (lane = 16*g + t: side g, boundary cell t,
+// sub-face k); [128,160) end ids, entry 4*l + e (e = 0,1 low end k = 0,1; 2,3 high end) -- the per-block halo / end
+// tables of ibh_analyze.cpp re-indexed for the quad's lanes.
+#define IBH_QROW 160
+struct QuadSet2 {
+    std::vector<QuadDesc2> qd;     // interior-phase quads first (n_int of them)
+    std::vector<int32_t> qtab;     // [nq][IBH_QROW]
+    std::vector<int32_t> singles;  // candidate blocks outside quads (block table indices), interior-phase ones first
+    int32_t nq_int = 0, ns_int = 0;
+};
+
 // 3-D: one full 8x8x8 block (512 consecutive local ids).  side s = 2*d + (0 low / 1 high); boundary cell of a
 // side indexed t = t1 + 8*t2 over the two tangential dims in increasing order.  The 3-D fast path takes
 // SAME / MIRROR / COARSE (2:1) sides; sides facing finer blocks are GENERAL (face-list body), so every
@@ -80,6 +101,11 @@ struct ibh_part {
     int32_t* img_list = nullptr; // image blocks, ascending, the first n_img_int of them < nB1
     int32_t n_img = 0, n_img_int = 0, img_all_fz = 0;
     int32_t fuse_all = 0;        // 1: every block is eligible for the single-kernel sweep and there are no face-list cells
+    // quad sweeps (ibh_quad2d.h): set 0 = all blocks (used when fuse_all), set 1 = image blocks (used when img_all_fz)
+    QuadDesc2* qd[2] = {nullptr, nullptr};
+    int32_t* qtab[2] = {nullptr, nullptr};
+    int32_t* qsingles[2] = {nullptr, nullptr};
+    int32_t nq[2] = {0, 0}, nq_int[2] = {0, 0}, nqs[2] = {0, 0}, nqs_int[2] = {0, 0};
     // mixed launches (fuse_all == 0): ascending block indices, interior-phase entries first
     int32_t* fz_list = nullptr;  // eligible blocks                       [n_fz], the first n_fz_int of them < nB1
     int32_t* ng_list = nullptr;  // blocks whose gradients somebody reads [n_ng], the first n_ng_int of them < nA1
@@ -150,6 +176,10 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
                          int32_t n_image, int32_t* n_phase1, std::vector<int32_t>& htab,
                          std::vector<int32_t>& etab, std::vector<char>& fusable, std::vector<char>& needg,
                          std::vector<int32_t>& dtab);
+
+// quads among the candidate blocks (cand[b] != 0); blocks < nB1 are interior-phase blocks
+void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<int32_t>& htab,
+                      const std::vector<int32_t>& etab, const std::vector<char>& cand, int32_t nB1, QuadSet2& out);
 
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,

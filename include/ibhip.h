@@ -94,6 +94,30 @@ int ibh_partition_destroy(ibh_part* part);
  *       sweeps are then one launch per phase), [11] = image blocks. */
 int ibh_partition_info(const ibh_part* part, int64_t* info, int n);
 
+/* Host-only view of the 2-D block analysis ibh_partition_create runs (block table, halo / end tables, the 2x2 block
+ * groups of the quad sweep): same inputs, no device needed.  Test infrastructure for the library's host logic; not
+ * part of the reference's surface.  ibh_host2d_get copies item `what` (of quad set `set`: 0 = all blocks, 1 = image
+ * blocks) into dst (may be NULL to query *nbytes). */
+typedef struct ibh_host2d ibh_host2d;
+enum {
+    IBH_H2D_BLOCKS = 0,    /* block descriptors, 120 bytes each (struct BlockDesc2 of csrc/ibh_common.h) */
+    IBH_H2D_HTAB = 1,      /* int32 [nblk][64] halo cell ids */
+    IBH_H2D_ETAB = 2,      /* int32 [nblk][16] side-end cell ids */
+    IBH_H2D_FUSABLE = 3,   /* char  [nblk] eligible for the single-kernel sweep */
+    IBH_H2D_QUAD_DESC = 4, /* {int32 base; uint32 cls; float rh[2]} per quad */
+    IBH_H2D_QUAD_TAB = 5,  /* int32 [nq][160] */
+    IBH_H2D_SINGLES = 6,   /* int32 block indices outside quads */
+    IBH_H2D_COUNTS = 7,    /* int64 [8]: blocks, quads, interior quads, singles, interior singles, fuse_all, img_all_fz, nB1 */
+    IBH_H2D_INFO = 8       /* int64 [12] as ibh_partition_info */
+};
+int ibh_analyze2_host(ibh_host2d** out, int32_t nc, const float* spacing, const int32_t* nf,
+                      const int32_t* const* owners, const int32_t* const* neighbors,
+                      const int32_t* const* left_off, const int32_t* const* left_idx,
+                      const int32_t* const* right_off, const int32_t* const* right_idx,
+                      int32_t n_image, const int32_t* image_in_domain, const int32_t* domain, int index_base);
+int ibh_host2d_get(const ibh_host2d* h, int what, int set, void* dst, int64_t cap_bytes, int64_t* nbytes);
+int ibh_host2d_destroy(ibh_host2d* h);
+
 /* ---- grid operators on a Partition (ImmersedBoundary.jl:873-1157) ----------
  * `u`: (nc, nv) cell field; `uf`: (nf_dim, nv) face field.  Outputs are new
  * arrays supplied by the caller (the reference returns fresh arrays).        */
