@@ -232,6 +232,8 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
             p->nq_int[k] = Q.nq_int;
             p->nqs[k] = (int32_t)Q.singles.size();
             p->nqs_int[k] = Q.ns_int;
+            p->info[12 + 2 * k] = p->nq[k];
+            p->info[13 + 2 * k] = p->nqs[k];
             if ((rc = ibh_upload(&p->qd[k], Q.qd.data(), Q.qd.size()))) return rc;
             if ((rc = ibh_upload(&p->qtab[k], Q.qtab.data(), Q.qtab.size()))) return rc;
             if ((rc = ibh_upload(&p->qsingles[k], Q.singles.data(), Q.singles.size()))) return rc;
@@ -381,7 +383,7 @@ int ibh_partition_destroy(ibh_part* p) {
 
 int ibh_partition_info(const ibh_part* p, int64_t* info, int n) {
     IBH_REQUIRE(p && info, "ibh_partition_info: null argument");
-    for (int i = 0; i < n && i < 12; ++i) info[i] = p->info[i];
+    for (int i = 0; i < n && i < 16; ++i) info[i] = p->info[i];
     return 0;
 }
 

@@ -121,7 +121,7 @@ struct ibh_part {
     // rec[(q*5 + 1 + k)*n_irr + t] = the cell across its k-th face (accumulator order).  One coalesced read
     // replaces the offsets -> face ids -> owner/neighbour chain of the CSR walk.
     int32_t* irr_rec = nullptr;
-    int64_t info[12] = {0};
+    int64_t info[16] = {0};
     // workspace for per-cell gradients + sensor (pass A output)
     float* G = nullptr;
     size_t G_bytes = 0;

@@ -482,6 +482,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 
 #include "ibh_block2d.h"
 #include "ibh_sweep2d.h"
+#include "ibh_quad2d.h"
 #include "ibh_block3d.h"
 
 namespace {
@@ -577,6 +578,31 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(IBH_SW
     if (first >= nblk) return;
     const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPB - 1) / WPB));
     blk2::sweep_adv<DT>(blocks, htab, etab, dtab, blist, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
+}
+
+// Quad sweep (quad2::sweep_quad): one wavefront per 2x2 group of sibling blocks; the blocks outside such groups take
+// the per-block single kernel (blk2::sweep_adv) in the SAME launch.  grid = [quad workgroups | single-block workgroups].
+#define QUAD_WG_LDS (WPB * (QUAD_LDS > BLK2_SWEEP_LDS ? QUAD_LDS : BLK2_SWEEP_LDS))
+template <bool DT>
+__global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict__ u, const float* __restrict__ C,
+                                                         uint32_t ldc, float* __restrict__ ud,
+                                                         const QuadDesc2* __restrict__ qd,
+                                                         const int32_t* __restrict__ qtab, int32_t nq, int32_t nwgq,
+                                                         const BlockDesc2* __restrict__ blocks,
+                                                         const int32_t* __restrict__ htab,
+                                                         const int32_t* __restrict__ etab,
+                                                         const int32_t* __restrict__ dtab,
+                                                         const int32_t* __restrict__ singles, int32_t ns, int32_t nwgs) {
+    __shared__ __attribute__((aligned(16))) float lds[QUAD_WG_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if ((int32_t)blockIdx.x < nwgq) {
+        const int32_t q = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwgq) * WPB + wave);
+        if (q < nq) quad2::sweep_quad(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane);
+        return;
+    }
+    const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x - nwgq, nwgs) * WPB + wave);
+    if (first < ns)
+        blk2::sweep_adv<DT>(blocks, htab, etab, dtab, singles, first, WPB, 1, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
 }
 
 // Single-kernel Euler sweep (blk2::sweep_euler); 1 / 2 / 4 waves per workgroup measured equal within 2 %
@@ -749,6 +775,8 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_euler(PartView p, const floa
 const int ibh_3d_wave = getenv("IBH_3D_WAVE") ? atoi(getenv("IBH_3D_WAVE")) : 1;
 // blocks per wave of the single-kernel sweep; 0 = automatic (IBH_SWEEP_ITERS overrides, for tuning)
 const int ibh_sweep_iters = getenv("IBH_SWEEP_ITERS") ? atoi(getenv("IBH_SWEEP_ITERS")) : 0;
+// IBH_QUAD=0: per-block single kernel everywhere (A/B runs)
+const int ibh_quad = getenv("IBH_QUAD") ? atoi(getenv("IBH_QUAD")) : 1;
 
 PartView view(const ibh_part* p) {
     PartView v;
@@ -832,13 +860,33 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
             hipLaunchKernelGGL(k_sweep_adv<false>, dim3(nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud, bl, ht,
                                et, p->dtab, count, nwg, iters, ls);
     };
+    // quad sweep over quad set `k` (0: all blocks, 1: image blocks): `ph1`/`ph2` select the interior / boundary part
+    auto quads_ok = [&](int k) {
+        return ibh_quad && !(flags & IBH_NO_QUAD) && p->nq[k] > 0 && ldc % 4 == 0 &&
+               (((uintptr_t)u | (uintptr_t)C | (uintptr_t)ud) & 15) == 0;
+    };
+    auto launch_quads = [&](int k, bool ph1, bool ph2) {
+        const int32_t q0 = ph2 ? p->nq_int[k] : 0, q1 = ph1 ? p->nq_int[k] : p->nq[k];
+        const int32_t s0 = ph2 ? p->nqs_int[k] : 0, s1 = ph1 ? p->nqs_int[k] : p->nqs[k];
+        const int32_t nwgq = (q1 - q0 + WPB - 1) / WPB, nwgs = (s1 - s0 + WPB - 1) / WPB;
+        if (nwgq + nwgs == 0) return;
+        if (p->n_dt > 0)
+            hipLaunchKernelGGL(k_sweep_quad<true>, dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc,
+                               ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq, p->blocks2, p->htab,
+                               p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs);
+        else
+            hipLaunchKernelGGL(k_sweep_quad<false>, dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc,
+                               ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq, p->blocks2, p->htab,
+                               p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs);
+    };
     if (tuned2 && (flags & IBH_IMAGE_ONLY) && p->img_all_fz && !p->fuse_all) {
         // only the image cells are wanted (a rank of a multi-GPU run) and every image block is eligible: one launch
         // per phase over the image blocks, no workspace, nothing for the skirt fragments
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
         IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
         const int32_t i0 = ph2 ? p->n_img_int : 0, i1 = ph1 ? p->n_img_int : p->n_img;
-        launch_sweep(p->img_list, i0, i1 - i0);
+        if (quads_ok(1)) launch_quads(1, ph1, ph2);
+        else launch_sweep(p->img_list, i0, i1 - i0);
         IBH_LAUNCH_CHECK();
         return 0;
     }
@@ -847,7 +895,8 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
         IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
         const int32_t b0 = ph2 ? p->nB1 : 0, b1 = ph1 ? p->nB1 : p->nblk;
-        launch_sweep(nullptr, b0, b1 - b0);
+        if (quads_ok(0)) launch_quads(0, ph1, ph2);
+        else launch_sweep(nullptr, b0, b1 - b0);
         IBH_LAUNCH_CHECK();
         return 0;
     }

@@ -91,7 +91,8 @@ int ibh_partition_destroy(ibh_part* part);
  * [7] = blocks whose whole sweep is independent of skirt cells (IBH_PHASE_INTERIOR),
  * [8] = blocks eligible for the single-kernel sweep, [9] = blocks whose gradients go through the workspace
  *       in a mixed launch (0 when every block is eligible), [10] = 1 when every image block is eligible (IBH_IMAGE_ONLY
- *       sweeps are then one launch per phase), [11] = image blocks. */
+ *       sweeps are then one launch per phase), [11] = image blocks, [12] / [13] = 2x2 block groups of the quad sweep and
+ *       blocks outside them when every block is eligible, [14] / [15] = the same among the image blocks. */
 int ibh_partition_info(const ibh_part* part, int64_t* info, int n);
 
 /* Host-only view of the 2-D block analysis ibh_partition_create runs (block table, halo / end tables, the 2x2 block
@@ -198,6 +199,7 @@ int ibh_copy_rows(const int32_t* dst_rows, const int32_t* src_rows, int32_t n,
 #define IBH_NO_FUSE 128       /* keep the two-kernel form (gradient workspace) even where one kernel could do the sweep */
 #define IBH_FORCE_MIXED 512    /* take the mixed launch (single kernel + two-kernel form) whatever the partition size */
 #define IBH_SWEEP_ONLY 256     /* measurement: of a mixed launch run only the single-kernel part */
+#define IBH_NO_QUAD 1024      /* A/B: per-block single kernel where the quad sweep (2x2 block groups per wavefront) would run */
 #define IBH_EXACT 16      /* block fast path with the literal IEEE arithmetic (bit-comparable with the face-list path) */
 int ibh_residual_advection(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags);
 int ibh_residual_euler_hll(ibh_part*, const float* P, int64_t ldp, float* R, int64_t ldr,

@@ -285,3 +285,32 @@ def test_image_only_euler_sweep_on_partitions(rae_domains):
             assert rel_inf(one[img, v], exp[img, v]) <= TOL, v
             assert rel_inf(one[img, v], full[img, v]) <= 5e-6, v
     assert used > 0
+
+
+@pytest.mark.parametrize("case", ["advection", "rae"])
+@pytest.mark.parametrize("kind", ["smooth", "step"])
+def test_quad_sweep(adv_mesh, rae_mesh_small, case, kind):
+    """Quad sweep (one wavefront per 2x2 group of sibling blocks, csrc/ibh_quad2d.h) on one-partition domains: against
+    the oracle, against the per-block single kernel (IBH_NO_QUAD), and split in overlap phases."""
+    import torch
+    from conftest import ADV_FAMILIES, RAE_FAMILIES
+    from oracle import residual_c as rc
+    msh, fam = (adv_mesh, ADV_FAMILIES) if case == "advection" else (rae_mesh_small, RAE_FAMILIES)
+    dom = ibamd.Domain(msh, hypercube_families=fam, max_partition_size=10 ** 9)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    assert dpart.info["quads"] > 0 and dpart.info["quads"] * 4 + dpart.info["quad_singles"] == dpart.info["full_blocks"]
+    u = seeded_field(part.centers, kind=kind)
+    C = np.stack([np.ones_like(u), f32(0.5) + seeded_field(part.centers, seed=3) * f32(0.1)], axis=1)
+    exp = rc.CPart(part).residual_advection(u, C)
+    ud = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+    ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud)
+    got = ibamd.to_host(ud)
+    assert not np.isnan(got).any()
+    assert rel_inf(got, exp) <= TOL
+    per_block = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), flags=ibamd.IBH_NO_QUAD))
+    assert rel_inf(got, per_block) <= 2e-6
+    ud2 = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+    ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud2, flags=ibamd.IBH_PHASE_INTERIOR)
+    ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud2, flags=ibamd.IBH_PHASE_BOUNDARY)
+    assert np.array_equal(ibamd.to_host(ud2), got)
