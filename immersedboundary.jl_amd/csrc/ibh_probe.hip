@@ -1,0 +1,90 @@
+// libibhip: measurement probes for the 2-D sweep (not on the product path).  Same grid, workgroup shape and LDS
+// allocation as the quad sweep launch of ibh_residual_advection, with the work stripped down in steps, so that a
+// profile can say how much of the sweep's duration is launch ramp, streaming and dependent gathers:
+//   mode 0: every wave returns at once                       (dispatch of the grid)
+//   mode 1: + own-cell loads of u, Cx, Cy and the store of ud (the sweep's algorithmic traffic, 16 B per cell)
+//   mode 2: + descriptor / halo-table loads and the dependent halo gathers (everything the sweep reads)
+#include "ibh_common.h"
+#include "ibh_quad2d.h"
+
+namespace {
+
+#ifndef WPB
+#define WPB 4
+#endif
+#define PROBE_WG_LDS (WPB * (QUAD_LDS > BLK2_SWEEP_LDS ? QUAD_LDS : BLK2_SWEEP_LDS))
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ __launch_bounds__(64 * WPB) void k_probe_sweep(const float* __restrict__ u, const float* __restrict__ C,
+                                                          uint32_t ldc, float* __restrict__ ud,
+                                                          const QuadDesc2* __restrict__ qd,
+                                                          const int32_t* __restrict__ qtab, int32_t nq, int32_t nwgq,
+                                                          const BlockDesc2* __restrict__ blocks,
+                                                          const int32_t* __restrict__ htab,
+                                                          const int32_t* __restrict__ etab,
+                                                          const int32_t* __restrict__ singles, int32_t ns, int32_t nc) {
+    __shared__ __attribute__((aligned(16))) float lds[PROBE_WG_LDS];
+    if (MODE == 0) {
+        if (ldc == 0xffffffffu) lds[threadIdx.x] = 0.f;  // keep the allocation
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if ((int32_t)blockIdx.x < nwgq) {
+        const int32_t q = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+        if (q >= nq) return;
+        const QuadDesc2 d = qd[q];
+        const int g = lane >> 4, t = lane & 15;
+        const uint32_t a0 = (uint32_t)d.base + 64u * ((g >> 1) + 2 * (t >> 3)) + 4u * (g & 1) + 8u * (t & 7);
+        v4f r = *(const v4f*)(u + a0) + *(const v4f*)(C + a0) + *(const v4f*)(C + ldc + a0);
+        if (MODE >= 2) {
+            const int32_t* row = qtab + (size_t)q * IBH_QROW;
+            const v2i hid = *(const v2i*)(row + 2 * lane);
+            const uint32_t eid = (uint32_t)row[128 + (lane & 31)];
+            const int delta = g == 0 ? -1 : g == 1 ? -8 : g == 2 ? 8 : 1;
+            const float* Cn = C + ((g == 1 || g == 2) ? ldc : 0u);
+            // (quads have no MIRROR side: the deeper cell hid + delta exists; clamped anyway, this is a probe)
+            const int d0 = min(max(hid.x + delta, 0), nc - 1), d1 = min(max(hid.y + delta, 0), nc - 1);
+            r.x += u[hid.x] + u[hid.y];
+            r.y += u[d0] + u[d1];
+            r.z += Cn[hid.x] + Cn[hid.y];
+            r.w += u[eid];
+        }
+        *(v4f*)(ud + a0) = r;
+        return;
+    }
+    const int32_t pos = __builtin_amdgcn_readfirstlane((blockIdx.x - nwgq) * WPB + wave);
+    if (pos >= ns) return;
+    const int32_t blk = singles[pos];
+    const BlockDesc2 bb = blocks[blk];
+    const uint32_t c = (uint32_t)bb.base + lane;
+    float r = u[c] + C[c] + C[ldc + c];
+    if (MODE >= 2) {
+        const int32_t h = htab[(size_t)blk * 64 + lane], e = etab[(size_t)blk * 16 + (lane & 15)];
+        const int s = lane >> 4;
+        const int delta = s == 0 ? -1 : s == 1 ? 1 : s == 2 ? -8 : 8;
+        const int32_t hd = min(max(h + delta, 0), nc - 1);  // MIRROR sides name the boundary cell itself: no deeper cell
+        r += u[h] + u[hd] + C[(s >= 2 ? ldc : 0u) + h] + u[e];
+    }
+    ud[c] = r;
+}
+
+}  // namespace
+
+extern "C" int ibh_probe_sweep(ibh_part* p, const float* u, const float* C, int64_t ldc, float* ud, int mode) {
+    IBH_REQUIRE(p && u && C && ud, "ibh_probe_sweep: null argument");
+    IBH_REQUIRE(p->nd == 2 && p->fuse_all && p->nq[0] > 0, "ibh_probe_sweep: needs a partition the quad sweep runs on");
+    const int32_t nq = p->nq[0], ns = p->nqs[0];
+    const int32_t nwgq = (nq + WPB - 1) / WPB, nwgs = (ns + WPB - 1) / WPB;
+#define PROBE_LAUNCH(M)                                                                                              \
+    hipLaunchKernelGGL(k_probe_sweep<M>, dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud, \
+                       p->qd[0], p->qtab[0], nq, nwgq, p->blocks2, p->htab, p->etab, p->qsingles[0], ns, p->nc)
+    if (mode == 0) PROBE_LAUNCH(0);
+    else if (mode == 1) PROBE_LAUNCH(1);
+    else PROBE_LAUNCH(2);
+#undef PROBE_LAUNCH
+    IBH_LAUNCH_CHECK();
+    return 0;
+}

@@ -95,6 +95,10 @@ int ibh_partition_destroy(ibh_part* part);
  *       blocks outside them when every block is eligible, [14] / [15] = the same among the image blocks. */
 int ibh_partition_info(const ibh_part* part, int64_t* info, int n);
 
+/* Measurement probe (not on the product path): the launch of the 2-D quad sweep with the work stripped down.
+ * mode 0 = dispatch only, 1 = + own-cell loads and the store (16 B per cell), 2 = + tables and halo gathers. */
+int ibh_probe_sweep(ibh_part* part, const float* u, const float* C, int64_t ldc, float* ud, int mode);
+
 /* Host-only view of the 2-D block analysis ibh_partition_create runs (block table, halo / end tables, the 2x2 block
  * groups of the quad sweep): same inputs, no device needed.  Test infrastructure for the library's host logic; not
  * part of the reference's surface.  ibh_host2d_get copies item `what` (of quad set `set`: 0 = all blocks, 1 = image

@@ -1,0 +1,61 @@
+"""Where the duration of the 2-D sweep goes: times ibh_probe_sweep modes 0..2 and the sweep itself with HIP events over
+a graph of back-to-back launches (run on the GPU box):  python scripts/probe_sweep.py [workload]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import bench  # noqa: E402
+import ibamd  # noqa: E402
+from ibamd import _lib  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "rae2822_0.87M"
+msh = bench.build_mesh(name)
+dom = ibamd.Domain(msh, max_partition_size=10 ** 9, boundaries=False)
+(part,) = dom.partitions.values()
+u_h, C_h = bench.synthetic_fields(part.centers)
+dpart = ibamd.to_backend(part, ibamd.hip)
+u, C = ibamd.hip(u_h), ibamd.hip(C_h)
+ud = torch.zeros(dpart.nc, dtype=torch.float32, device=u.device)
+ldc = C.stride(1)
+
+
+def probe(mode):
+    _lib.call("ibh_set_stream", _lib.c_vp(torch.cuda.current_stream().cuda_stream))
+    _lib.call("ibh_probe_sweep", dpart.handle, u.data_ptr(), C.data_ptr(), ldc, ud.data_ptr(), mode)
+
+
+def timed(fn, n=50, reps=20):
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            g.replay()
+            e1.record(side)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / n)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+out = {"workload": name, "cells": int(dpart.nc), "quads": int(dpart.info["quads"]),
+       "quad_singles": int(dpart.info["quad_singles"])}
+for mode, key in ((0, "dispatch_only_us"), (1, "stream_16B_per_cell_us"), (2, "stream_tables_gathers_us")):
+    out[key] = round(timed(lambda: probe(mode)), 3)
+out["sweep_us"] = round(timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud)), 3)
+out["sweep_per_block_kernel_us"] = round(timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud,
+                                                                                  flags=ibamd.IBH_NO_QUAD)), 3)
+print(json.dumps(out))
