@@ -67,6 +67,8 @@ _SIGS = {
     "ibh_scatter_rows": [c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_copy_rows": [c_vp, c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_residual_advection": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
+    "ibh_set_tuning": [C.c_char_p, c_int],
+    "ibh_debug_buffer": [c_vp],
     "ibh_probe_sweep": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
     "ibh_residual_euler_hll": [c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(ibh_fluid), c_int],
     "ibh_cfd_speed_of_sound": [C.POINTER(ibh_fluid), c_i64, c_vp, c_vp],

@@ -19,6 +19,8 @@
 // bit for bit with each other and with the oracle's array-at-a-time evaluation.
 #include <algorithm>
 
+#include <string.h>
+
 #include "ibh_common.h"
 #include "ibh_flux.h"
 
@@ -580,10 +582,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(IBH_SW
     blk2::sweep_adv<DT>(blocks, htab, etab, dtab, blist, first, WPB, nb, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
 }
 
-// Quad sweep (quad2::sweep_quad): one wavefront per 2x2 group of sibling blocks; the blocks outside such groups take
-// the per-block single kernel (blk2::sweep_adv) in the SAME launch.  grid = [quad workgroups | single-block workgroups].
+// Quad sweep (quad2::sweep_quad): one wavefront per 2x2 group of sibling blocks; the blocks outside such groups take the
+// per-block single kernel (blk2::sweep_adv) in the SAME launch: grid = [quad workgroups | single-block workgroups]
+// (the other order measured 0.5 us slower).  Measured and dropped (profiles/r2_*/README.md): a persistent form (about
+// two waves per SIMD splitting the item list by estimated cost, next item's loads in flight: 7.2 us against 5.5 us) and
+// several quads per wave with prefetch (6.1 us) -- the sweep lives on wave-level parallelism.
 #define QUAD_WG_LDS (WPB * (QUAD_LDS > BLK2_SWEEP_LDS ? QUAD_LDS : BLK2_SWEEP_LDS))
-template <bool DT>
+// wave timeline of a launch (STAMP, ibh_debug_buffer): per wave {start, end} in 100 MHz ticks and the HW_ID register
+__device__ unsigned long long* ibh_dbg_buf = nullptr;
+__device__ __forceinline__ void dbg_stamp(int32_t slot, int k, unsigned long long v) {
+    if (ibh_dbg_buf && threadIdx.x % 64 == 0) ibh_dbg_buf[(size_t)slot * 8 + k] = v;
+}
+
+template <bool DT, bool STAMP, int GM = 127>
 __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict__ u, const float* __restrict__ C,
                                                          uint32_t ldc, float* __restrict__ ud,
                                                          const QuadDesc2* __restrict__ qd,
@@ -592,17 +603,34 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
                                                          const int32_t* __restrict__ htab,
                                                          const int32_t* __restrict__ etab,
                                                          const int32_t* __restrict__ dtab,
-                                                         const int32_t* __restrict__ singles, int32_t ns, int32_t nwgs) {
+                                                         const int32_t* __restrict__ singles, int32_t ns, int32_t nwgs,
+                                                         int32_t singles_first) {
     __shared__ __attribute__((aligned(16))) float lds[QUAD_WG_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if ((int32_t)blockIdx.x < nwgq) {
-        const int32_t q = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwgq) * WPB + wave);
-        if (q < nq) quad2::sweep_quad(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane);
-        return;
+    const int32_t slot = blockIdx.x * WPB + wave;
+    if constexpr (STAMP) {
+        dbg_stamp(slot, 0, __builtin_amdgcn_s_memrealtime());
+        dbg_stamp(slot, 2, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));  // HW_REG_HW_ID, all 32 bits
     }
-    const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x - nwgq, nwgs) * WPB + wave);
-    if (first < ns)
-        blk2::sweep_adv<DT>(blocks, htab, etab, dtab, singles, first, WPB, 1, u, C, ldc, ud, lds + wave * BLK2_SWEEP_LDS, lane);
+    const int32_t wgq = singles_first ? (int32_t)blockIdx.x - nwgs : (int32_t)blockIdx.x;
+    const bool isq = wgq >= 0 && wgq < nwgq;
+    if (isq) {
+        const int32_t q = __builtin_amdgcn_readfirstlane(xcd_remap(wgq, nwgq) * WPB + wave);
+        if (q < nq)
+            quad2::sweep_quad<STAMP, GM>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane,
+                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr);
+    } else {
+        const int32_t wgs = singles_first ? (int32_t)blockIdx.x : (int32_t)blockIdx.x - nwgq;
+        const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(wgs, nwgs) * WPB + wave);
+        if (first < ns)
+            blk2::sweep_adv<DT>(blocks, htab, etab, dtab, singles, first, WPB, 1, u, C, ldc, ud,
+                                lds + wave * BLK2_SWEEP_LDS, lane);
+    }
+    if constexpr (STAMP) {
+        __builtin_amdgcn_s_waitcnt(0);
+        dbg_stamp(slot, 1, __builtin_amdgcn_s_memrealtime());
+        dbg_stamp(slot, 3, (unsigned long long)isq);
+    }
 }
 
 // Single-kernel Euler sweep (blk2::sweep_euler); 1 / 2 / 4 waves per workgroup measured equal within 2 %
@@ -777,6 +805,9 @@ const int ibh_3d_wave = getenv("IBH_3D_WAVE") ? atoi(getenv("IBH_3D_WAVE")) : 1;
 const int ibh_sweep_iters = getenv("IBH_SWEEP_ITERS") ? atoi(getenv("IBH_SWEEP_ITERS")) : 0;
 // IBH_QUAD=0: per-block single kernel everywhere (A/B runs)
 const int ibh_quad = getenv("IBH_QUAD") ? atoi(getenv("IBH_QUAD")) : 1;
+// ibh_set_tuning(key, v): "quad_variant" 4 = wave time stamps (scripts/wave_timeline.py); "quad_parts" 1 / 2 = only the
+// quads / only the single blocks of a quad sweep (measurement); "quad_singles_first" = grid order
+int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_first = 0;
 
 PartView view(const ibh_part* p) {
     PartView v;
@@ -810,6 +841,21 @@ int ensure_G(ibh_part* p, size_t floats) {
 }  // namespace
 
 extern "C" {
+
+int ibh_debug_buffer(void* buf) {  // device buffer of 8 x uint64 per wave of the launch, or NULL
+    unsigned long long* b = (unsigned long long*)buf;
+    IBH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ibh_dbg_buf), &b, sizeof(b)));
+    return 0;
+}
+
+int ibh_set_tuning(const char* key, int value) {
+    IBH_REQUIRE(key, "ibh_set_tuning: null key");
+    if (!strcmp(key, "quad_variant")) ibh_quad_variant = value;
+    else if (!strcmp(key, "quad_parts")) ibh_quad_parts = value;
+    else if (!strcmp(key, "quad_singles_first")) ibh_quad_singles_first = value;
+    else return ibh_fail(-1, "ibh_set_tuning: unknown key", __FILE__, __LINE__);
+    return 0;
+}
 
 int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t ldc, float* ud, int flags) {
     IBH_REQUIRE(p && u && C && ud, "ibh_residual_advection: null argument");
@@ -866,18 +912,25 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
                (((uintptr_t)u | (uintptr_t)C | (uintptr_t)ud) & 15) == 0;
     };
     auto launch_quads = [&](int k, bool ph1, bool ph2) {
-        const int32_t q0 = ph2 ? p->nq_int[k] : 0, q1 = ph1 ? p->nq_int[k] : p->nq[k];
-        const int32_t s0 = ph2 ? p->nqs_int[k] : 0, s1 = ph1 ? p->nqs_int[k] : p->nqs[k];
+        int32_t q0 = ph2 ? p->nq_int[k] : 0, q1 = ph1 ? p->nq_int[k] : p->nq[k];
+        int32_t s0 = ph2 ? p->nqs_int[k] : 0, s1 = ph1 ? p->nqs_int[k] : p->nqs[k];
+        if (q1 - q0 + s1 - s0 <= 0) return;
+        if (ibh_quad_parts == 1) s1 = s0;  // measurement: quads only / single blocks only
+        if (ibh_quad_parts == 2) q1 = q0;
         const int32_t nwgq = (q1 - q0 + WPB - 1) / WPB, nwgs = (s1 - s0 + WPB - 1) / WPB;
         if (nwgq + nwgs == 0) return;
-        if (p->n_dt > 0)
-            hipLaunchKernelGGL(k_sweep_quad<true>, dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc,
-                               ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq, p->blocks2, p->htab,
-                               p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs);
-        else
-            hipLaunchKernelGGL(k_sweep_quad<false>, dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc,
-                               ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq, p->blocks2, p->htab,
-                               p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs);
+#define QUAD_LAUNCH(DT, STAMP, ...)                                                                                    \
+    hipLaunchKernelGGL((k_sweep_quad<DT, STAMP, ##__VA_ARGS__>), dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C,              \
+                       (uint32_t)ldc, ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq,            \
+                       p->blocks2, p->htab, p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs, ibh_quad_singles_first)
+        if (p->n_dt > 0) QUAD_LAUNCH(true, false);
+        else if (ibh_quad_variant == 4) QUAD_LAUNCH(false, true);
+        else if (ibh_quad_variant == 85) QUAD_LAUNCH(false, false, 85);  // measurement: subsets of the halo gathers
+        else if (ibh_quad_variant == 69) QUAD_LAUNCH(false, false, 69);
+        else if (ibh_quad_variant == 5) QUAD_LAUNCH(false, false, 5);
+        else if (ibh_quad_variant == 100) QUAD_LAUNCH(false, false, 0);
+        else QUAD_LAUNCH(false, false);
+#undef QUAD_LAUNCH
     };
     if (tuned2 && (flags & IBH_IMAGE_ONLY) && p->img_all_fz && !p->fuse_all) {
         // only the image cells are wanted (a rank of a multi-GPU run) and every image block is eligible: one launch

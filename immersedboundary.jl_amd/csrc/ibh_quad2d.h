@@ -42,6 +42,9 @@ __device__ __forceinline__ float dpp_shr1(float old, float v) {  // lane i <- la
 __device__ __forceinline__ float dpp_shl1(float old, float v) {  // lane i <- lane i+1; lane 15 keeps old
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x101, 0xf, 0xf, false));
 }
+__device__ __forceinline__ float dpp_shl1z(float v) {  // lane i <- lane i+1; lane 15 gets 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float bperm(int byte_addr, float v) {  // value of lane byte_addr/4
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
 }
@@ -98,77 +101,192 @@ __device__ __forceinline__ float jst(float g, float a, float rh) {
     return fmaf(fabsf(g), rh, 1e-7f) * __builtin_amdgcn_rcpf(fmaf(a, rh, 1e-7f));
 }
 
-__device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, const int32_t* __restrict__ qtab, int32_t q,
-                                           const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
-                                           float* __restrict__ ud, float* lds, int lane) {
-    using blk2::ldg;
-    using blk2::wave_lds_sync;
-    float* tU = lds;
-    float* tSY = lds + QUAD_TILE;
-    float* tD = lds + 2 * QUAD_TILE;
-    float* tCY = lds + 3 * QUAD_TILE;
-    float* ext = lds + QUAD_OFF_EXT;
-    float* ringM = lds + QUAD_OFF_RING;
-    float* ringF = ringM + 64;
-    float* ringQ = ringM + 128;
-    float* exf = lds + QUAD_OFF_EX;
-    // ---- lane-only geometry
-    const int g = lane >> 4, t = lane & 15, tl = lane & 7;
-    const bool g0 = g == 0, g3 = g == 3, lr = g0 || g3, t0 = t == 0, t15 = t == 15;
-    const int delta = g0 ? -1 : g == 1 ? -8 : g == 2 ? 8 : 1;          // deeper cell of a halo cell
-    const bool dny = g == 1 || g == 2;                                  // side normal to y
-    const float sgn = g >= 2 ? 1.0f : -1.0f;                            // +1: the quad's cell is the owner of the edge face
-    const int lhs = 2 * g + (t >> 3);                                   // outer half-side of this lane's slots
-    const int bx = g0 ? 0 : g3 ? 15 : t, by = lr ? t : g == 1 ? 0 : 15;  // boundary cell of the slots
-    const int pos_b = by * QUAD_PITCH + bx;
-    const int mate = (t & 1) ? -1 : 1;
-    const int pos_b1 = pos_b + mate * (lr ? QUAD_PITCH : 1);           // its pair mate t ^ 1 (COARSE sides)
-    const int pos_own = t * QUAD_PITCH + 4 * g;                         // this lane's four cells in a tile
-    const int myrow = t0 ? 0 : t15 ? 1 : 2;                             // ring row this lane reads
-    const int rowB = t0 ? 0 : 2, rowT = t15 ? 1 : 2;
-    const int wrow = g == 1 ? 0 : g == 2 ? 1 : 3;                       // ring row this lane's side writes
-    const int eline = (lane & 31) >> 2, ee = lane & 3;
-    const int epos = eline * 20 + (ee < 2 ? ee : 16 + ee);
-    // neutral ring rows: u ring unused, sensor correction 0, weight 1/2 (read by lanes that are not on the y edges)
-    ringF[32 + (lane & 15)] = 0.0f;
-    ringQ[32 + (lane & 15)] = 0.5f;
+// Lane table of the quad sweep, built at compile time: per lane 8 words, LDS byte offsets packed two per word (see
+// sweep_quad for the meaning of the fields), the lane's cell offset inside the quad and its deeper-cell step.
+struct QuadLaneTab {
+    uint32_t w[64][8];
+    constexpr QuadLaneTab() : w() {
+        for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, t = lane & 15, tl = lane & 7, lhs = lane >> 3;
+            const bool g0 = g == 0, g3 = g == 3, lr = g0 || g3, t0 = t == 0, t15 = t == 15;
+            const int bx = g0 ? 0 : g3 ? 15 : t, by = lr ? t : g == 1 ? 0 : 15;
+            const int pos_b = by * QUAD_PITCH + bx;
+            const int pos_b1 = lr ? (t ^ 1) * QUAD_PITCH + bx : by * QUAD_PITCH + (t ^ 1);
+            const int pos_own = t * QUAD_PITCH + 4 * g;
+            const int myrow = t0 ? 0 : t15 ? 1 : 2, rowB = t0 ? 0 : 2, rowT = t15 ? 1 : 2;
+            const int wrow = g == 1 ? 0 : g == 2 ? 1 : 3;
+            const int eline = (lane & 31) >> 2, ee = lane & 3;
+            const int epos = QUAD_OFF_EXT + eline * 20 + (ee < 2 ? ee : 16 + ee);
+            const int line = QUAD_OFF_EXT + lhs * 20;
+            const uint32_t f[14] = {
+                (uint32_t)pos_own, (uint32_t)pos_b, (uint32_t)pos_b1, (uint32_t)(line + 2 + 2 * tl), (uint32_t)epos,
+                (uint32_t)(QUAD_OFF_RING + wrow * 16 + t), (uint32_t)(QUAD_OFF_RING + myrow * 16 + 4 * g),
+                (uint32_t)(QUAD_OFF_RING + rowB * 16 + 4 * g), (uint32_t)(QUAD_OFF_RING + rowT * 16 + 4 * g),
+                (uint32_t)(line + 2 * tl), (uint32_t)(line + 2 * (tl & ~1)), (uint32_t)(line + 2 * (tl | 1) + 4),
+                0u, 0u};
+            for (int k = 0; k < 6; ++k) w[lane][k] = (4u * f[2 * k]) | ((4u * f[2 * k + 1]) << 16);
+            w[lane][6] = 64u * ((g >> 1) + 2 * (t >> 3)) + 4u * (g & 1) + 8u * (t & 7);
+            w[lane][7] = (uint32_t)(g0 ? -1 : g == 1 ? -8 : g == 2 ? 8 : 1);
+        }
+    }
+};
+__device__ const QuadLaneTab lane_tab = QuadLaneTab();
 
-    // ---- loads
-    const QuadDesc2 d = qd[q];  // wave-uniform
+// ---- the wave's lane-only state: LDS pointers from a compile-time table (two 16-byte loads; computing them costs
+// ~90 vector instructions per wave, a fifth of a quad's arithmetic), lane classes from the lane id
+struct QuadLane {
+    float *p_own;    // this lane's four cells in a tile
+    float *p_b;      // boundary cell of this lane's halo slots (in tile U)
+    float *p_b1;     // its pair mate t ^ 1 (COARSE sides)
+    float *p_extw;   // this lane's two slots in the lateral line of its half-side
+    float *p_epos;   // where lane & 31 puts its end value
+    float *p_ringw;  // ring entry this lane's side writes (dump row for left / right)
+    float *p_ringm;  // ring row this lane reads: bottom (t = 0), top (t = 15), neutral
+    float *p_ringB;  // weight row for the low y side: bottom or neutral
+    float *p_ringT;  // ... high y side: top or neutral
+    float *p_LbS;    // low lateral pair of this lane's slots, SAME / FINE half-sides (high pair: + 4)
+    float *p_LbC;    // ... COARSE half-sides
+    float *p_HbC;    // high lateral pair, COARSE
+    uint32_t a0off;  // this lane's first cell relative to the quad's
+    int delta;       // deeper cell of a halo cell: -1, -8, +8, +1
+    int lane, tl, lhs;
+    bool g0, g3, lr, dny, t15;
+    float sgn;       // +1: the quad's cell is the owner of the edge face (top / right), -1 on left / bottom
+};
+
+__device__ __forceinline__ QuadLane quad_lane(float* lds, int lane) {
+    QuadLane G;
+    char* const L = (char*)lds;
+    const uint4 w0 = *(const uint4*)(lane_tab.w[lane]);
+    const uint4 w1 = *(const uint4*)(lane_tab.w[lane] + 4);
+#define QL_LO(w) ((w) & 0xffffu)
+#define QL_HI(w) ((w) >> 16)
+    G.p_own = (float*)(L + QL_LO(w0.x));
+    G.p_b = (float*)(L + QL_HI(w0.x));
+    G.p_b1 = (float*)(L + QL_LO(w0.y));
+    G.p_extw = (float*)(L + QL_HI(w0.y));
+    G.p_epos = (float*)(L + QL_LO(w0.z));
+    G.p_ringw = (float*)(L + QL_HI(w0.z));
+    G.p_ringm = (float*)(L + QL_LO(w0.w));
+    G.p_ringB = (float*)(L + QL_HI(w0.w));
+    G.p_ringT = (float*)(L + QL_LO(w1.x));
+    G.p_LbS = (float*)(L + QL_HI(w1.x));
+    G.p_LbC = (float*)(L + QL_LO(w1.y));
+    G.p_HbC = (float*)(L + QL_HI(w1.y));
+#undef QL_LO
+#undef QL_HI
+    // from the lane id (the own-cell loads then wait for the descriptor only):
+    // 64 ((g >> 1) + 2 (t >> 3)) + 4 (g & 1) + 8 (t & 7)
+    G.a0off = ((lane & 7) << 3) | ((lane & 8) << 4) | ((lane & 16) >> 2) | ((lane & 32) << 1);
+    G.delta = (int)w1.w;
+    G.lane = lane;
+    G.tl = lane & 7;
+    G.lhs = lane >> 3;  // outer half-side of this lane's slots
+    G.g0 = lane < 16;
+    G.g3 = lane >= 48;
+    G.lr = G.g0 || G.g3;
+    G.dny = !G.lr;
+    G.t15 = (lane & 15) == 15;
+    G.sgn = lane >= 32 ? 1.0f : -1.0f;
+    // neutral ring rows: u ring unused, sensor correction 0, weight 1/2 (read by lanes that are not on the y edges)
+    ((float*)(L + 4 * (QUAD_OFF_RING + 64 + 32)))[lane & 15] = 0.0f;
+    ((float*)(L + 4 * (QUAD_OFF_RING + 128 + 32)))[lane & 15] = 0.5f;
+    return G;
+}
+
+// ---- what a wave fetches for a quad, in three dependent steps
+struct QuadTab {   // needs the quad's index only
+    QuadDesc2 d;   // wave-uniform
+    v2i hid;       // halo cells of this lane's two slots
+    uint32_t eid;  // end cell of lane & 31
+};
+struct QuadOwn {   // needs the descriptor
+    v4f U, CX, CY;
+    uint32_t a0;
+};
+struct QuadHalo {  // needs the table entries
+    v2f hu, hd, hc;
+    float eu;
+};
+__device__ __forceinline__ QuadTab quad_load_tab(const QuadDesc2* __restrict__ qd, const int32_t* __restrict__ qtab,
+                                                 int32_t q, int lane) {
+    QuadTab T;
+    T.d = qd[q];
     const int32_t* row = qtab + (size_t)q * IBH_QROW;
-    const v2i hid = *(const v2i*)(row + 2 * lane);
-    const uint32_t eid = (uint32_t)row[128 + (lane & 31)];
-    const uint32_t a0 = (uint32_t)d.base + 64u * ((g >> 1) + 2 * (t >> 3)) + 4u * (g & 1) + 8u * (t & 7);
-    const v4f U = *(const v4f*)((const char*)u + ((size_t)a0 << 2));
-    const v4f CX = *(const v4f*)((const char*)C + ((size_t)a0 << 2));
-    const v4f CY = *(const v4f*)((const char*)(C + ldc) + ((size_t)a0 << 2));
-    const float* Cn = C + (dny ? ldc : 0u);
-    const v2f hu = v2f{ldg(u, (uint32_t)hid.x), ldg(u, (uint32_t)hid.y)};
-    const v2f hd = v2f{ldg(u, (uint32_t)(hid.x + delta)), ldg(u, (uint32_t)(hid.y + delta))};
-    const v2f hc = v2f{ldg(Cn, (uint32_t)hid.x), ldg(Cn, (uint32_t)hid.y)};
-    const float eu = ldg(u, eid);
-    const uint32_t ty = (d.cls >> (4 * lhs)) & 15u;
+    T.hid = *(const v2i*)(row + 2 * lane);
+    T.eid = (uint32_t)row[128 + (lane & 31)];
+    return T;
+}
+__device__ __forceinline__ QuadOwn quad_load_own(const QuadLane& G, const QuadTab& T, const float* __restrict__ u,
+                                                 const float* __restrict__ C, uint32_t ldc) {
+    QuadOwn O;
+    O.a0 = (uint32_t)T.d.base + G.a0off;
+    O.U = *(const v4f*)((const char*)u + ((size_t)O.a0 << 2));
+    O.CX = *(const v4f*)((const char*)C + ((size_t)O.a0 << 2));
+    O.CY = *(const v4f*)((const char*)(C + ldc) + ((size_t)O.a0 << 2));
+    return O;
+}
+// Halo gathers.  Each costs the memory pipeline about as much as a float4 load of the whole tile when nothing else runs
+// (scripts/probe_sweep.py); inside the sweep they hide behind the arithmetic (measured: dropping the second-slot
+// gathers on quads without a FINE side, or pairing halo + deeper cell in one 8-byte load, changed nothing).
+// GM (measurement only, wrong results unless 127): which of the seven gathers are really performed
+template <int GM = 127>
+__device__ __forceinline__ QuadHalo quad_load_halo(const QuadLane& G, const QuadTab& T, const float* __restrict__ u,
+                                                   const float* __restrict__ C, uint32_t ldc) {
+    using blk2::ldg;
+    QuadHalo H;
+    const float* Cn = C + (G.dny ? ldc : 0u);
+    const float z = (float)(T.hid.x + T.hid.y + (int)T.eid) * 1e-30f;  // keeps the table loads alive
+    H.hu.x = (GM & 1) ? ldg(u, (uint32_t)T.hid.x) : z;
+    H.hu.y = (GM & 2) ? ldg(u, (uint32_t)T.hid.y) : H.hu.x;
+    H.hd.x = (GM & 4) ? ldg(u, (uint32_t)(T.hid.x + G.delta)) : z;
+    H.hd.y = (GM & 8) ? ldg(u, (uint32_t)(T.hid.y + G.delta)) : H.hd.x;
+    H.hc.x = (GM & 16) ? ldg(Cn, (uint32_t)T.hid.x) : 1.0f + z;
+    H.hc.y = (GM & 32) ? ldg(Cn, (uint32_t)T.hid.y) : H.hc.x;
+    H.eu = (GM & 64) ? ldg(u, T.eid) : z;
+    return H;
+}
+
+// ---- the arithmetic of one quad.  STAMP: phase time stamps of the wave (100 MHz ticks) for scripts/wave_timeline.py
+template <bool STAMP>
+__device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T, const QuadOwn& O, const QuadHalo& H,
+                                             float* __restrict__ ud, unsigned long long* stamps) {
+    using blk2::wave_lds_sync;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_s_waitcnt(0);
+            if (stamps && G.lane == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    const v4f U = O.U, CX = O.CX, CY = O.CY;
+    const v2f hu = H.hu, hd = H.hd, hc = H.hc;
+    const bool g0 = G.g0, g3 = G.g3, lr = G.lr, dny = G.dny, t15 = G.t15;
+    const int lane = G.lane;
+    const float sgn = G.sgn;
+    const uint32_t ty = (T.d.cls >> (4 * G.lhs)) & 15u;
     const bool isC = ty == SIDE_COARSE, isF = ty == SIDE_FINE;
     const float qs = isC ? (1.0f / 3.0f) : isF ? (2.0f / 3.0f) : 0.5f;  // at_faces weight of the quad's cell
     const float irt = isC ? 0.5f : isF ? 2.0f : 1.0f;                   // h / h_halo
-    const float rhx = d.rh[0], rhy = d.rh[1];
+    const float rhx = T.d.rh[0], rhy = T.d.rh[1];
 
     // ---- stage: u tile, lateral lines
-    *(v4f*)(tU + pos_own) = U;
-    *(v4f*)(tCY + pos_own) = CY;
-    *(v2f*)(ext + lhs * 20 + 2 + 2 * tl) = hu;
-    ext[epos] = eu;
+    *(v4f*)G.p_own = U;
+    *(v4f*)(G.p_own + 3 * QUAD_TILE) = CY;
+    *(v2f*)G.p_extw = hu;
+    *G.p_epos = H.eu;
     wave_lds_sync();
-    const float m0 = lds_read(tU + pos_b);
-    const float m1r = lds_read(tU + pos_b1);
+    stamp(4);
+    const float m0 = lds_read(G.p_b);
+    const float m1r = lds_read(G.p_b1);
     const float m1 = isC ? m1r : m0;
     const float hm = 0.5f * (hu.x + hu.y);
     // sensor correction of a boundary cell that faces two finer cells: its |d| sum counts both of them
     const float fix = 0.5f * (fabsf(hu.x - m0) + fabsf(hu.y - m0)) - fabsf(hm - m0);
-    ringM[wrow * 16 + t] = hm;
-    ringF[wrow * 16 + t] = fix;
-    ringQ[wrow * 16 + t] = qs;
+    G.p_ringw[0] = hm;
+    G.p_ringw[64] = fix;
+    G.p_ringw[128] = qs;
     wave_lds_sync();
+    stamp(5);
 
     // ---- own cells: undivided slopes + sensor
     v4f SX, SY, D;
@@ -182,10 +300,10 @@ __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, con
         const v4f dR = UR - U, dL = U - UL;
         SX = qR * dR + qL * dL;
         const v4f gx = dR - dL;
-        const v4f rM = *(const v4f*)(ringM + myrow * 16 + 4 * g);
-        const v4f rF = *(const v4f*)(ringF + myrow * 16 + 4 * g);
-        const v4f qB = *(const v4f*)(ringQ + rowB * 16 + 4 * g);
-        const v4f qT = *(const v4f*)(ringQ + rowT * 16 + 4 * g);
+        const v4f rM = *(const v4f*)G.p_ringm;
+        const v4f rF = *(const v4f*)(G.p_ringm + 64);
+        const v4f qB = *(const v4f*)(G.p_ringB + 128);
+        const v4f qT = *(const v4f*)(G.p_ringT + 128);
         v4f uB;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -205,23 +323,21 @@ __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, con
             D[c] = max3(jst(gx[c], ax, rhx), jst(gy[c], ay, rhy), 1e-7f);
         }
     }
-    *(v4f*)(tSY + pos_own) = SY;
-    *(v4f*)(tD + pos_own) = D;
+    *(v4f*)(G.p_own + QUAD_TILE) = SY;
+    *(v4f*)(G.p_own + 2 * QUAD_TILE) = D;
 
-    // ---- halo cells of this lane's two slots: slope along the side normal (towards +) and sensor
-    v2f Shn, Dh;  // Shn = MINUS the slope along the axis on low sides, the slope itself on high sides ... see flux below
+    // ---- halo cells of this lane's two slots: slope along the side normal and sensor
+    v2f Shn, Dh;  // Shn: slope of the halo cell seen from the quad outwards (sign folded for the edge flux below)
     {
         const float ihn = (dny ? rhy : rhx) * irt, iht = (dny ? rhx : rhy) * irt;
         const v2f dm0 = m0 - hu, dm1 = m1 - hu, dde = hd - hu;
         const v2f din = 0.5f * (dm0 + dm1);
-        // slope of the halo cell seen from the quad outwards: -(1 - qs) din + dde / 2  (= -x of blk2::sweep_adv)
+        // -(1 - qs) din + dde / 2  (= -x of blk2::sweep_adv)
         Shn = 0.5f * dde - (1.0f - qs) * din;
         // lateral neighbours (ibh_sweep2d.h:246-255 in pair form; quad_model.py checks the equivalence)
-        const int Lb = isC ? 2 * (tl & ~1) : 2 * tl;
-        const int Hb = (isC ? 2 * (tl | 1) : 2 * tl) + 4;
-        const v2f Lp = *(const v2f*)(ext + lhs * 20 + Lb);
-        const v2f Hp = *(const v2f*)(ext + lhs * 20 + Hb);
-        const bool t0l = tl == 0, t7l = tl == 7;
+        const v2f Lp = *(const v2f*)(isC ? G.p_LbC : G.p_LbS);
+        const v2f Hp = *(const v2f*)(isC ? G.p_HbC : G.p_LbS + 4);
+        const bool t0l = G.tl == 0, t7l = G.tl == 7;
         const v2f lo0 = v2f{(isF && !t0l) ? Lp.y : Lp.x, isF ? hu.x : Lp.x};
         const v2f lo1 = v2f{Lp.y, isF ? hu.x : Lp.y};
         const v2f hi0 = v2f{isF ? hu.y : Hp.x, Hp.x};
@@ -250,19 +366,21 @@ __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, con
         v4f St, Dt, Ct;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            St[c] = dpp_shl1(SY[c], SY[c]);
-            Dt[c] = dpp_shl1(D[c], D[c]);
-            Ct[c] = dpp_shl1(CY[c], CY[c]);
+            St[c] = dpp_shl1z(SY[c]);  // lanes t = 15: zero (their top face is an edge face, taken from `ex` below)
+            Dt[c] = dpp_shl1z(D[c]);
+            Ct[c] = dpp_shl1z(CY[c]);
         }
         FT = flux_half4(U, uT, SY, St, D, Dt, CY, Ct);
     }
 
     // ---- edge faces: both sub-faces of this lane's boundary cell
     wave_lds_sync();  // SY, D tiles
+    stamp(6);
     float edge;
     {
         const float So_lr = g3 ? SX.w : SX.x, Do_lr = g3 ? D.w : D.x, Co_lr = g3 ? CX.w : CX.x;
-        const float So_bt = lds_read(tSY + pos_b), Do_bt = lds_read(tD + pos_b), Co_bt = lds_read(tCY + pos_b);
+        const float So_bt = lds_read(G.p_b + QUAD_TILE), Do_bt = lds_read(G.p_b + 2 * QUAD_TILE),
+                    Co_bt = lds_read(G.p_b + 3 * QUAD_TILE);
         const float So = lr ? So_lr : So_bt;
         const float Do = lr ? Do_lr : Do_bt;
         const float Co = lr ? Co_lr : Co_bt;
@@ -270,15 +388,16 @@ __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, con
         const v2f F = flux_w2(m0, hu, sgn * So, Shn, Do, Dh, sgn * Co, sgn * hc, qs);
         edge = sgn * (0.5f * (F.x + F.y));
     }
-    exf[wrow * 16 + t] = edge;
+    G.p_ringw[QUAD_OFF_EX - QUAD_OFF_RING] = edge;
     wave_lds_sync();
+    stamp(7);
 
     // ---- Green-Gauss
     {
         const float FRm = bperm((lane - 16) << 2, FR.w);
         const v4f FL = v4f{g0 ? edge : FRm, FR.x, FR.y, FR.z};
         const v4f FRf = v4f{FR.x, FR.y, FR.z, g3 ? edge : FR.w};
-        const v4f ex = *(const v4f*)(exf + myrow * 16 + 4 * g);
+        const v4f ex = *(const v4f*)(G.p_ringm + (QUAD_OFF_EX - QUAD_OFF_RING));
         v4f FB, FTf;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -286,8 +405,23 @@ __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, con
             FTf[c] = t15 ? ex[c] : FT[c];
         }
         const v4f res = -((FRf - FL) * rhx) - ((FTf - FB) * rhy);
-        *(v4f*)((char*)ud + ((size_t)a0 << 2)) = res;
+        *(v4f*)((char*)ud + ((size_t)O.a0 << 2)) = res;
     }
+}
+
+// ---- one quad by one wave.  (Sweeping several quads per wave with the next quad's loads in flight was measured and
+// dropped: the prefetch registers cost a wave per SIMD -- 124 VGPRs against 89 -- and the sweep lives on wave-level
+// parallelism: 6.1 us against 5.5 us at 0.87 M cells, no gain at 3.47 M.)
+template <bool STAMP, int GM = 127>
+__device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, const int32_t* __restrict__ qtab, int32_t q,
+                                           const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
+                                           float* __restrict__ ud, float* lds, int lane,
+                                           unsigned long long* stamps = nullptr) {
+    const QuadLane G = quad_lane(lds, lane);
+    const QuadTab T = quad_load_tab(qd, qtab, q, lane);
+    const QuadOwn O = quad_load_own(G, T, u, C, ldc);
+    const QuadHalo H = quad_load_halo<GM>(G, T, u, C, ldc);
+    quad_compute<STAMP>(G, T, O, H, ud, stamps);
 }
 
 #pragma clang fp contract(off)

@@ -95,6 +95,11 @@ int ibh_partition_destroy(ibh_part* part);
  *       blocks outside them when every block is eligible, [14] / [15] = the same among the image blocks. */
 int ibh_partition_info(const ibh_part* part, int64_t* info, int n);
 
+/* Measurement switches of the kernels (A/B runs inside one process); key "quad_variant": variant of the quad sweep. */
+int ibh_set_tuning(const char* key, int value);
+/* Wave timeline of the quad sweep (quad_variant 4): 8 x uint64 per wave {start, end (100 MHz ticks), HW_ID, is_quad, 4 phase stamps of a quad wave}. */
+int ibh_debug_buffer(void* device_buffer);
+
 /* Measurement probe (not on the product path): the launch of the 2-D quad sweep with the work stripped down.
  * mode 0 = dispatch only, 1 = + own-cell loads and the store (16 B per cell), 2 = + tables and halo gathers. */
 int ibh_probe_sweep(ibh_part* part, const float* u, const float* C, int64_t ldc, float* ud, int mode);

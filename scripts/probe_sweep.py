@@ -55,7 +55,35 @@ out = {"workload": name, "cells": int(dpart.nc), "quads": int(dpart.info["quads"
        "quad_singles": int(dpart.info["quad_singles"])}
 for mode, key in ((0, "dispatch_only_us"), (1, "stream_16B_per_cell_us"), (2, "stream_tables_gathers_us")):
     out[key] = round(timed(lambda: probe(mode)), 3)
+if os.environ.get("PROBE_DETAIL"):
+    for bits, key in ((3, "own+tables"), (2, "tables_only"), (2 + 4, "tables+hu0"), (3 + 4, "own+tables+hu0"),
+                      (3 + 4 + 16, "own+tables+hu0+hd0"), (3 + 4 + 16 + 64, "own+tables+hu0+hd0+hc0"),
+                      (3 + 4 + 16 + 64 + 256, "all_k0"), (3 + 4 + 8 + 16 + 32, "own+tables+hu01+hd01"),
+                      (1 + 2 + 256, "own+tables+ends")):
+        out[key] = round(timed(lambda: probe(16 + bits)), 3)
 out["sweep_us"] = round(timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud)), 3)
+def sweep_time():
+    return timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud))
+
+
+if os.environ.get("QUAD_TUNE"):  # same-process A/B: alternate, keep the best median of each
+    best = {}
+    cases = {"both_quads_first": (3, 0), "both_singles_first": (3, 1), "quads_only": (1, 0), "singles_only": (2, 0)}
+    for _ in range(3):
+        for name_, (parts, sf) in cases.items():
+            _lib.call("ibh_set_tuning", b"quad_parts", parts)
+            _lib.call("ibh_set_tuning", b"quad_singles_first", sf)
+            best[name_] = min(best.get(name_, 1e9), sweep_time())
+    _lib.call("ibh_set_tuning", b"quad_parts", 1)
+    for _ in range(3):
+        for name_, var in (("quads_only_all_gathers", 0), ("quads_only_k0+ends", 85), ("quads_only_hu0_hd0_ends", 69),
+                           ("quads_only_hu0_hd0", 5), ("quads_only_no_gathers", 100)):
+            _lib.call("ibh_set_tuning", b"quad_variant", var)
+            best[name_] = min(best.get(name_, 1e9), sweep_time())
+    _lib.call("ibh_set_tuning", b"quad_variant", 0)
+    out["parts_us"] = {k: round(v, 3) for k, v in best.items()}
+    _lib.call("ibh_set_tuning", b"quad_parts", 3)
+    _lib.call("ibh_set_tuning", b"quad_singles_first", 0)
 out["sweep_per_block_kernel_us"] = round(timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud,
                                                                                   flags=ibamd.IBH_NO_QUAD)), 3)
 print(json.dumps(out))
