@@ -4,7 +4,8 @@ SURVEY.md 8d = the closure of /root/reference/test/advection.jl:67-83) on the 2-
 block-quadtree mesh at ~1 M cells (BASELINE.json configs[1]).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or plainly as
+   `python bench.py --gpus N ...`: without WORLD_SIZE in the environment the script starts the N ranks itself)
 
 One step = one residual sweep over the rank's partition with all fields resident in HBM; for
 N > 1 the ~1 M-cell domain is cut into N contiguous partitions (one per GPU, strong scaling)
@@ -30,6 +31,8 @@ WORKLOADS = {
     "rae2822_0.87M": (2.5e-4, 1.25e-4),
     "rae2822_3.47M": (6e-5, 3e-5),
     "rae2822_37k": (1e-2, 5e-3),
+    # secondary: working set (16 B/cell + tables) past the 256 MiB Infinity Cache: the kernel against real HBM
+    "rae2822_28M": (1e-5, 5e-6),
     # 3-D (secondary): unit sphere (icosphere STL) in a [-8,8]^3 box, 8^3 blocks (BASELINE.json configs[3] shape)
     "sphere3d_1.6M": 0.06,
     "sphere3d_4.6M": 0.03,
@@ -117,9 +120,25 @@ def cpu_baseline(part, u, C, budget_s=10.0):
             break
     mc = u.shape[0] / 1e6
     other = best[not fused]
+    # what the job may really use: CPUs in the affinity mask and the cgroup CPU quota (a box can show 256 cores and
+    # give this job about one: then one thread wins the scan above)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                tok = f.read().split()
+            if path.endswith("cpu.max"):
+                quota = None if tok[0] == "max" else round(int(tok[0]) / int(tok[1]), 2)
+            else:
+                q = int(tok[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    quota = None if q < 0 else round(q / int(f.read().split()[0]), 2)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
     return dict(value=mc * n / dt, n=n, secs=dt, threads=threads, form="cell-fused" if fused else "faithful",
                 other_form="faithful" if fused else "cell-fused", other_value=mc * other[0], other_threads=other[1],
-                one_thread=mc * rate(False, 1, 2))
+                one_thread=mc * rate(False, 1, 2), affinity=len(os.sched_getaffinity(0)), cgroup_cpus=quota)
 
 
 def main():
@@ -150,7 +169,48 @@ def main():
                          "reproduces the rccl exchange bit for bit at start-up, else rccl")
     ap.add_argument("--graph-batch", type=int, default=20,
                     help="sweeps captured per HIP graph (launch-bound loop; 0 = eager launches)")
+    ap.add_argument("--repeats", type=int, default=20,
+                    help="the timed block of --steps sweeps is repeated this many times; the median is reported")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="check the launch path only: ranks meet (gloo), rank 0 prints one JSON line; no GPU is touched")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: become the launcher.  Nothing in this process has touched the GPU (torch is not even
+        # imported yet); the ranks are children of torch.distributed.run and rank 0's JSON line is relayed.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        if lines:
+            print(lines[-1])
+        else:
+            sys.stderr.write(proc.stdout)
+        raise SystemExit(proc.returncode if proc.returncode else (0 if lines else 1))
+
+    if args.rendezvous_only:
+        import torch
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            ok = int(t.item()) == world
+            rank = dist.get_rank()
+            dist.destroy_process_group()
+        else:
+            ok, rank = True, 0
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rendezvous": "ok" if ok else "failed"}))
+        raise SystemExit(0 if ok else 1)
 
     import torch
     import torch.distributed as dist
@@ -232,7 +292,9 @@ def main():
                     raise
                 if rank == 0:
                     print(f"[bench] xgmi halo exchange unavailable ({e}); using {halo_kind}", file=sys.stderr)
-        overlap = args.overlap and not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
+        # (the Euler sweep has overlap phases only where the image blocks all take the single kernel)
+        overlap = (args.overlap and not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
+                   and (not euler or image_only))
         comm_stream = torch.cuda.Stream() if overlap else None
 
     def sweep(extra=0):
@@ -291,16 +353,31 @@ def main():
                 step()
 
     run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    # EXACTLY `steps` sweeps between barrier + synchronize on both sides, max over ranks -- and that block `repeats`
+    # times: a block is a fraction of a millisecond, its wall time moves with launch jitter; the median is reported
+    dts = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        dts.append(time.perf_counter() - t0)
     if world > 1:
         red_dev = u.device if args.backend == "nccl" else "cpu"
-        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        tmax = torch.tensor(dts, dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dts = [float(x) for x in tmax.tolist()]
+    dts.sort()
+    dt = dts[len(dts) // 2]
+    halo_timeouts = None
+    if world > 1:
+        if halo_kind == "xgmi-direct":
+            # a wait kernel that hit its spin bound unpacked stale skirt values: the figure would be for a wrong
+            # residual.  Checked after the timed region (collective); such a run does not publish a number.
+            halo_timeouts = 0 if hx.healthy() else 1
+            if halo_timeouts:
+                raise SystemExit("xgmi halo exchange: a wait timed out during the run (stale skirt values); "
+                                 "rerun with --halo rccl")
         tot = torch.tensor([n_image], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot)
         total_cells = int(tot.item())
@@ -378,12 +455,16 @@ def main():
         tA = time_pass(ibamd.IBH_PASS_A_ONLY, reps)
     # R1 = 4*(1 + nd + 1) B/cell, R2 = 2 * 4 * (nd + 2) B/cell
     b_alg = (40.0 if is3d else 32.0) if euler else (20.0 if is3d else B_ALG_2D)
-    achieved = b_alg * cells_launch / tB / 1e9
+    # two-kernel workloads: the algorithmic bytes are priced against pass A + pass B (the sweep), not pass B alone
+    t_kern = tB + (tA or 0.0)
+    achieved = b_alg * cells_launch / t_kern / 1e9
     # HBM-side traffic of one launch of the dominant kernel from the committed PMC passes of this build (separate
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
     # calibrated against the kernel's known tile loads); null if not profiled.
     kernel = ("k_passB3e_blk" if (euler and is3d) else "k_sweep_euler" if (fused_e or (image_only and euler)) else "k_passB_euler_blk" if euler else
               "k_passB3_adv_blk" if is3d else
+              "k_sweep_quad" if ((fused and inf.get("quads", 0) > 0) or
+                                 (image_only and not euler and inf.get("image_quads", 0) > 0)) else
               "k_sweep_adv" if (fused or mixed or (image_only and not euler)) else "k_passB_adv<2,false>")
     traffic = None
     pmc_extra = {}
@@ -392,18 +473,39 @@ def main():
             pm = json.load(f)
         if pm.get("workload") == args.workload and pm.get("kernel") == kernel and world == 1:
             traffic = round((2.0 * pm["fetch_kb"] + pm["write_kb"]) * 1024.0)
-            pmc_extra = {k: pm[k] for k in ("valu_insts_per_block", "valu_busy_frac", "lds_insts_per_block") if k in pm}
+            pmc_extra = {k: pm[k] for k in ("valu_insts_per_wave", "valu_busy_frac", "lds_insts_per_wave",
+                                            "wave_wait_frac") if k in pm}
     except (OSError, KeyError, ValueError):
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                 "kernel_us": round(tB * 1e6, 3), "passA_us": None if tA is None else round(tA * 1e6, 3),
+                "frac_priced_on": "pass A + pass B" if tA is not None else "the one kernel of the sweep",
                 "alg_bytes_per_cell": b_alg, "cells_per_launch": cells_launch,
                 "sweep_frac": round(b_alg * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
     if pmc_extra:
-        # the sweep sits at the FP32-vector ridge (~11 flop/B): the committed PMC passes show the vector ALUs issuing
-        # most of the time -- the binding limit is VALU issue, the HBM figure above prices algorithmic bytes
-        roofline["binding_limit"] = dict(pmc_extra, what="VALU issue (profiles/current_pmc.json)")
+        roofline["binding_limit"] = dict(pmc_extra, what="launch ramp + two dependent load round trips, then VALU issue "
+                                                         "(profiles/current_pmc.json, DESIGN.md section 3)")
+    if kernel == "k_sweep_quad" and world == 1:
+        # what the launch itself costs on this box: the same grid with the work stripped down (ibh_probe_sweep)
+        from ibamd import backend as _bk
+
+        def probe(mode):
+            def f(_=0):
+                _bk._stream()
+                _lib.call("ibh_probe_sweep", dpart.handle, u.data_ptr(), C.data_ptr(), C.stride(1), ud.data_ptr(), mode)
+            return f
+        keep = sweep
+        try:
+            sweep = probe(0)
+            t_disp = time_pass(0, reps)
+            sweep = probe(1)
+            t_stream = time_pass(0, reps)
+        finally:
+            sweep = keep
+        roofline["ceiling"] = {"dispatch_only_us": round(t_disp * 1e6, 3), "stream_16B_per_cell_us": round(t_stream * 1e6, 3),
+                               "frac_of_a_pure_stream_kernel": round(b_alg * cells_launch / t_stream / 1e9 / HBM_PEAK_GBS, 4),
+                               "what": "same grid: every wave returns at once / loads its cells of u, Cx, Cy and stores ud"}
     if bw:
         roofline.update(measured_copy_gbs=round(bw["copy"], 1), measured_triad_gbs=round(bw["triad"], 1),
                         frac_of_measured_triad=round(achieved / bw["triad"], 4))
@@ -412,7 +514,9 @@ def main():
         "metric": "Mcells*iters/s residual sweep (%s), %s" % ("Euler HLL-JST-MUSCL" if euler else "advection-JST-MUSCL",
                                                               "3D sphere" if is3d else "2D RAE2822"),
         "value": round(value, 2), "unit": "Mcells*iters/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "warmup": args.warmup, "repeats": len(dts), "ms_per_step": round(ms_per_step, 5),
+        "ms_per_step_min_max": [round(dts[0] / args.steps * 1e3, 5), round(dts[-1] / args.steps * 1e3, 5)],
+        "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {'3D sphere block octree' if is3d else '2D RAE2822 block quadtree'}, "
                                f"{ncells} cells, {msh.nblocks} {'8x8x8' if is3d else '8x8'} blocks, "
@@ -426,7 +530,7 @@ def main():
                             if mixed else "block-fast-path, two kernels"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",
                    "halo": None if hx is None else {"backend": args.backend, "exchange": halo_kind,
-                                                    "overlap": comm_stream is not None,
+                                                    "overlap": comm_stream is not None, "timeouts": halo_timeouts,
                                                     "send_cells": hx.plan.n_send, "recv_cells": hx.plan.n_recv,
                                                     "peers": len(hx.plan.peers),
                                                     "interior_blocks": dpart.info["interior_blocks"]},
@@ -436,7 +540,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler and not is3d:
         cb = cpu_baseline(part, u_h, C_h)
         out["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "Mcells*iters/s", "cores": cb["threads"],
-                               "kind": "port",
+                               "kind": "port", "host_cores": os.cpu_count(), "affinity_cpus": cb["affinity"],
+                               "cgroup_cpu_quota": cb["cgroup_cpus"],
                                "sample": f"{cb['n']} sweeps of the same {u_h.shape[0]}-cell partition in {cb['secs']:.1f} s: "
                                          f"C restatement of the Julia closure (oracle/csrc/residual.c), {cb['form']} form, "
                                          f"OpenMP on {cb['threads']} threads of a {os.cpu_count()}-core host (best of a scan); "

@@ -117,6 +117,17 @@ def _field(t, n=None):
     return t, nv, ld
 
 
+def _field_inplace(t, n=None, what="destination"):
+    """A device field that a kernel WRITES: it must already be Float32 with the cell index fastest (column-major,
+    ``ibamd.hip`` / ``colmajor_empty`` give that), because a silent layout copy would take the update and drop it."""
+    f, nv, ld = _field(t, n)
+    if f.data_ptr() != t.data_ptr() or f.stride() != t.stride():
+        raise TypeError(f"{what} must be a column-major Float32 device array (cell index fastest, e.g. ibamd.hip(a) or "
+                        f"colmajor_empty(n, nv)); got strides {tuple(t.stride())} for shape {tuple(t.shape)}: it would "
+                        "be copied and the update lost")
+    return f, nv, ld
+
+
 def _like(t, n):
     return colmajor_empty(n) if t.ndim == 1 else colmajor_empty(n, t.shape[1])
 
@@ -419,7 +430,12 @@ def residual_advection(part, u, C_, out=None, flags=0):
     C_, nvc, ldc = _field(C_, part.nc)
     if nvc != part.nd:
         raise ValueError("C must be (nc, nd)")
-    ud = out if out is not None else torch.zeros(part.nc, dtype=torch.float32, device=u.device)
+    if out is not None:
+        ud, nvo, _ = _field_inplace(out, part.nc, "out")
+        if nvo != 1 or out.ndim != 1:
+            raise ValueError("out must be a scalar field (nc,)")
+    else:
+        ud = torch.zeros(part.nc, dtype=torch.float32, device=u.device)
     _stream()
     call("ibh_residual_advection", part.handle, _ptr(u), _ptr(C_), ldc, _ptr(ud), flags)
     return ud
@@ -434,7 +450,9 @@ def residual_euler_hll(part, P, fluid_R=283.0, fluid_gamma=1.4, out=None, flags=
     if nv != part.nd + 2:
         raise ValueError("P must be (nc, nd+2) = [p T u v (w)]")
     R = out if out is not None else torch.zeros((nv, part.nc), dtype=torch.float32, device=P.device).T
-    R, _, ldr = _field(R, part.nc)
+    R, nvr, ldr = _field_inplace(R, part.nc, "out")
+    if nvr != nv:
+        raise ValueError(f"out must be (nc, {nv})")
     fl = _lib.ibh_fluid(float(fluid_R), float(fluid_gamma), 0.0, 1.0, 0.0, 0)
     _stream()
     call("ibh_residual_euler_hll", part.handle, _ptr(P), ldp, _ptr(R), ldr, C.byref(fl), flags)
@@ -479,7 +497,7 @@ def impose_bc(f, dom, bname, *args, conv_to_backend=None, conv_from_backend=None
             raise TypeError("impose_bc needs device arrays or conv_to_backend/conv_from_backend (no CPU path)")
         host_args = args
         args = tuple(conv_to_backend(a) for a in args)
-    fields = [_field(a) for a in args]
+    fields = [_field_inplace(a, what="impose_bc argument") for a in args]  # updated in place (:1241-1245)
     for ipart in dom.boundaries[bname]:
         bdry = to_backend(dom.boundaries[bname][ipart])
         iargs = []

@@ -827,12 +827,17 @@ FlatRec flat_of(const ibh_part* p, const int32_t* cells) {
     return r;
 }
 
-int ensure_G(ibh_part* p, size_t floats) {
-    size_t bytes = floats * sizeof(float);
-    if (p->G_bytes >= bytes) return 0;
-    if (p->G) IBH_HIP(hipFree(p->G));
-    p->G = nullptr;
-    p->G_bytes = 0;
+// Gradient workspace of the two-kernel forms: allocated ONCE, on the first sweep that needs it, for the largest sweep
+// of the partition ((nd (nd + 2) + 1) nc floats: the Euler sweep), and kept until ibh_partition_destroy -- a HIP
+// graph captured earlier keeps the pointer, so it must never be freed or moved by a later, larger request.  The
+// single-kernel / quad / image-only paths never touch it and do not allocate it.
+int ensure_G(ibh_part* p) {
+    if (p->G) return 0;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (ibh_stream && hipStreamIsCapturing(ibh_stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+        return ibh_fail(-1, "the gradient workspace is allocated on the first two-kernel sweep of a partition: run one "
+                            "sweep before capturing it into a HIP graph", __FILE__, __LINE__);
+    const size_t bytes = (size_t)(p->nd * (p->nd + 2) + 1) * (size_t)p->nc * sizeof(float);
     IBH_HIP(hipMalloc((void**)&p->G, bytes));
     p->G_bytes = bytes;
     return 0;
@@ -860,9 +865,9 @@ int ibh_set_tuning(const char* key, int value) {
 int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t ldc, float* ud, int flags) {
     IBH_REQUIRE(p && u && C && ud, "ibh_residual_advection: null argument");
     if (p->nc == 0) return 0;
-    int rc = ensure_G(p, (size_t)(p->nd + 1) * p->nc);
-    if (rc) return rc;
+    int rc = 0;
     if (p->nd == 3 && p->bs == 8 && p->blocks3 && p->nblk > 0 && !(flags & (IBH_FORCE_GENERAL | IBH_EXACT))) {
+        if ((rc = ensure_G(p))) return rc;
         // 3-D block path: block kernels over the requested block range + face-list kernels over the rest
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
         IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
@@ -971,6 +976,7 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         const int32_t nI = ph1 ? 0 : p->n_irr;
         const int32_t gI = (nI + 64 * WPB - 1) / (64 * WPB);
         PartView v = view(p);
+        if ((rc = ensure_G(p))) return rc;
         const int32_t nwgA = (g1 - g0 + WPB - 1) / WPB, nwgB = (r1 - r0 + WPB - 1) / WPB;
         if (!(flags & IBH_SWEEP_ONLY)) {
             if (nwgA + gI)
@@ -986,6 +992,7 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         IBH_LAUNCH_CHECK();
         return 0;
     }
+    if ((rc = ensure_G(p))) return rc;
     const bool fast = p->bs == 8 && p->nd == 2 && p->nblk > 0 && !(flags & IBH_FORCE_GENERAL);
     const int bpwg = WPB;  // blocks per workgroup
     // overlap phases: INTERIOR = blocks independent of skirt data, BOUNDARY = the rest + face-list cells
@@ -1045,9 +1052,6 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
                            int flags) {
     IBH_REQUIRE(p && P && R && fluid, "ibh_residual_euler_hll: null argument");
     if (p->nc == 0) return 0;
-    const int nv = p->nd + 2;
-    int rc = ensure_G(p, (size_t)(p->nd * nv + 1) * p->nc);
-    if (rc) return rc;
     const bool tuned2e = p->nd == 2 && p->bs == 8 && p->nblk > 0 &&
                          !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY));
     if (tuned2e && (p->fuse_all || ((flags & IBH_IMAGE_ONLY) && p->img_all_fz))) {
@@ -1071,6 +1075,12 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
         IBH_LAUNCH_CHECK();
         return 0;
     }
+    // the forms below run the whole sweep: they have no overlap phases (the single-kernel branch above does)
+    IBH_REQUIRE(!(flags & (IBH_PHASE_INTERIOR | IBH_PHASE_BOUNDARY)),
+                "ibh_residual_euler_hll: overlap phases need a partition whose (image) blocks are all eligible for the "
+                "single-kernel sweep; run the sweep unphased after the exchange");
+    int rc = ensure_G(p);
+    if (rc) return rc;
     PartView v = view(p);
     dim3 blk(64 * WPB);
     // tuned block path: 2-D only and not with IBH_EXACT (the literal arithmetic lives in the face-list body)

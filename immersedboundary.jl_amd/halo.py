@@ -109,7 +109,7 @@ class HaloExchange:
     def _unpack(self, field, idx, buf):
         if field.is_cuda:
             from . import backend as B
-            f, nv, ld = B._field(field)
+            f, nv, ld = B._field_inplace(field, what="halo field")
             B._stream()
             B.call("ibh_scatter_rows", B._ptr(idx), idx.numel(), B._ptr(buf), nv, idx.numel(), B._ptr(f), ld)
         else:
@@ -223,6 +223,14 @@ class XgmiHalo:
         world = dist.get_world_size(group)
         me = plan.pid - 1
         self.peers_recv, self.peers_send = sorted(plan.recv), sorted(plan.send)
+        # The double-buffer argument (class docstring) needs every peer I write to to be a peer I wait on: only then
+        # am I at most one step ahead of it.  Skirt dependencies are symmetric for face-connected partitions; a
+        # one-sided plan (e.g. donor-extended lists) is rejected here, collectively, instead of racing silently.
+        sym = torch.tensor([1 if self.peers_recv == self.peers_send else 0], dtype=torch.int32,
+                           device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(sym, op=dist.ReduceOp.MIN, group=group)
+        if not bool(sym.item()):
+            raise ValueError("XgmiHalo needs symmetric peers (every send peer is also a receive peer) on every rank")
         self.recv_off, o = {}, 0
         for q in self.peers_recv:
             self.recv_off[q] = o
@@ -291,7 +299,7 @@ class XgmiHalo:
     def start(self, field):
         """The whole exchange, one launch (``ibh_halo_exchange``); ``finish`` has nothing left to do."""
         B, C, nv = self.B, self.C, self.nv
-        f, fnv, ld = B._field(field)
+        f, fnv, ld = B._field_inplace(field, what="halo field")  # skirt cells are written in place
         if fnv != nv:
             raise ValueError(f"XgmiHalo was built for nv={nv}")
         self.step += 1
@@ -319,6 +327,10 @@ class XgmiHalo:
                           device=self.device if self.dist.get_backend(self.group) == "nccl" else "cpu")
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
         return bool(ok.item())
+
+    def reset_health(self):
+        """Clear the time-out flag (after a caller has dealt with a failed ``healthy()``)."""
+        self.state[2] = 0
 
     def close(self):
         torch.cuda.synchronize()

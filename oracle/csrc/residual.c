@@ -12,10 +12,11 @@
  * Two forms of the scalar sweep:
  *   ibo_residual_advection_faithful -- one array pass per reference broadcast (same pass structure and the same
  *       Float32 evaluation order as the Julia code; bit-identical to oracle/domain.py), loops split over OpenMP threads;
- *   ibo_residual_advection_fused    -- one loop over cells, everything of a cell's faces recomputed in registers
- *       (what a hand-fused CPU implementation of the same closure would do); agrees with the faithful form to rounding.
+ *   ibo_residual_advection_fused    -- three passes (cells: gradients + sensor; faces: every flux once; cells: the
+ *       Green-Gauss sum), reciprocals instead of repeated divisions: what a hand-fused CPU implementation of the same
+ *       closure would do; agrees with the faithful form to rounding.
  * Parity unpinned against the reference itself (no Julia here): see DESIGN.md section 5.
- * Built by oracle/Makefile: gcc -O2 -ffp-contract=off -fopenmp.
+ * Built by oracle/Makefile: gcc -O3 -ffp-contract=off -fopenmp.
  */
 #include <math.h>
 #include <stdint.h>
@@ -152,15 +153,18 @@ int ibo_residual_advection_faithful(const ibo_part* p, const float* u, const flo
     return 0;
 }
 
-/* ---- fused form: two loops over cells (gradients + sensor, then fluxes), nothing else stored ---- */
+/* ---- fused form: three passes -- cells (gradients + sensor), faces (every flux ONCE), cells (Green-Gauss) ---- */
 static inline float face_avg(const float* h, const float* u, int32_t o, int32_t n) {
     return (u[o] * h[n] + u[n] * h[o]) / (h[n] + h[o]);
 }
 int ibo_residual_advection_fused(const ibo_part* p, const float* u, const float* C, int64_t ldc, float* ud) {
     const size_t nc = (size_t)p->nc;
     const int nd = p->nd;
-    float* G = (float*)malloc(sizeof(float) * (size_t)(nd + 1) * nc); /* gradients per dim, then the sensor */
+    size_t nftot = 0, foff[4] = {0, 0, 0, 0};
+    for (int d = 0; d < nd; ++d) { foff[d] = nftot; nftot += (size_t)p->nf[d]; }
+    float* G = (float*)malloc(sizeof(float) * ((size_t)(nd + 1) * nc + nftot)); /* gradients per dim, sensor, fluxes */
     if (!G) return -1;
+    float* F = G + (size_t)(nd + 1) * nc;
 #pragma omp parallel for schedule(static)
     for (int32_t c = 0; c < p->nc; ++c) {
         float nu = 1e-7f;
@@ -182,41 +186,41 @@ int ibo_residual_advection_fused(const ibo_part* p, const float* u, const float*
                 const float df = u[n[f]] - u[o[f]];
                 sl += face_avg(h, u, o[f], n[f]) * w; dl += df * w; al += fabsf(df) * w;
             }
-            G[(size_t)d * nc + c] = (sr - sl) / h[c];
-            nu = fmaxf(nu, (1e-7f + fabsf((dr - dl) / h[c])) / (1e-7f + (ar + al) / h[c]));
+            const float rh = 1.0f / h[c];
+            G[(size_t)d * nc + c] = (sr - sl) * rh;
+            nu = fmaxf(nu, (1e-7f + fabsf((dr - dl) * rh)) / (1e-7f + (ar + al) * rh));
         }
         G[(size_t)nd * nc + c] = nu;
     }
     const float* D = G + (size_t)nd * nc;
+    for (int d = 0; d < nd; ++d) {
+        const float* h = p->spacing + (size_t)d * nc;
+        const float* g = G + (size_t)d * nc;
+        const float* Cd = C + (size_t)d * ldc;
+        const int32_t *o = p->owners[d], *n = p->neighbors[d];
+        float* Fd = F + foff[d];
+#pragma omp parallel for schedule(static)
+        for (int32_t f = 0; f < p->nf[d]; ++f) {
+            const int32_t oo = o[f], nn = n[f];
+            const float down = h[oo] * 0.5f, dneigh = h[nn] * 0.5f, inv = 1.0f / (down + dneigh);
+            const float uo = u[oo], un = u[nn], go = g[oo], gn = g[nn];
+            float guf = (un - uo) * inv;
+            const float gu = (2.0f * go - guf) * down, Du = (2.0f * gn - guf) * dneigh;
+            guf = minmod(Du, gu);
+            const float Df = fmaxf(fmaxf(D[oo], D[nn]), 1e-7f);
+            const float uf = (uo * dneigh + un * down) * inv + (go * down - gn * dneigh) * 0.125f;
+            const float uL = (uo + guf) * Df + (1.0f - Df) * uf, uR = (un - guf) * Df + (1.0f - Df) * uf;
+            const float Cf = (Cd[oo] * dneigh + Cd[nn] * down) * inv;
+            Fd[f] = 0.5f * ((uL + uR) * Cf + fabsf(Cf) * (uL - uR));
+        }
+    }
 #pragma omp parallel for schedule(static)
     for (int32_t c = 0; c < p->nc; ++c) {
         float r = 0.0f;
         for (int d = 0; d < nd; ++d) {
-            const float* h = p->spacing + (size_t)d * nc;
-            const float* g = G + (size_t)d * nc;
-            const float* Cd = C + (size_t)d * ldc;
-            const int32_t *o = p->owners[d], *n = p->neighbors[d];
-            float side[2] = {0, 0};
-            for (int s = 0; s < 2; ++s) {
-                const int32_t* off = s ? p->roff[d] : p->loff[d];
-                const int32_t* idx = s ? p->ridx[d] : p->lidx[d];
-                const int32_t a = off[c], b = off[c + 1];
-                const float w = b > a ? 1.0f / (float)(b - a) : 0.0f;
-                for (int32_t k = a; k < b; ++k) {
-                    const int32_t f = idx[k], oo = o[f], nn = n[f];
-                    const float down = h[oo] / 2.0f, dneigh = h[nn] / 2.0f;
-                    float guf = (u[nn] - u[oo]) / (down + dneigh);
-                    const float gu = (2.0f * g[oo] - guf) * down, Du = (2.0f * g[nn] - guf) * dneigh;
-                    guf = minmod(Du, gu);
-                    const float Df = fmaxf(fmaxf(D[oo], D[nn]), 1e-7f);
-                    float uf = (u[oo] * dneigh + u[nn] * down) / (down + dneigh);
-                    uf = uf + (g[oo] * down - g[nn] * dneigh) / 8.0f;
-                    const float uL = (u[oo] + guf) * Df + (1.0f - Df) * uf, uR = (u[nn] - guf) * Df + (1.0f - Df) * uf;
-                    const float Cf = face_avg(h, Cd, oo, nn);
-                    side[s] += ((uL + uR) * Cf / 2.0f + fabsf(Cf) * (uL - uR) / 2.0f) * w;
-                }
-            }
-            r -= (side[1] - side[0]) / h[c];
+            const float* Fd = F + foff[d];
+            r -= (acc_mean(p->roff[d], p->ridx[d], c, Fd) - acc_mean(p->loff[d], p->lidx[d], c, Fd)) /
+                 p->spacing[(size_t)d * nc + c];
         }
         ud[c] = r;
     }

@@ -128,3 +128,25 @@ def test_image_only_flag(adv_domains):
     skirt = np.ones(u.shape[0], bool)
     skirt[img] = False
     assert np.all(got[skirt] == 123.0)                         # skirt rows untouched (ImmersedBoundary.jl:857-859)
+
+
+def test_inplace_arguments_must_be_column_major(adv_domains):
+    """A row-major (n, nv) tensor handed to something that writes it (out=, impose_bc args, halo fields) raises instead
+    of being copied silently (the update would go to the temporary); a wrong-sized `out` is rejected too."""
+    import torch
+    dp, _ = adv_domains
+    part = next(iter(dp.partitions.values()))
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    n = dpart.nc
+    u = ibamd.hip(np.zeros(n, dtype=np.float32))
+    Cc = ibamd.hip(np.ones((n, 2), dtype=np.float32))
+    with pytest.raises(ValueError):
+        ibamd.residual_advection(dpart, u, Cc, out=torch.zeros(n - 1, dtype=torch.float32, device="cuda"))
+    with pytest.raises(TypeError):
+        ibamd.residual_advection(dpart, u, Cc, out=torch.zeros(2 * n, dtype=torch.float32, device="cuda")[::2])
+    P = ibamd.hip(np.ones((n, 4), dtype=np.float32))
+    with pytest.raises(TypeError):
+        ibamd.residual_euler_hll(dpart, P, out=torch.zeros((n, 4), dtype=torch.float32, device="cuda"))  # row-major
+    row_major = torch.zeros((len(dp), 3), dtype=torch.float32, device="cuda")
+    with pytest.raises(TypeError):
+        ibamd.impose_bc(lambda bdry, a: a, dp, "outlet", row_major)
