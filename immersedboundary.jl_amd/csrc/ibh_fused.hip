@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
         const int32_t q = __builtin_amdgcn_readfirstlane(xcd_remap(wgq, nwgq) * WPB + wave);
         if (q < nq)
             quad2::sweep_quad<STAMP, GM>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane,
-                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr);
+                                         STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr);
     } else {
         const int32_t wgs = singles_first ? (int32_t)blockIdx.x : (int32_t)blockIdx.x - nwgq;
         const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(wgs, nwgs) * WPB + wave);

@@ -226,10 +226,13 @@ __device__ __forceinline__ QuadOwn quad_load_own(const QuadLane& G, const QuadTa
     O.CY = *(const v4f*)((const char*)(C + ldc) + ((size_t)O.a0 << 2));
     return O;
 }
-// Halo gathers.  Each costs the memory pipeline about as much as a float4 load of the whole tile when nothing else runs
-// (scripts/probe_sweep.py); inside the sweep they hide behind the arithmetic (measured: dropping the second-slot
-// gathers on quads without a FINE side, or pairing halo + deeper cell in one 8-byte load, changed nothing).
-// GM (measurement only, wrong results unless 127): which of the seven gathers are really performed
+// Halo gathers: seven per quad.  Measured (scripts/probe_sweep.py, profiles/r2_final/README.md): alone each costs
+// about as much as a float4 load of the whole tile; inside the sweep, dropping ALL second-slot gathers is worth 0.35 us
+// of 4.95 (wrong on FINE half-sides), but every exact way of skipping them where the second slot names the same cell
+// as the first -- a wave-uniform branch, a second code path for quads without a FINE side, exec-masked loads, a paired
+// 8-byte load of halo + deeper cell -- measured equal or slower than gathering everything: the sweep ends with its
+// slowest waves, and those are the quads with a FINE side either way.
+// GM: which of the seven gathers are performed (127 = all; anything else: measurement only, wrong results)
 template <int GM = 127>
 __device__ __forceinline__ QuadHalo quad_load_halo(const QuadLane& G, const QuadTab& T, const float* __restrict__ u,
                                                    const float* __restrict__ C, uint32_t ldc) {
@@ -418,7 +421,7 @@ __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, con
                                            float* __restrict__ ud, float* lds, int lane,
                                            unsigned long long* stamps = nullptr) {
     const QuadLane G = quad_lane(lds, lane);
-    const QuadTab T = quad_load_tab(qd, qtab, q, lane);
+    const QuadTab T = quad_load_tab(qd, qtab, q, lane);  // everything that needs the quad's index only is in flight
     const QuadOwn O = quad_load_own(G, T, u, C, ldc);
     const QuadHalo H = quad_load_halo<GM>(G, T, u, C, ldc);
     quad_compute<STAMP>(G, T, O, H, ud, stamps);

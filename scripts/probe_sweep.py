@@ -68,7 +68,7 @@ def sweep_time():
 
 if os.environ.get("QUAD_TUNE"):  # same-process A/B: alternate, keep the best median of each
     best = {}
-    cases = {"both_quads_first": (3, 0), "both_singles_first": (3, 1), "quads_only": (1, 0), "singles_only": (2, 0)}
+    cases = {"both_quads_first": (3, 0), "both_singles_first": (3, 1), "singles_only": (2, 0)}
     for _ in range(3):
         for name_, (parts, sf) in cases.items():
             _lib.call("ibh_set_tuning", b"quad_parts", parts)
