@@ -21,6 +21,8 @@ def __getattr__(name):
     backend = importlib.import_module(__name__ + ".backend")
     if hasattr(backend, name):
         return getattr(backend, name)
+    if name == "HipArray":
+        return getattr(importlib.import_module(__name__ + ".hiparray"), name)
     if name == "FAS":
         return importlib.import_module(__name__ + ".solver").FAS
     raise AttributeError(name)

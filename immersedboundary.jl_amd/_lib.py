@@ -67,6 +67,10 @@ _SIGS = {
     "ibh_scatter_rows": [c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_copy_rows": [c_vp, c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_residual_advection": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
+    "ibh_ew_binary": [c_int, c_i64, c_int, c_vp, c_int, C.c_float, c_vp, c_int, C.c_float, c_vp],
+    "ibh_ew_unary": [c_int, c_i64, c_vp, c_vp],
+    "ibh_ew_fill": [c_i64, C.c_float, c_vp],
+    "ibh_ew_reduce": [c_int, c_i64, c_vp, c_vp],
     "ibh_set_tuning": [C.c_char_p, c_int],
     "ibh_debug_buffer": [c_vp],
     "ibh_probe_sweep": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],

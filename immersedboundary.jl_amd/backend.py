@@ -93,7 +93,29 @@ def hip(a):
 
 def to_host(t):
     """``conv_from_backend``: device array -> numpy array."""
+    if not isinstance(t, torch.Tensor):
+        t = t.t  # HipArray
     return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+def _hipaware(fn):
+    """Operators take and return ``HipArray`` (hiparray.py: broadcast arithmetic through ``ibh_ew_*``) when they are
+    called with one: the Python form of Julia's dispatch on the array type (julia/IBHip.jl)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        from .hiparray import HipArray, rewrap, unwrap
+
+        def un(x):
+            if isinstance(x, tuple):
+                return tuple(un(v) for v in x)
+            return unwrap(x)
+        hit = any(isinstance(a, HipArray) or (isinstance(a, tuple) and any(isinstance(v, HipArray) for v in a))
+                  for a in list(args) + list(kwargs.values()))
+        out = fn(*[un(a) for a in args], **{k: un(v) for k, v in kwargs.items()})
+        return rewrap(out, hit)
+    return wrapper
 
 
 def _field(t, n=None):
@@ -210,6 +232,9 @@ class DeviceAccumulator:
         self.handle = h
 
     def __call__(self, v):
+        from .hiparray import HipArray
+        if isinstance(v, HipArray):
+            return HipArray(self(v.t))
         v, nv, ld = _field(v, self.n_input)
         out = _like(v, self.n_output)
         _stream()
@@ -299,21 +324,25 @@ def _cell_to_face(name, part, u, dim):
     return out
 
 
+@_hipaware
 def at_owners(part, u, dim):
     """:879"""
     return _cell_to_face("ibh_at_owners", part, u, dim)
 
 
+@_hipaware
 def at_neighbors(part, u, dim):
     """:889"""
     return _cell_to_face("ibh_at_neighbors", part, u, dim)
 
 
+@_hipaware
 def at_faces(part, u, dim):
     """:899"""
     return _cell_to_face("ibh_at_faces", part, u, dim)
 
 
+@_hipaware
 def face_gradient(part, u, a, b=None):
     """:1039 ``face_gradient(part,u,dim)`` / :1051 ``face_gradient(part,u,grad_u,dim)``."""
     if b is None:
@@ -332,16 +361,19 @@ def _gg(part, uf, dim, uns):
     return out
 
 
+@_hipaware
 def green_gauss(part, uf, dim):
     """:918"""
     return _gg(part, uf, dim, 0)
 
 
+@_hipaware
 def unsigned_green_gauss(part, uf, dim):
     """:934"""
     return _gg(part, uf, dim, 1)
 
 
+@_hipaware
 def divergent(part, uf):
     """:950"""
     s = green_gauss(part, uf[0], 1)
@@ -350,6 +382,7 @@ def divergent(part, uf):
     return s
 
 
+@_hipaware
 def cell_gradient(part, u, dim=None):
     """:965 / :980"""
     part = _part(part)
@@ -385,6 +418,7 @@ def neighbor_distance(part, dim):
     return _dist("ibh_neighbor_distance", part, dim)
 
 
+@_hipaware
 def JST_sensor(part, p, dim=0):
     """:1077"""
     part = _part(part)
@@ -395,6 +429,7 @@ def JST_sensor(part, p, dim=0):
     return out
 
 
+@_hipaware
 def MUSCL(part, u, du, dim, D=None, high_order=False):
     """:1113"""
     part = _part(part)
@@ -421,6 +456,7 @@ def MUSCL(part, u, du, dim, D=None, high_order=False):
 # ---------------------------------------------------------------------------
 # fused residual sweeps
 # ---------------------------------------------------------------------------
+@_hipaware
 def residual_advection(part, u, C_, out=None, flags=0):
     """Fused closure of test/advection.jl:67-83 (``ud`` from zero): returns ``ud``."""
     part = _part(part)
@@ -441,6 +477,7 @@ def residual_advection(part, u, C_, out=None, flags=0):
     return ud
 
 
+@_hipaware
 def residual_euler_hll(part, P, fluid_R=283.0, fluid_gamma=1.4, out=None, flags=0, fluid=None):
     """Fused Euler residual R2: JST(p) + cell_gradient + MUSCL(high_order) + HLL + green_gauss."""
     part = _part(part)
@@ -491,6 +528,9 @@ def impose_bc(f, dom, bname, *args, conv_to_backend=None, conv_from_backend=None
     """
     if (conv_to_backend is None) != (conv_from_backend is None):
         raise AssertionError("Backend converters must be provided at the same time")
+    from .hiparray import HipArray
+    wrapped = any(isinstance(a, HipArray) for a in args)
+    args = tuple(a.t if isinstance(a, HipArray) else a for a in args)
     host_args = None
     if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
         if conv_to_backend is None:
@@ -506,9 +546,10 @@ def impose_bc(f, dom, bname, *args, conv_to_backend=None, conv_from_backend=None
             ia = _like(a, bdry.ng)
             call("ibh_bc_interp", bdry.handle, _ptr(a), nv, ld, _ptr(ia), bdry.ng)
             iargs.append(ia)
-        r = f(bdry, *iargs, **kwargs)
+        r = f(bdry, *([HipArray(ia) for ia in iargs] if wrapped else iargs), **kwargs)
         if not isinstance(r, tuple):
             r = (r,)
+        r = tuple(x.t if isinstance(x, HipArray) else x for x in r)
         for (a, nv, ld), ba, ia in zip(fields, r, iargs):
             if isinstance(ba, torch.Tensor):
                 ba, nvb, ldb = _field(ba.expand_as(ia) if ba.shape != ia.shape else ba, bdry.ng)

@@ -1,0 +1,177 @@
+// libibhip: elementwise kernels behind `Base.Broadcast` on device arrays (julia/IBHip.jl) -- what a user closure
+// writes between the operators, e.g. `@. (uL + uR) * Cf / 2 + abs(Cf) * (uL - uR) / 2` and `ud .-= ...`
+// (/root/reference/test/advection.jl:67-83), `max.(a, b)` and `maximum(...)` (:52-59).  One launch per broadcast node;
+// HBM-bound (8-12 B per element).  Fields are column-major (n, nv); an operand is a field of the same shape, a column
+// vector (n,) broadcast over the columns, or a scalar.
+#include "ibh_common.h"
+
+namespace {
+
+template <int OP>
+__device__ __forceinline__ float ew2(float a, float b) {
+    if (OP == IBH_EW_ADD) return a + b;
+    if (OP == IBH_EW_SUB) return a - b;
+    if (OP == IBH_EW_MUL) return a * b;
+    if (OP == IBH_EW_DIV) return a / b;
+    if (OP == IBH_EW_MAX) return fmaxf(a, b);
+    return fminf(a, b);
+}
+
+// out[i + j n] = a(i, j) OP b(i, j); an operand with nv* == 1 is a column vector, a null pointer a scalar
+template <int OP>
+__global__ __launch_bounds__(256) void k_ew_binary(int64_t n, int nv, const float* __restrict__ a, int nva, float sa,
+                                                   const float* __restrict__ b, int nvb, float sb, float* out) {
+    const int64_t total = n * nv;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t % n;
+        const float x = a ? (nva == 1 ? a[i] : a[t]) : sa;
+        const float y = b ? (nvb == 1 ? b[i] : b[t]) : sb;
+        out[t] = ew2<OP>(x, y);
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_ew_unary(int64_t total, const float* __restrict__ a, float* out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const float x = a[t];
+        out[t] = OP == IBH_EW_ABS ? fabsf(x) : OP == IBH_EW_NEG ? -x : OP == IBH_EW_SQRT ? sqrtf(x) : x;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ew_fill(int64_t total, float v, float* out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = v;
+}
+
+template <int OP>
+__device__ __forceinline__ float red2(float a, float b) {
+    return OP == IBH_EW_SUM ? a + b : OP == IBH_EW_MAX ? fmaxf(a, b) : fminf(a, b);
+}
+template <int OP>
+__device__ __forceinline__ float red_identity() {
+    return OP == IBH_EW_SUM ? 0.0f : OP == IBH_EW_MAX ? -INFINITY : INFINITY;
+}
+template <int OP>
+__device__ __forceinline__ float block_reduce(float v, float* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = red2<OP>(v, __shfl_down(v, o, 64));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    v = threadIdx.x < (blockDim.x >> 6) ? sm[threadIdx.x] : red_identity<OP>();
+    if (w == 0) {
+#pragma unroll
+        for (int o = 2; o > 0; o >>= 1) v = red2<OP>(v, __shfl_down(v, o, 64));
+    }
+    return v;
+}
+// one launch: every block reduces its stride of the array, the last block to finish combines the partials
+template <int OP>
+__global__ __launch_bounds__(256) void k_ew_reduce(int64_t total, const float* __restrict__ a, float* part,
+                                                   unsigned int* counter, float* out) {
+    __shared__ float sm[4];
+    __shared__ bool last;
+    float v = red_identity<OP>();
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+        v = red2<OP>(v, a[t]);
+    v = block_reduce<OP>(v, sm);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = v;
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    v = red_identity<OP>();
+    for (unsigned t = threadIdx.x; t < gridDim.x; t += blockDim.x) v = red2<OP>(v, ((volatile float*)part)[t]);
+    __syncthreads();
+    v = block_reduce<OP>(v, sm);
+    if (threadIdx.x == 0) {
+        *out = v;
+        *counter = 0;  // ready for the next launch on this stream
+    }
+}
+
+// scratch of the reductions: partials of up to 1024 blocks + the arrival counter (one per host thread)
+struct RedScratch {
+    float* part = nullptr;
+    unsigned int* counter = nullptr;
+};
+thread_local RedScratch red_scratch;
+
+int ensure_scratch() {
+    if (red_scratch.part) return 0;
+    IBH_HIP(hipMalloc((void**)&red_scratch.part, 1024 * sizeof(float)));
+    IBH_HIP(hipMalloc((void**)&red_scratch.counter, sizeof(unsigned int)));
+    IBH_HIP(hipMemset(red_scratch.counter, 0, sizeof(unsigned int)));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ibh_ew_binary(int op, int64_t n, int nv, const float* a, int nva, float sa, const float* b, int nvb, float sb,
+                  float* out) {
+    IBH_REQUIRE(out && n >= 0 && nv >= 1, "ibh_ew_binary: bad argument");
+    IBH_REQUIRE((!a || nva == nv || nva == 1) && (!b || nvb == nv || nvb == 1),
+                "ibh_ew_binary: an operand is a field of the result's shape, a column vector (nv = 1) or a scalar (NULL)");
+    if (n * nv == 0) return 0;
+    const dim3 grid(ibh_grid(n * nv, 256 * 4)), blk(256);
+#define EW2(OP) hipLaunchKernelGGL(k_ew_binary<OP>, grid, blk, 0, ibh_stream, n, nv, a, nva, sa, b, nvb, sb, out)
+    switch (op) {
+        case IBH_EW_ADD: EW2(IBH_EW_ADD); break;
+        case IBH_EW_SUB: EW2(IBH_EW_SUB); break;
+        case IBH_EW_MUL: EW2(IBH_EW_MUL); break;
+        case IBH_EW_DIV: EW2(IBH_EW_DIV); break;
+        case IBH_EW_MAX: EW2(IBH_EW_MAX); break;
+        case IBH_EW_MIN: EW2(IBH_EW_MIN); break;
+        default: return ibh_fail(-1, "ibh_ew_binary: unknown operation", __FILE__, __LINE__);
+    }
+#undef EW2
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_ew_unary(int op, int64_t total, const float* a, float* out) {
+    IBH_REQUIRE(a && out && total >= 0, "ibh_ew_unary: bad argument");
+    if (total == 0) return 0;
+    const dim3 grid(ibh_grid(total, 256 * 4)), blk(256);
+    switch (op) {
+        case IBH_EW_ABS: hipLaunchKernelGGL(k_ew_unary<IBH_EW_ABS>, grid, blk, 0, ibh_stream, total, a, out); break;
+        case IBH_EW_NEG: hipLaunchKernelGGL(k_ew_unary<IBH_EW_NEG>, grid, blk, 0, ibh_stream, total, a, out); break;
+        case IBH_EW_SQRT: hipLaunchKernelGGL(k_ew_unary<IBH_EW_SQRT>, grid, blk, 0, ibh_stream, total, a, out); break;
+        case IBH_EW_COPY: hipLaunchKernelGGL(k_ew_unary<IBH_EW_COPY>, grid, blk, 0, ibh_stream, total, a, out); break;
+        default: return ibh_fail(-1, "ibh_ew_unary: unknown operation", __FILE__, __LINE__);
+    }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_ew_fill(int64_t total, float value, float* out) {
+    IBH_REQUIRE(out && total >= 0, "ibh_ew_fill: bad argument");
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_ew_fill, dim3(ibh_grid(total, 256 * 4)), dim3(256), 0, ibh_stream, total, value, out);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_ew_reduce(int op, int64_t total, const float* a, float* out_device) {
+    IBH_REQUIRE(a && out_device && total >= 1, "ibh_ew_reduce: bad argument (an empty reduction has no value)");
+    int rc = ensure_scratch();
+    if (rc) return rc;
+    const dim3 grid(std::min(1024, ibh_grid(total, 256 * 8))), blk(256);
+    float* part = red_scratch.part;
+    unsigned int* cnt = red_scratch.counter;
+    switch (op) {
+        case IBH_EW_SUM: hipLaunchKernelGGL(k_ew_reduce<IBH_EW_SUM>, grid, blk, 0, ibh_stream, total, a, part, cnt, out_device); break;
+        case IBH_EW_MAX: hipLaunchKernelGGL(k_ew_reduce<IBH_EW_MAX>, grid, blk, 0, ibh_stream, total, a, part, cnt, out_device); break;
+        case IBH_EW_MIN: hipLaunchKernelGGL(k_ew_reduce<IBH_EW_MIN>, grid, blk, 0, ibh_stream, total, a, part, cnt, out_device); break;
+        default: return ibh_fail(-1, "ibh_ew_reduce: unknown operation", __FILE__, __LINE__);
+    }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -95,6 +95,20 @@ int ibh_partition_destroy(ibh_part* part);
  *       blocks outside them when every block is eligible, [14] / [15] = the same among the image blocks. */
 int ibh_partition_info(const ibh_part* part, int64_t* info, int n);
 
+/* ---- Elementwise kernels: what `Base.Broadcast` on device arrays lowers to in the reference-side binding
+ * (julia/IBHip.jl) -- the arithmetic a user closure writes between the operators, e.g.
+ * `@. (uL + uR) * Cf / 2 + abs(Cf) * (uL - uR) / 2`, `ud .-= ...` (test/advection.jl:67-83), `max.(a, b)` and
+ * `maximum(...)` (:52-59).  Fields are column-major (n, nv), contiguous.  An operand of ibh_ew_binary is a field of
+ * the result's shape (nv* == nv), a column vector broadcast over the columns (nv* == 1) or a scalar (pointer NULL,
+ * value s*).  `out` may alias an operand.  ibh_ew_reduce leaves its scalar on the device. */
+enum { IBH_EW_ADD = 0, IBH_EW_SUB = 1, IBH_EW_MUL = 2, IBH_EW_DIV = 3, IBH_EW_MAX = 4, IBH_EW_MIN = 5, IBH_EW_SUM = 6 };
+enum { IBH_EW_ABS = 16, IBH_EW_NEG = 17, IBH_EW_SQRT = 18, IBH_EW_COPY = 19 };
+int ibh_ew_binary(int op, int64_t n, int nv, const float* a, int nva, float sa, const float* b, int nvb, float sb,
+                  float* out);
+int ibh_ew_unary(int op, int64_t total, const float* a, float* out);
+int ibh_ew_fill(int64_t total, float value, float* out);
+int ibh_ew_reduce(int op, int64_t total, const float* a, float* out_device);
+
 /* Measurement switches of the kernels (A/B runs inside one process); key "quad_variant": variant of the quad sweep. */
 int ibh_set_tuning(const char* key, int value);
 /* Wave timeline of the quad sweep (quad_variant 4): 8 x uint64 per wave {start, end (100 MHz ticks), HW_ID, is_quad, 4 phase stamps of a quad wave}. */

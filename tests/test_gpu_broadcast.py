@@ -1,0 +1,105 @@
+"""The closure of /root/reference/test/advection.jl:47-83 VERBATIM -- same expression tree, the broadcast arithmetic
+between the operators going through the elementwise entry points of the C ABI (``ibh_ew_*``) exactly as
+``Base.Broadcast`` on a ``HipArray`` does in julia/IBHip.jl -- against the oracle's numpy statement of the same lines.
+Plus the elementwise kernels on their own."""
+import numpy as np
+import pytest
+
+import ibamd
+from conftest import rel_inf, seeded_field
+from oracle import domain as od
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+KW = dict(conv_to_backend=lambda a: ibamd.HipArray(a), conv_from_backend=lambda a: ibamd.to_host(a))
+
+
+def test_elementwise_kernels():
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-2, 2, (1000, 3)).astype(f32)
+    b = rng.uniform(0.5, 2, (1000, 3)).astype(f32)
+    v = rng.uniform(0.5, 2, 1000).astype(f32)
+    A, Bm, V = ibamd.HipArray(a), ibamd.HipArray(b), ibamd.HipArray(v)
+    assert np.array_equal((A + Bm).to_host(), a + b)
+    assert np.array_equal((A - Bm).to_host(), a - b)
+    assert np.array_equal((A * Bm).to_host(), a * b)
+    assert np.allclose((A / Bm).to_host(), a / b, rtol=1e-6)       # IEEE division on both sides
+    assert np.array_equal((A * V).to_host(), a * v[:, None])        # column vector over the columns
+    assert np.array_equal((V * A).to_host(), a * v[:, None])
+    assert np.array_equal((A / 2).to_host(), a / f32(2))
+    assert np.array_equal((2 - A).to_host(), f32(2) - a)
+    assert np.array_equal(abs(A).to_host(), np.abs(a))
+    assert np.array_equal((-A).to_host(), -a)
+    assert np.array_equal(A.maximum_with(Bm).to_host(), np.maximum(a, b))
+    assert A.maximum() == a.max() and A.minimum() == a.min()
+    assert abs(A.sum() - a.sum(dtype=np.float64)) <= 1e-3
+    c = A.copy()
+    c -= Bm
+    c += 1
+    assert np.array_equal(c.to_host(), a - b + f32(1))
+    assert np.array_equal(A.col(2).to_host(), a[:, 1])
+    z = A.similar().fill(0)
+    assert not z.to_host().any()
+    with pytest.raises(TypeError):
+        A[0]
+    with pytest.raises(ValueError):
+        A + ibamd.HipArray(np.zeros((999, 3), f32))
+
+
+def test_advection_closure_verbatim(adv_domains):
+    dp, do = adv_domains
+    n = len(dp)
+    X = dp.global_centers()
+    u0 = seeded_field(X, kind="step")
+    Cx, Cy = np.ones(n, f32), np.ones(n, f32)
+    C = np.stack([Cx, Cy], axis=1)
+
+    # ---- oracle: advection.jl:52-59 and :67-83 in numpy
+    def o_dt(part, cx, cy):
+        return f32(0.5) / np.max(np.maximum(od.unsigned_green_gauss(part, od.at_faces(part, cx, 1), 1),
+                                            od.unsigned_green_gauss(part, od.at_faces(part, cy, 2), 2)))
+
+    def o_closure(part, u, ud, Cl):
+        D = od.JST_sensor(part, u)
+        for dim in (1, 2):
+            Cf = od.at_faces(part, np.ascontiguousarray(Cl[:, dim - 1]), dim)
+            gu = od.cell_gradient(part, u, dim)
+            uL, uR = od.MUSCL(part, u, gu, dim, D=D, high_order=True)
+            ud -= od.green_gauss(part, (uL + uR) * Cf / f32(2) + np.abs(Cf) * (uL - uR) / f32(2), dim)
+
+    # ---- the same lines against the binding: every array below is a HipArray, every operator between them an ibh_ew_*
+    def timestep_length(part, cx, cy):
+        return 0.5 / ibamd.unsigned_green_gauss(part, ibamd.at_faces(part, cx, 1), 1).maximum_with(
+            ibamd.unsigned_green_gauss(part, ibamd.at_faces(part, cy, 2), 2)).maximum()
+
+    def closure(part, u, ud, C):
+        D = ibamd.JST_sensor(part, u)
+        for dim in range(1, part.ndims + 1):
+            Cd = C.col(dim)                                   # Cd = @view C[:, dim]
+            Cf = ibamd.at_faces(part, Cd, dim)
+            gu = ibamd.cell_gradient(part, u, dim)
+            uL, uR = ibamd.MUSCL(part, u, gu, dim, D=D, high_order=True)
+            ud -= ibamd.green_gauss(part, (uL + uR) * Cf / 2 + abs(Cf) * (uL - uR) / 2, dim)   # ud .-= green_gauss(...)
+        assert all(isinstance(x, ibamd.HipArray) for x in (D, Cf, gu, uL, uR, ud))
+
+    dt_o = min(do(o_dt, Cx, Cy)) * f32(0.75)
+    dt_g = min(dp(timestep_length, Cx, Cy, **KW)) * f32(0.75)
+    assert abs(dt_o - dt_g) <= 1e-6 * dt_o
+    uo, ug = u0.copy(), u0.copy()
+    for _ in range(2):
+        udo, udg = np.zeros(n, f32), np.zeros(n, f32)
+        do(o_closure, uo, udo, C)
+        dp(closure, ug, udg, C, **KW)
+        assert rel_inf(udg, udo) <= 1e-5
+        uo += udo * dt_o
+        ug += udg * dt_o
+        # impose_bc! with the closures of advection.jl:33-46 on device-resident arrays
+        od.impose_bc(lambda b, ui: f32(1.0), do, "upper", uo)
+        od.impose_bc(lambda b, ui: f32(0.0), do, "lower", uo)
+        od.impose_bc(lambda b, ui: ui.copy(), do, "outlet", uo)
+        dev = ibamd.HipArray(ug)
+        ibamd.impose_bc(lambda b, ui: 1.0, dp, "upper", dev)
+        ibamd.impose_bc(lambda b, ui: 0.0, dp, "lower", dev)
+        ibamd.impose_bc(lambda b, ui: ui.copy(), dp, "outlet", dev)
+        ug = dev.to_host()
+        assert rel_inf(ug, uo) <= 1e-5
