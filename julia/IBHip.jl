@@ -2,12 +2,16 @@
 # residual hot path on MI355X through libibhip.so (C ABI: include/ibhip.h).
 #
 # It plugs into the reference's own hooks and nothing else:
-#   * `conv_to_backend = IBHip.hip`, `conv_from_backend = Array` in `dom(f, args...)` and `impose_bc!`
-#     (/root/reference/src/ImmersedBoundary.jl:823-824, :846-855, :1202-1203);
+#   * `conv_to_backend = IBHip.converter(dom)` (or `IBHip.hip`), `conv_from_backend = Array` in `dom(f, args...)`
+#     and `impose_bc!` (/root/reference/src/ImmersedBoundary.jl:823-824, :846-855, :1202-1203);
 #   * `ArrayBackends.to_backend(part, hip)` (src/arraybends.jl:14-77, registered for Partition at
 #     src/ImmersedBoundary.jl:788) -- specialised here to upload ONCE and cache a native handle;
 #   * Julia multiple dispatch on the operators (src/ImmersedBoundary.jl:873-1157): methods for
-#     `HipPartition` + `HipArray` that `ccall` the library.  User closures stay unchanged.
+#     `HipPartition` + `HipArray` that `ccall` the library, including `divergent`, the tuple `face_gradient`, the
+#     `Accumulator` call and `impose_bc!` on device-resident arrays;
+#   * `Base.Broadcast` on `HipArray`: every broadcast node (`+ - * / max min abs`, scalars, `.=`, `.-=`, `@.`)
+#     becomes one elementwise kernel (`ibh_ew_*`), so closures like test/advection.jl:67-83 run unchanged --
+#     tests/test_gpu_broadcast.py runs exactly that expression tree through the same C entry points from Python.
 #
 # No KernelAbstractions, no CUDA.jl/AMDGPU.jl: device memory is owned by the library
 # (ibh_malloc/ibh_free) behind `HipArray`.  There is no Julia runtime in the build container, so this
@@ -16,8 +20,9 @@
 module IBHip
 
 using ImmersedBoundary
-import ImmersedBoundary: Partition, Boundary, at_owners, at_neighbors, at_faces, green_gauss,
-    unsigned_green_gauss, cell_gradient, face_distance, owner_distance, neighbor_distance, face_gradient, MUSCL
+import ImmersedBoundary: Partition, Boundary, Domain, Accumulator, at_owners, at_neighbors, at_faces, green_gauss,
+    unsigned_green_gauss, cell_gradient, face_distance, owner_distance, neighbor_distance, face_gradient, MUSCL,
+    divergent, impose_bc!
 import ImmersedBoundary.CFD: JST_sensor
 import ImmersedBoundary.ArrayBackends: to_backend
 
@@ -36,18 +41,25 @@ init(device::Integer = 0) = check(ccall((:ibh_init, lib), Cint, (Cint,), device)
 mutable struct HipArray{T, N} <: AbstractArray{T, N}
     ptr::Ptr{Cvoid}
     dims::NTuple{N, Int}
+    parent::Any   # the array a column view aliases (kept alive), or nothing for an owning array
     function HipArray{T, N}(::UndefInitializer, dims::NTuple{N, Int}) where {T, N}
         p = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:ibh_malloc, lib), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, max(prod(dims), 1) * sizeof(T)))
-        a = new{T, N}(p[], dims)
+        a = new{T, N}(p[], dims, nothing)
         finalizer(x -> ccall((:ibh_free, lib), Cint, (Ptr{Cvoid},), x.ptr), a)
         a
     end
+    # non-owning alias (no finalizer): `@view C[:, dim]`
+    HipArray{T, N}(ptr::Ptr{Cvoid}, dims::NTuple{N, Int}, parent) where {T, N} = new{T, N}(ptr, dims, parent)
 end
 HipArray{T}(u::UndefInitializer, dims::Int...) where {T} = HipArray{T, length(dims)}(u, dims)
 Base.size(a::HipArray) = a.dims
 Base.similar(a::HipArray{T}, ::Type{S}, dims::Dims) where {T, S} = HipArray{S, length(dims)}(undef, dims)
 Base.getindex(::HipArray, i...) = error("scalar indexing of a HipArray; copy it back with Array(a)")
+# columns of a column-major (n, nv) field are contiguous: `@view C[:, dim]` / `C[:, dim]` alias them
+Base.view(a::HipArray{T, 2}, ::Colon, j::Integer) where {T} =
+    HipArray{T, 1}(a.ptr + (j - 1) * size(a, 1) * sizeof(T), (size(a, 1),), a)
+Base.getindex(a::HipArray{T, 2}, ::Colon, j::Integer) where {T} = copy(view(a, :, j))
 
 "`conv_to_backend`: host array -> device array."
 function hip(a::Array{T, N}) where {T, N}
@@ -67,6 +79,93 @@ end
 
 ld(a::HipArray) = Int64(size(a, 1))
 nv(a::HipArray) = Cint(length(a) ÷ max(size(a, 1), 1))
+
+"The converter handed to `conv_to_backend`: callable like `hip`, and carries what `to_backend(::Partition, conv)` cannot
+see in a `Partition` -- the mesh's block size (`dom.mesh.block_size`, src/mesher.jl:977), which switches the library's
+block-structured fast path on (it still verifies every block against the face lists)."
+struct HipConv
+    block_size::Int
+end
+(c::HipConv)(a) = hip(a)
+converter(dom::Domain) = HipConv(dom.mesh.block_size)
+
+# ---------------------------------------------------------------------------------------------------
+# Base.Broadcast: one elementwise kernel per node of the broadcast tree (include/ibhip.h, ibh_ew_*)
+# ---------------------------------------------------------------------------------------------------
+const EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_MAX, EW_MIN, EW_SUM = Cint.(0:6)
+const EW_ABS, EW_NEG, EW_SQRT, EW_COPY = Cint.(16:19)
+const _binop = IdDict{Any, Cint}(+ => EW_ADD, - => EW_SUB, * => EW_MUL, / => EW_DIV, max => EW_MAX, min => EW_MIN)
+const _unop = IdDict{Any, Cint}(abs => EW_ABS, - => EW_NEG, sqrt => EW_SQRT, identity => EW_COPY, + => EW_COPY)
+
+struct HipStyle <: Base.Broadcast.BroadcastStyle end
+Base.Broadcast.BroadcastStyle(::Type{<:HipArray}) = HipStyle()
+Base.Broadcast.BroadcastStyle(::HipStyle, ::Base.Broadcast.DefaultArrayStyle{0}) = HipStyle()   # scalars
+Base.Broadcast.BroadcastStyle(::HipStyle, ::Base.Broadcast.BroadcastStyle) =
+    error("broadcast between a HipArray and a host array: convert it with IBHip.hip first")
+
+_rows(a::HipArray) = size(a, 1)
+_operand(a::HipArray) = (a.ptr, nv(a), 0f0)
+_operand(x::Number) = (C_NULL, Cint(0), Float32(x))
+_operand(x::Base.RefValue) = _operand(x[])
+
+"Evaluate one node: operands are HipArrays (same shape, or a column vector over the columns) or scalars."
+function _ew(op, a, b, out::Union{HipArray, Nothing} = nothing)
+    code = get(_binop, op) do
+        error("IBHip broadcast: unsupported binary operation $op")
+    end
+    arrs = filter(x -> x isa HipArray, (a, b))
+    isempty(arrs) && return op(a, b)
+    big = arrs[argmax(map(length, arrs))]
+    o = isnothing(out) ? similar(big) : out
+    (pa, na, sa), (pb, nb, sb) = _operand(a), _operand(b)
+    check(ccall((:ibh_ew_binary, lib), Cint,
+        (Cint, Int64, Cint, Ptr{Cvoid}, Cint, Cfloat, Ptr{Cvoid}, Cint, Cfloat, Ptr{Cvoid}),
+        code, _rows(big), nv(big), pa, na, sa, pb, nb, sb, o.ptr))
+    o
+end
+function _ew(op, a::HipArray, out::Union{HipArray, Nothing} = nothing)
+    code = get(_unop, op) do
+        error("IBHip broadcast: unsupported unary operation $op")
+    end
+    o = isnothing(out) ? similar(a) : out
+    check(ccall((:ibh_ew_unary, lib), Cint, (Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}), code, length(a), a.ptr, o.ptr))
+    o
+end
+
+# recursive evaluation of a (possibly nested, `@.`-fused) Broadcasted tree; n-ary + and * fold left like Julia does
+_eval(x) = x
+_eval(bc::Base.Broadcast.Broadcasted) = _node(bc.f, map(_eval, bc.args)...)
+_node(f, a) = a isa HipArray ? _ew(f, a) : f(a)
+_node(f, a, b) = _ew(f, a, b)
+_node(f::Union{typeof(+), typeof(*)}, a, b, c, rest...) = _node(f, _ew(f, a, b), c, rest...)
+
+Base.copy(bc::Base.Broadcast.Broadcasted{HipStyle}) = _eval(bc)
+function Base.copyto!(dest::HipArray, bc::Base.Broadcast.Broadcasted{HipStyle})
+    # `dest .= f.(dest, x)` / `dest .-= x`: the top node writes straight into dest
+    if length(bc.args) == 2 && haskey(_binop, bc.f)
+        a, b = map(_eval, bc.args)
+        _ew(bc.f, a, b, dest)
+    else
+        r = _eval(bc)
+        r isa HipArray ? _ew(identity, r, dest) : fill!(dest, r)
+    end
+    dest
+end
+Base.copyto!(dest::HipArray, bc::Base.Broadcast.Broadcasted{<:Base.Broadcast.DefaultArrayStyle{0}}) = fill!(dest, bc[])
+function Base.fill!(a::HipArray{Float32}, v)
+    check(ccall((:ibh_ew_fill, lib), Cint, (Int64, Cfloat, Ptr{Cvoid}), length(a), Float32(v), a.ptr))
+    a
+end
+Base.copy(a::HipArray) = _ew(identity, a)
+
+function _reduce(code::Cint, a::HipArray{Float32})
+    out = HipArray{Float32, 1}(undef, (1,))
+    check(ccall((:ibh_ew_reduce, lib), Cint, (Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}), code, length(a), a.ptr, out.ptr))
+    Array(out)[1]
+end
+Base.maximum(a::HipArray{Float32}) = _reduce(EW_MAX, a)
+Base.minimum(a::HipArray{Float32}) = _reduce(EW_MIN, a)
+Base.sum(a::HipArray{Float32}) = _reduce(EW_SUM, a)
 
 # ---------------------------------------------------------------------------------------------------
 # Partition on the device: to_backend(part, hip) uploads once (the reference re-uploads per call, :848)
@@ -99,7 +198,8 @@ function csr(acc, n::Int)
     off, idx
 end
 
-function to_backend(part::Partition{Ti, Tf}, ::typeof(hip)) where {Ti, Tf}
+to_backend(part::Partition, ::typeof(hip)) = to_backend(part, HipConv(8))   # mesher.jl:977 default; verified by the library
+function to_backend(part::Partition{Ti, Tf}, conv::HipConv) where {Ti, Tf}
     get!(_cache, part) do
         nd = ndims(part)
         nc = size(part.spacing, 1)
@@ -121,7 +221,7 @@ function to_backend(part::Partition{Ti, Tf}, ::typeof(hip)) where {Ti, Tf}
                  Int32, Ptr{Int32}, Ptr{Int32}, Cint, Cint),
                 h, nd, nc, Array(part.spacing), Array(part.centers), nf,
                 ptrs(owners), ptrs(neighs), ptrs(loff), ptrs(lidx), ptrs(roff), ptrs(ridx),
-                length(iid), iid, domain, 8 #= mesh.block_size =#, 1 #= Julia indices =#))
+                length(iid), iid, domain, conv.block_size, 1 #= Julia indices =#))
         end
         hp = HipPartition{Ti, Tf}(h[], part, nc, Int.(nf), hip(Array(part.spacing)), hip(Array(part.centers)))
         hp
@@ -186,6 +286,118 @@ function MUSCL(part::HipPartition, u::HipArray, δu::HipArray, dim::Int;
     (uL, uR)
 end
 
+"`divergent(part, uf::Tuple)` (:950-956): sum over dims of `green_gauss`, accumulated in place."
+function divergent(part::HipPartition, uf::Tuple)
+    r = green_gauss(part, uf[1], 1)
+    for dim = 2:ndims(part)
+        r .+= green_gauss(part, uf[dim], dim)
+    end
+    r
+end
+
+"`face_gradient(part, u, ∇u::Tuple, dim)` (:1051-1069): normal component from the face difference, the others from `at_faces(∇u[i])`."
+face_gradient(part::HipPartition, u::HipArray, ∇u::Tuple, dim::Int) =
+    tuple((i == dim ? face_gradient(part, u, dim) : at_faces(part, ∇u[i], dim) for i = 1:ndims(part))...)
+
+# ---------------------------------------------------------------------------------------------------
+# Accumulator on the device (src/accumulator.jl:78-130, defaults op = +, f = identity, Δ = false: the only form the
+# reference's callers use) -- interpolators of `impose_bc!`, coarseners / prolongators of `multigrid`
+# ---------------------------------------------------------------------------------------------------
+struct HipAccumulator
+    handle::Ptr{Cvoid}
+    n_output::Int
+    n_input::Int
+end
+
+"Bucketed stencils + weights -> CSR with weights (1-based indices)."
+function csr_weighted(acc::Accumulator)
+    off, idx = csr(acc, acc.n_output)
+    w = ones(Float32, length(idx))
+    for (len, (rows, _, wt)) in acc.stencils
+        isnothing(wt) && continue
+        for (k, r) in enumerate(rows), j = 1:len
+            w[off[r] + j - 1] = wt[j, k]
+        end
+    end
+    off, idx, w
+end
+
+function to_backend(acc::Accumulator, ::Union{typeof(hip), HipConv})
+    get!(_cache, acc) do
+        off, idx, w = csr_weighted(acc)
+        n_in = isempty(idx) ? 0 : Int(maximum(idx))
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ibh_acc_create, lib), Cint,
+            (Ptr{Ptr{Cvoid}}, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Float32}, Cint),
+            h, acc.n_output, n_in, off, idx, w, 1))
+        HipAccumulator(h[], acc.n_output, n_in)
+    end
+end
+
+function (acc::HipAccumulator)(v::HipArray)
+    out = out_like(v, acc.n_output)
+    check(ccall((:ibh_accumulate, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64),
+        acc.handle, v.ptr, nv(v), ld(v), out.ptr, ld(out)))
+    out
+end
+
+# ---------------------------------------------------------------------------------------------------
+# impose_bc! on device-resident global arrays (src/ImmersedBoundary.jl:1197-1247): per boundary chunk
+#   ia = W * a[image_domain]  (ibh_bc_interp),  ba = f(bdry, ia...),  a[ghost] = η ia + (1 - η) ba  (ibh_bc_blend)
+# ---------------------------------------------------------------------------------------------------
+struct HipBoundary{Ti, Tf}
+    handle::Ptr{Cvoid}
+    host::Boundary{Ti, Tf}
+    ng::Int
+    projections::HipArray{Tf, 2}
+    normals::HipArray{Tf, 2}
+    image_distances::HipArray{Tf, 1}
+    ghost_distances::HipArray{Tf, 1}
+end
+
+function to_backend(b::Boundary{Ti, Tf}, ::Union{typeof(hip), HipConv}) where {Ti, Tf}
+    get!(_cache, b) do
+        off, idx, w = csr_weighted(b.image_interpolator)
+        gi, idm = Int32.(b.ghost_indices), Int32.(b.image_domain)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ibh_bc_create, lib), Cint,
+            (Ptr{Ptr{Cvoid}}, Int32, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Int32, Ptr{Int32},
+             Ptr{Int32}, Ptr{Int32}, Ptr{Float32}, Cint),
+            h, length(gi), gi, Float32.(b.ghost_distances), Float32.(b.image_distances), length(idm), idm,
+            off, idx, w, 1))
+        HipBoundary{Ti, Tf}(h[], b, length(gi), hip(Array(b.projections)), hip(Array(b.normals)),
+                            hip(Array(b.image_distances)), hip(Array(b.ghost_distances)))
+    end
+end
+
+function impose_bc!(f, dom::Domain, bname::String, args::HipArray{Float32}...; kwargs...)
+    for (_, b) in dom.boundaries[bname]
+        bdry = to_backend(b, hip)
+        iargs = map(args) do a
+            ia = out_like(a, bdry.ng)
+            check(ccall((:ibh_bc_interp, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64),
+                bdry.handle, a.ptr, nv(a), ld(a), ia.ptr, ld(ia)))
+            ia
+        end
+        r = f(bdry, iargs...; kwargs...)
+        r isa Tuple || (r = (r,))
+        for (a, ba, ia) in zip(args, r, iargs)
+            if ba isa HipArray       # an array of boundary values, (ng,) broadcast over the columns or (ng, nv)
+                bfull = size(ba) == size(ia) ? ba : ia .* 0f0 .+ ba
+                check(ccall((:ibh_bc_blend, lib), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cfloat}),
+                    bdry.handle, a.ptr, nv(a), ld(a), ia.ptr, ld(ia), bfull.ptr, ld(bfull), C_NULL))
+            else                     # a constant (per variable): the closure returned a number
+                c = fill(Float32(ba), Int(nv(a)))
+                check(ccall((:ibh_bc_blend, lib), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cfloat}),
+                    bdry.handle, a.ptr, nv(a), ld(a), ia.ptr, ld(ia), C_NULL, 0, c))
+            end
+        end
+    end
+    nothing
+end
+
 # ---------------------------------------------------------------------------------------------------
 # fused residual sweeps (bypass broadcast: one C call = the whole closure of test/advection.jl:67-83)
 # ---------------------------------------------------------------------------------------------------
@@ -220,7 +432,7 @@ end
 
 # flags of the fused sweeps (include/ibhip.h)
 const FORCE_GENERAL, IMAGE_ONLY, PASS_A_ONLY, PASS_B_ONLY, EXACT = 1, 2, 4, 8, 16
-const PHASE_INTERIOR, PHASE_BOUNDARY, NO_FUSE = 32, 64, 128
+const PHASE_INTERIOR, PHASE_BOUNDARY, NO_FUSE, NO_QUAD = 32, 64, 128, 1024
 
 # ---------------------------------------------------------------------------------------------------
 # point-implicit smoother: the device kernels behind src/point_implicit.jl (hutchinson_trick :17-91,
