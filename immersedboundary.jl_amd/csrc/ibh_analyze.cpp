@@ -393,7 +393,6 @@ void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<i
     for (int32_t o : order) {
         if (used[o] || !cand[o]) continue;
         const BlockDesc2& b0 = blocks[o];
-        if (b0.base % 4 != 0) continue;  // float4 accesses of the quad sweep
         int32_t idx[4] = {o, -1, -1, -1};
         bool ok = true;
         for (int k = 1; k < 4 && ok; ++k) {

@@ -913,8 +913,7 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     };
     // quad sweep over quad set `k` (0: all blocks, 1: image blocks): `ph1`/`ph2` select the interior / boundary part
     auto quads_ok = [&](int k) {
-        return ibh_quad && !(flags & IBH_NO_QUAD) && p->nq[k] > 0 && ldc % 4 == 0 && p->nc % 2 == 0 &&
-               (((uintptr_t)u | (uintptr_t)C | (uintptr_t)ud) & 15) == 0;
+        return ibh_quad && !(flags & IBH_NO_QUAD) && p->nq[k] > 0;
     };
     auto launch_quads = [&](int k, bool ph1, bool ph2) {
         int32_t q0 = ph2 ? p->nq_int[k] : 0, q1 = ph1 ? p->nq_int[k] : p->nq[k];

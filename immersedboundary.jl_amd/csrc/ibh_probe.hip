@@ -14,7 +14,7 @@ namespace {
 #endif
 #define PROBE_WG_LDS (WPB * (QUAD_LDS > BLK2_SWEEP_LDS ? QUAD_LDS : BLK2_SWEEP_LDS))
 
-typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4), aligned(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
 // bits of `what`: 1 own-cell loads + store, 2 table loads, 4 hu(k0), 8 hu(k1), 16 hdeep(k0), 32 hdeep(k1), 64 hc(k0),

@@ -26,6 +26,9 @@ namespace quad2 {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
+// float4 in global memory at any 4-byte aligned address: a quad's first cell is a multiple of 4 only on partitions
+// without skirt fragments in front of it (global_load/store_dwordx4 need dword alignment only)
+typedef float v4f_g __attribute__((ext_vector_type(4), aligned(4)));
 
 // LDS per wave (floats): tile U | tile SY | tile D | tile CY (16 rows, pitch 20: conflict-free ds_write_b128) |
 // lateral lines ext[8][20] | rings M, F, Q [4 rows][16] (row 0 bottom, 1 top, 2 neutral, 3 dump) | edge fluxes [4][16]
@@ -221,9 +224,9 @@ __device__ __forceinline__ QuadOwn quad_load_own(const QuadLane& G, const QuadTa
                                                  const float* __restrict__ C, uint32_t ldc) {
     QuadOwn O;
     O.a0 = (uint32_t)T.d.base + G.a0off;
-    O.U = *(const v4f*)((const char*)u + ((size_t)O.a0 << 2));
-    O.CX = *(const v4f*)((const char*)C + ((size_t)O.a0 << 2));
-    O.CY = *(const v4f*)((const char*)(C + ldc) + ((size_t)O.a0 << 2));
+    O.U = *(const v4f_g*)((const char*)u + ((size_t)O.a0 << 2));
+    O.CX = *(const v4f_g*)((const char*)C + ((size_t)O.a0 << 2));
+    O.CY = *(const v4f_g*)((const char*)(C + ldc) + ((size_t)O.a0 << 2));
     return O;
 }
 // Halo gathers: seven per quad.  Measured (scripts/probe_sweep.py, profiles/r2_final/README.md): alone each costs
@@ -408,7 +411,7 @@ __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T
             FTf[c] = t15 ? ex[c] : FT[c];
         }
         const v4f res = -((FRf - FL) * rhx) - ((FTf - FB) * rhy);
-        *(v4f*)((char*)ud + ((size_t)O.a0 << 2)) = res;
+        *(v4f_g*)((char*)ud + ((size_t)O.a0 << 2)) = res;
     }
 }
 

@@ -349,6 +349,107 @@ def _project_2d(dfield, X, R):
     return P
 
 
+def _seg_proj(p0, p1, x):
+    """``proj2simplex`` for 2-vertex simplices, column-wise (mesher.jl:549-567): arrays ``(nd, m)``."""
+    eps_ = f32(1e-14)
+    u = p1 - p0
+    a = (x - p0) * u
+    b = u * u
+    num, den = a[0], b[0]
+    for q in range(1, a.shape[0]):
+        num = num + a[q]
+        den = den + b[q]
+    xi = num / (den + eps_)
+    proj = p0 + u * xi
+    proj = np.where(xi < -eps_, p0, proj)
+    proj = np.where(xi > 1.0 + eps_, p1, proj)
+    return proj
+
+
+def _dist_cols(a, b):
+    d = a - b
+    s = d[0] * d[0]
+    for q in range(1, d.shape[0]):
+        s = s + d[q] * d[q]
+    return np.sqrt(s)
+
+
+def _project_3d(dfield, X, R, chunk=20_000):
+    """Vectorised ``projection(dfield, x, R)`` for triangle surfaces (mesher.jl:778-801 with ``proj2simplex``
+    :544-596): the (ghost, candidate triangle) pairs of a chunk of ghosts at once -- ``pinv`` of the 3 x 2 edge
+    matrix once per triangle, the three edge projections where the foot point falls outside the triangle (first
+    strict minimum, faces in the order of ``simplex_faces``), then per ghost the first candidate, in ascending simplex
+    order, that strictly improves on the nearest-centre distance.  A candidate is dropped beforehand when it cannot
+    win: |x - centre| - (largest vertex distance from the centre) >= nearest-centre distance -- the reference replaces
+    the nearest centre only by a strictly closer point, so the result is the same.  Agrees with the per-ghost loop to
+    the last bit or two of the ``pinv`` product (tests/test_3d.py checks the ghost sets and the projections)."""
+    n = X.shape[1]
+    idx, d = dfield.nn(X)
+    P = dfield.centers[:, idx].copy()
+    if n == 0:
+        return P
+    pts = dfield.stl.points
+    simp = dfield.stl.simplices - 1
+    eps_ = f32(1e-14)
+    T0, T1, T2 = pts[:, simp[0]], pts[:, simp[1]], pts[:, simp[2]]
+    cache = getattr(dfield, "_tri_cache", None)
+    if cache is None:
+        M = np.stack([T1 - T0, T2 - T0], axis=2).transpose(1, 0, 2)          # (nt, 3, 2)
+        pinvM = np.linalg.pinv(M)                                            # (nt, 2, 3), one SVD per triangle
+        ctr = dfield.centers
+        rmax = np.maximum(np.maximum(_dist_cols(T0, ctr), _dist_cols(T1, ctr)), _dist_cols(T2, ctr))
+        cache = dfield._tri_cache = (M, pinvM, rmax.astype(np.float64) * 1.0001 + 1e-12)
+    M, pinvM, rmax = cache
+    use = R > d
+    Xt = np.ascontiguousarray(X.T, dtype=np.float64)
+    for c0 in range(0, n, chunk):
+        c1 = min(c0 + chunk, n)
+        sel = np.nonzero(use[c0:c1])[0] + c0
+        if sel.size == 0:
+            continue
+        cand = dfield.tree.query_ball_point(Xt[sel], r=R[sel].astype(np.float64), return_sorted=True)
+        lens = np.fromiter((len(c) for c in cand), dtype=np.int64, count=sel.size)
+        if lens.sum() == 0:
+            continue
+        rows = np.repeat(sel, lens)
+        tri = np.concatenate([np.asarray(c, dtype=np.int64) for c in cand if len(c)])
+        x = X[:, rows]
+        # exact pruning (see docstring); the bound is evaluated in Float64 with a safety margin on rmax
+        dc = _dist_cols(x.astype(np.float64), dfield.centers[:, tri].astype(np.float64))
+        keep = dc - rmax[tri] < d[rows].astype(np.float64)
+        rows, tri, x = rows[keep], tri[keep], x[:, keep]
+        if rows.size == 0:
+            continue
+        p0, p1, p2 = T0[:, tri], T1[:, tri], T2[:, tri]
+        rhs = (x - p0).T
+        Pv = pinvM[tri]
+        xi = Pv[:, :, 0] * rhs[:, 0:1] + Pv[:, :, 1] * rhs[:, 1:2] + Pv[:, :, 2] * rhs[:, 2:3]   # (m, 2)
+        Mt = M[tri]
+        pr = p0 + (Mt[:, :, 0] * xi[:, 0:1] + Mt[:, :, 1] * xi[:, 1:2]).T
+        outside = (xi[:, 0] < -eps_) | (xi[:, 1] < -eps_) | ((xi[:, 0] + xi[:, 1]) > 1.0 + eps_)
+        if outside.any():
+            o = np.nonzero(outside)[0]
+            xo = x[:, o]
+            best = np.empty((3, o.size), dtype=X.dtype)
+            bd = np.full(o.size, np.inf, dtype=np.float64)
+            # simplex_faces: the simplex without vertex i, i = 1, 2, 3
+            for (a, b) in ((p1, p2), (p0, p2), (p0, p1)):
+                q = _seg_proj(a[:, o], b[:, o], xo)
+                dq = _dist_cols(q, xo)
+                take = dq < bd
+                best[:, take] = q[:, take]
+                bd = np.where(take, dq, bd)
+            pr[:, o] = best
+        dist = _dist_cols(pr, x)
+        # per ghost: candidates in ascending simplex order, the first one at the minimum distance, if below d
+        order = np.lexsort((tri, dist, rows))
+        rs = rows[order]
+        first = order[np.concatenate([[True], rs[1:] != rs[:-1]])]
+        better = dist[first] < d[rows[first]]
+        P[:, rows[first][better]] = pr[:, first[better]]
+    return P
+
+
 def ghosts_and_projections(dfield, centers, widths, ghost_layer_ratio=f32(1.5)):
     """ImmersedBoundary.jl:194-230."""
     ratio = f32(ghost_layer_ratio)
@@ -360,9 +461,7 @@ def ghosts_and_projections(dfield, centers, widths, ghost_layer_ratio=f32(1.5)):
     if centers.shape[0] == 2:
         projs = _project_2d(dfield, Xg, Rg).astype(centers.dtype)
     else:
-        projs = np.empty((centers.shape[0], ghosts.size), dtype=centers.dtype)
-        for k in range(ghosts.size):
-            projs[:, k] = dfield.projection(Xg[:, k], Rg[k])
+        projs = _project_3d(dfield, Xg, Rg).astype(centers.dtype)
     diff = projs - Xg
     d = np.sqrt(_colsum(diff * diff))
     m = d <= diams[ghosts] * ratio

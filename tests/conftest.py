@@ -126,3 +126,26 @@ def oracle_view(part):
         o.n_output, o.first_index, o.stencils = acc.n_output, True, acc.stencils
         op.face_accumulators[k] = o
     return op
+
+
+def oracle_boundaries_view(dom):
+    """Oracle-side view of the boundaries of a product Domain (same arrays, oracle Accumulator objects): lets the
+    oracle's ``impose_bc`` run on domains too large for the literal ``Domain(msh)`` restatement."""
+    from oracle.accumulator import Accumulator as OAcc
+
+    class V:
+        pass
+    view = V()
+    view.boundaries = {}
+    for name, parts in dom.boundaries.items():
+        view.boundaries[name] = {}
+        for ipart, b in parts.items():
+            ob = V()
+            for k in ("ghost_indices", "projections", "normals", "image_distances", "ghost_distances", "image_domain"):
+                setattr(ob, k, getattr(b, k))
+            acc = b.image_interpolator
+            o = object.__new__(OAcc)
+            o.n_output, o.first_index, o.stencils = acc.n_output, True, acc.stencils
+            ob.image_interpolator = o
+            view.boundaries[name][ipart] = ob
+    return view

@@ -193,3 +193,27 @@ def test_3d_block_path(octree8_mesh, nparts):
             ibamd.residual_advection(dpart, ud_, Cd, out=out, flags=ibamd.IBH_PHASE_BOUNDARY)
             img = part.image_in_domain
             assert np.array_equal(ibamd.to_host(out)[img], fast[img])
+
+
+def test_vectorised_surface_projection_matches_the_per_ghost_loop():
+    """domain._project_3d (all ghost x candidate-triangle pairs at once, pinv once per triangle, exact pruning) against
+    the literal per-ghost ``projection`` (mesher.jl:778-801 over proj2simplex :544-596) on an immersed sphere: same
+    projections to the last bit or two of the pinv product, same ghost set after the distance test."""
+    from ibamd import domain as D
+    from ibamd.mesher import get_cells
+    msh = Mesh(f32([-2, -2, -2]), f32([4, 4, 4]), ("sphere", icosphere(1.0, subdiv=2), f32(0.25)), block_size=4)
+    c, w = get_cells(msh)
+    df = msh.distance_fields["sphere"]
+    ratio = f32(1.5)
+    diams = np.sqrt(D._colsum(w * w))
+    _, dists = df.nn(c)
+    cand = np.nonzero(dists <= diams * ratio * f32(2))[0]
+    assert cand.size > 500
+    pick = cand[np.random.default_rng(1).choice(cand.size, 120, replace=False)]
+    Xg, Rg = c[:, pick], diams[pick] * ratio * f32(2)
+    Pv = D._project_3d(df, Xg, Rg)
+    Pl = np.stack([df.projection(Xg[:, k], Rg[k]) for k in range(pick.size)], axis=1)
+    assert np.abs(Pv - Pl).max() <= 4 * np.finfo(f32).eps * max(1.0, np.abs(Pl).max())
+    dv, dl = D._dist_cols(Pv, Xg), D._dist_cols(Pl, Xg)
+    assert np.array_equal(dv <= diams[pick] * ratio, dl <= diams[pick] * ratio)
+    assert (dv <= diams[pick] * ratio).sum() > 10

@@ -82,3 +82,34 @@ def test_full_size_euler_sweep_variants_agree(full):
     for v in range(4):
         assert rel_inf(two[:, v], exp[:, v]) <= 1e-5, v
         assert rel_inf(one[:, v], exp[:, v]) <= 1e-5, v
+
+
+def test_config3_partitions_image_only_sweep():
+    """BASELINE.json configs[2] on one GPU: the 3.47 M-cell RAE2822 mesh cut in 8 block-aligned partitions
+    (ImmersedBoundary.jl:594-621); the image-only sweep (what a rank of the 8-GPU run computes) of the first and of an
+    interior partition against the C restatement of the closure on `part.domain`."""
+    import torch
+    import bench
+    from oracle import residual_c as rc
+    msh = bench.build_mesh("rae2822_3.47M")
+    ncells, world = len(msh), 8
+    assert ncells == 3469888
+    mps = -(-(-(-ncells // world)) // 64) * 64
+    dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=False, only=[1, 4])
+    for k in (1, 4):
+        part = dom.partitions[k]
+        img = part.image_in_domain
+        assert img.size == mps and part.spacing.shape[0] > img.size     # skirt cells are there
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        assert dpart.info["image_blocks_all_eligible"] and dpart.info["image_blocks"] * 64 == img.size
+        assert dpart.info["image_quads"] > 0
+        u, C = bench.synthetic_fields(part.centers)
+        exp = rc.CPart(part).residual_advection(u, C)
+        out = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out, flags=ibamd.IBH_IMAGE_ONLY)
+        got = ibamd.to_host(out)
+        assert np.isnan(got).sum() == u.shape[0] - img.size              # nothing written outside the image
+        assert rel_inf(got[img], exp[img]) <= 1e-5
+        per_block = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C),
+                                                           flags=ibamd.IBH_IMAGE_ONLY | ibamd.IBH_NO_QUAD))
+        assert rel_inf(got[img], per_block[img]) <= 2e-6

@@ -250,7 +250,10 @@ def test_image_only_sweep_on_partitions(rae_domains):
         ibamd.residual_advection(dpart, ibamd.hip(up), ibamd.hip(C), out=out2, flags=IO | ibamd.IBH_PHASE_INTERIOR)
         got1 = ibamd.to_host(out2)
         done = ~np.isnan(got1)
-        assert done.sum() == 64 * info["interior_blocks"] and np.array_equal(got1[done], one[done])
+        # (a 2x2 block group of the quad sweep is interior only if all four blocks are: a few interior blocks wait for
+        # the boundary phase)
+        assert 0 < done.sum() <= 64 * info["interior_blocks"] and done.sum() % 64 == 0
+        assert done.sum() >= 32 * info["interior_blocks"] and np.array_equal(got1[done], one[done])
         ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out2, flags=IO | ibamd.IBH_PHASE_BOUNDARY)
         assert np.array_equal(ibamd.to_host(out2)[img], one[img])
     assert used > 0

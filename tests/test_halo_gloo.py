@@ -95,3 +95,55 @@ def test_halo_plan_lists_are_mirror_images():
         # every skirt cell is received exactly once
         nskirt = dr.size - dom.partitions[r].image.size
         assert pr.n_recv == nskirt
+
+
+def _worker_config3(rank, world, port, out):
+    """BASELINE.json configs[2]: the 3.47 M-cell RAE2822 mesh in 8 block-aligned partitions (skirt growth of
+    ImmersedBoundary.jl:594-621); one full exchange, every local array must equal global[part.domain]."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        msh = bench.build_mesh("rae2822_3.47M")
+        ncells = len(msh)
+        mps = -(-(-(-ncells // world)) // 64) * 64
+        dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=False, only=[rank + 1])
+        part = dom.partitions[rank + 1]
+        # a field every rank can evaluate for any global cell without building the other partitions: a hash of the id
+        gid = np.asarray(part.domain, dtype=np.int64)
+        value = lambda g: ((g * 2654435761) % 1000003).astype(np.float32) / np.float32(1000003.0)
+        local = value(gid)
+        expect = local.copy()
+        skirt = np.ones(local.shape[0], dtype=bool)
+        skirt[part.image_in_domain] = False
+        local[skirt] = np.nan
+        plan = HaloPlan(dom, rank + 1)
+        hx = HaloExchange(plan, "cpu")
+        t = torch.from_numpy(local)
+        hx.exchange(t)
+        ok = np.array_equal(t.numpy(), expect) and plan.n_recv == int(skirt.sum()) and part.image.size % 64 == 0
+        res = torch.tensor([int(ok), int(skirt.sum())], dtype=torch.int64)
+        dist.all_reduce(res, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            out.put((int(res[0].item()), ncells, int(res[1].item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_halo_exchange_gloo_config3_8_ranks():
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config3, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    ok, ncells, min_skirt = q.get(timeout=10)
+    assert ok == 1 and ncells == 3469888 and min_skirt > 0
