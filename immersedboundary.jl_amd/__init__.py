@@ -10,7 +10,7 @@ that computes needs libibhip.so and a gfx950 device and fails loudly otherwise.
 from .mesher import (Ball, Box, DistanceField, Line, Mesh, Stereolitography, cat, centers_and_normals,
                      feature_regions, get_cells, merge_points, refine_to_length)
 from .accumulator import Accumulator
-from .domain import Boundary, Domain, Partition, multigrid
+from .domain import Boundary, Domain, Partition, Surface, multigrid
 
 
 def __getattr__(name):

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from ._lib import call, c_vp
 from .accumulator import Accumulator
-from .domain import Boundary, Partition
+from .domain import Boundary, Partition, Surface
 
 IBH_FORCE_GENERAL = 1
 IBH_IMAGE_ONLY = 2
@@ -281,10 +281,70 @@ class DeviceBoundary:
             pass
 
 
+class DeviceSurface:
+    """Device-resident Surface (ImmersedBoundary.jl:328-376): two Accumulators + the areas for the integrals."""
+
+    def __init__(self, s: Surface):
+        self.host = s
+        self.n = int(s.points.shape[0])
+        self.interpolator = DeviceAccumulator(s.interpolator)
+        self.offset_interpolator = DeviceAccumulator(s.offset_interpolator)
+        self.points, self.normals = hip(s.points), hip(s.normals)
+        self.offsets, self.areas = hip(s.offsets), hip(s.areas)
+
+    def __call__(self, u):
+        """``surf(u)``: values of the field array ``u`` at the surface control points (:364)."""
+        return self.interpolator(u)
+
+
+def at_offset(surf, u):
+    """``at_offset(surf, u)`` (:372): values at the offset sampling points."""
+    return to_backend(surf).offset_interpolator(u)
+
+
+def surface_integral(surf, u):
+    """``surface_integral(surf, u)`` (:345-357): sum over the control points of ``areas .* u`` per column --
+    one elementwise product and one device reduction per column (``ibh_ew_binary`` / ``ibh_ew_reduce``)."""
+    from .hiparray import HipArray
+    surf = to_backend(surf)
+    U = u if isinstance(u, HipArray) else HipArray(u)
+    if U.n != surf.n:
+        raise ValueError(f"field has {U.n} rows, the surface {surf.n} control points")
+    prod = U * HipArray(surf.areas)
+    if U.ndim == 1:
+        return np.float32(prod.sum())
+    return np.array([HipArray(prod.t[:, v]).sum() for v in range(U.nv)], dtype=np.float32)
+
+
+def volume_integral(dom, A):
+    """``volume_integral(dom, A)`` (:1415-1431) on a device-resident global array: A times the cell volumes (the
+    widths come from the Domain's cell table), summed per column on the device."""
+    from .hiparray import HipArray
+    U = A if isinstance(A, HipArray) else HipArray(A)
+    if U.n != len(dom):
+        raise ValueError("volume_integral takes a global array (one row per cell of the domain)")
+    wd = getattr(dom, "_device_widths", None)
+    if wd is None:
+        from .mesher import get_cells
+        _, widths = get_cells(dom.mesh)
+        wd = dom._device_widths = [HipArray(np.ascontiguousarray(widths[d], dtype=np.float32))
+                                   for d in range(widths.shape[0])]
+    prod = U * wd[0]          # `Ai .*= part.spacing[:, dim]` dim by dim, like the reference
+    for w in wd[1:]:
+        prod *= w
+    if U.ndim == 1:
+        return np.float32(prod.sum())
+    return np.array([HipArray(prod.t[:, v]).sum() for v in range(U.nv)], dtype=np.float32)
+
+
 def to_backend(x, converter=hip):
     """``ArrayBackends.to_backend`` (arraybends.jl:14-77) for the structs on the hot path."""
-    if isinstance(x, (DevicePartition, DeviceAccumulator, DeviceBoundary)):
+    if isinstance(x, (DevicePartition, DeviceAccumulator, DeviceBoundary, DeviceSurface)):
         return x
+    if isinstance(x, Surface):
+        if getattr(x, "_device", None) is None:
+            x._device = DeviceSurface(x)
+        return x._device
     if isinstance(x, Partition):
         if getattr(x, "_device", None) is None:
             x._device = DevicePartition(x)

@@ -498,8 +498,9 @@ def knn_sorted(tree, Xq, k):
     return np.take_along_axis(idx, order, axis=1)
 
 
-def interpolator(X, Xc, tree, linear=True, k=0):
-    """Batched ``Interpolator(X, Xc, tree; first_index=true, linear)`` (nninterp.jl:86-138).
+def interpolator(X, Xc, tree, linear=True, k=0, bias=None):
+    """Batched ``Interpolator(X, Xc, tree; first_index=true, linear, bias)`` (nninterp.jl:86-138): with ``bias`` the
+    donors are the nearest neighbours of ``Xc + bias``, the weights those of ``Xc`` (:80-82, :121-126).
 
     ``X (n, nd)`` donors, ``Xc (m, nd)`` targets.  Weights: weighted least-squares linear
     (nninterp.jl:16-42) or inverse distance (:47-69); entries with |w| <= eps (sqrt(eps) for IDW)
@@ -509,7 +510,7 @@ def interpolator(X, Xc, tree, linear=True, k=0):
     if k == 0:
         k = 2 ** nd
     eps_ = np.finfo(f32).eps
-    nb = knn_sorted(tree, Xc, k)  # (m, k)
+    nb = knn_sorted(tree, Xc if bias is None else Xc + bias, k)  # (m, k)
     dX = X[nb] - Xc[:, None, :]   # (m, k, nd)
     s = dX[..., 0] * dX[..., 0]
     for q in range(1, nd):
@@ -560,6 +561,33 @@ def boundary_partitions(cT, wT, tree, ghosts, projs, max_partition_size, ghost_r
     return bd
 
 
+class Surface:
+    """Post-processing surface of an immersed boundary (ImmersedBoundary.jl:328-343, built at :744-766): control
+    points = simplex centres of the (refined) STL, ``offsets`` = 1.01 x diameter of the nearest cell, unit ``normals``,
+    ``areas`` = norm of the area-weighted normals, ``interpolator`` (stencil searched at points + normals*offset,
+    evaluated AT the points) and ``offset_interpolator`` (at points + normals*offset*ghost_layer_ratio)."""
+
+    def __init__(self, points, offsets, normals, areas, interpolator, offset_interpolator, stl):
+        self.points, self.offsets, self.normals, self.areas = points, offsets, normals, areas
+        self.interpolator, self.offset_interpolator, self.stl = interpolator, offset_interpolator, stl
+
+
+def make_surface(dfield, cT, tree, diams, ghost_layer_ratio):
+    """ImmersedBoundary.jl:744-766."""
+    from .mesher import centers_and_normals
+    eps_ = np.finfo(f32).eps
+    fcenters, fnormals = centers_and_normals(dfield.stl)            # (nd, ns) each
+    _, idx = tree.query(np.ascontiguousarray(fcenters.T, dtype=np.float64))
+    h = (diams[idx] * f32(1.01)).astype(f32)
+    fnT = np.ascontiguousarray(fnormals.T)
+    A = (np.sqrt(_rowsum(fnT * fnT)) + eps_).astype(f32)
+    fnT = (fnT / A[:, None]).astype(f32)
+    fcT = np.ascontiguousarray(fcenters.T).astype(f32)
+    bias = (fnT * h[:, None]).astype(f32)
+    return Surface(fcT, h, fnT, A, interpolator(cT, fcT, tree, bias=bias),
+                   interpolator(cT, (fcT + bias * f32(ghost_layer_ratio)).astype(f32), tree), dfield.stl)
+
+
 class Domain:
     """``Domain(msh; max_partition_size, partition_skirt_depth, ghost_layer_ratio, hypercube_families)``.
 
@@ -590,6 +618,7 @@ class Domain:
                 ipart + 1, image, ncells, fd, fo, fn, centers, widths, partition_skirt_depth, msh.block_size)
             self.domains[ipart + 1] = self.partitions[ipart + 1].domain
         self.boundaries = {}
+        self.surfaces = {}
         if boundaries:
             cT = np.ascontiguousarray(centers.T)
             wT = np.ascontiguousarray(widths.T)
@@ -602,9 +631,10 @@ class Domain:
                 g, p = ghosts_and_projections(dfield, centers, widths, ghost_layer_ratio)
                 self.boundaries[bname] = boundary_partitions(cT, wT, tree, g, np.ascontiguousarray(p.T),
                                                              max_partition_size, ghost_layer_ratio)
+                self.surfaces[bname] = make_surface(dfield, cT, tree, np.sqrt(_colsum(widths * widths)),
+                                                    ghost_layer_ratio)
         self.ncells = ncells
         self.mesh = msh
-        self.surfaces = {}
         self.reconstruction_kwargs = dict(
             max_partition_size=max_partition_size, partition_skirt_depth=partition_skirt_depth,
             ghost_layer_ratio=ghost_layer_ratio, hypercube_families=list(hypercube_families))

@@ -75,6 +75,46 @@ class Boundary:
         self.image_domain = dom.astype(np.int32)
 
 
+class Surface:
+    """ImmersedBoundary.jl:328-376 (struct, surface_integral, call, at_offset), built at :744-766."""
+
+    def __init__(self, points, offsets, normals, areas, interpolator, offset_interpolator, stl):
+        self.points, self.offsets, self.normals, self.areas = points, offsets, normals, areas
+        self.interpolator, self.offset_interpolator, self.stl = interpolator, offset_interpolator, stl
+
+    @staticmethod
+    def build(dfield, cT, tree, diams, ghost_layer_ratio):
+        from ibamd.mesher import centers_and_normals
+        eps_ = np.finfo(f32).eps
+        fcenters, fnormals = centers_and_normals(dfield.stl)
+        _, idx = tree.query(np.ascontiguousarray(fcenters.T, dtype=np.float64))
+        h = diams[idx] * f32(1.01)
+        fnT = np.ascontiguousarray(fnormals.T)
+        A = np.sqrt(_rowsum(fnT * fnT)) + eps_
+        fnT = fnT / A[:, None]
+        fcT = np.ascontiguousarray(fcenters.T)
+        bias = fnT * h[:, None]
+        return Surface(fcT, h, fnT, A,
+                       nninterp.Interpolator(cT, fcT, tree, bias=bias, first_index=True),
+                       nninterp.Interpolator(cT, fcT + bias * f32(ghost_layer_ratio), tree, first_index=True), dfield.stl)
+
+    def __call__(self, u):
+        """:364"""
+        return self.interpolator(u)
+
+
+def at_offset(surf, u):
+    """:372"""
+    return surf.offset_interpolator(u)
+
+
+def surface_integral(surf, u):
+    """:345-357"""
+    if u.ndim == 1:
+        return (surf.areas * u).sum(dtype=f32)
+    return (surf.areas[:, None] * u).sum(axis=0, dtype=f32)
+
+
 def _rowsum(a):
     s = a[:, 0].copy()
     for k in range(1, a.shape[1]):
@@ -183,6 +223,7 @@ class Domain:
                 face_accumulators, face_owners_neighbors, domain, image, image_in_domain)
 
         boundaries = {}
+        surfaces = {}
         cT = np.ascontiguousarray(centers.T)
         wT = np.ascontiguousarray(widths.T)
         tree = cKDTree(cT.astype(np.float64))
@@ -195,12 +236,13 @@ class Domain:
             ghosts, projs = ghosts_and_projections(dfield, centers, widths, ghost_layer_ratio)
             boundaries[bname] = boundary_partitions(
                 cT, wT, tree, ghosts, np.ascontiguousarray(projs.T), max_partition_size, ghost_layer_ratio)
+            surfaces[bname] = Surface.build(dfield, cT, tree, np.sqrt(_colsum(widths * widths)), ghost_layer_ratio)
 
         self.ncells = ncells
         self.mesh = msh
         self.partitions = partitions
         self.boundaries = boundaries
-        self.surfaces = {}
+        self.surfaces = surfaces
         self.reconstruction_kwargs = dict(
             max_partition_size=max_partition_size, partition_skirt_depth=partition_skirt_depth,
             ghost_layer_ratio=ghost_layer_ratio, hypercube_families=list(hypercube_families))

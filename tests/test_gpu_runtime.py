@@ -247,3 +247,35 @@ def test_partition_pack_feeds_the_library(adv_domains, tmp_path):
     ra = ibamd.to_host(ibamd.residual_advection(a, ibamd.hip(u), ibamd.hip(C)))
     rb = ibamd.to_host(ibamd.residual_advection(b, ibamd.hip(u), ibamd.hip(C)))
     assert np.array_equal(ra, rb)
+
+
+def test_surface_and_volume_integrals(rae_domains):
+    """``surf(u)``, ``at_offset``, ``surface_integral`` and ``volume_integral`` (ImmersedBoundary.jl:345-376,
+    :1415-1431) on the device against the oracle."""
+    dp, do = rae_domains
+    so, sp = do.surfaces["wall"], dp.surfaces["wall"]
+    X = dp.global_centers()
+    n = len(dp)
+    rng = np.random.default_rng(5)
+    U = np.stack([np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]), 1e5 * (1 + 0.1 * rng.uniform(-1, 1, n))], axis=1).astype(f32)
+    ds = ibamd.to_backend(sp, ibamd.hip)
+    got = ibamd.to_host(ds(ibamd.hip(U)))
+    exp = so(U)
+    assert got.shape == exp.shape and rel_inf(got, exp) <= 1e-5
+    got_off = ibamd.to_host(ibamd.at_offset(sp, ibamd.hip(U)))
+    assert rel_inf(got_off, od.at_offset(so, U)) <= 1e-5
+    si = ibamd.surface_integral(sp, ds(ibamd.hip(U)))
+    sio = od.surface_integral(so, exp)
+    assert si.shape == (2,) and np.abs(si - sio).max() <= 1e-5 * np.abs(sio).max()
+    s1 = ibamd.surface_integral(sp, ibamd.hip(np.ones(so.points.shape[0], f32)))
+    assert abs(float(s1) - float(od.surface_integral(so, np.ones(so.points.shape[0], f32)))) <= 1e-5 * float(s1)
+    vi = ibamd.volume_integral(dp, ibamd.hip(U))
+    vio = od.volume_integral(do, U)
+    from ibamd.mesher import get_cells
+    _, widths = get_cells(dp.mesh)
+    exact = (U.astype(np.float64) * np.prod(widths.astype(np.float64), axis=0)[:, None]).sum(axis=0)
+    # Float32 sums of 3.7e4 terms: the device's tree reduction is the closer one to the Float64 value; the oracle's
+    # running Float32 sum (like the reference's) carries ~1e-4
+    assert np.abs(vi - exact).max() <= 1e-5 * np.abs(exact).max()
+    assert np.abs(vio - exact).max() <= 1e-3 * np.abs(exact).max()
+    assert abs(float(ibamd.volume_integral(dp, ibamd.hip(np.ones(n, f32)))) - 2500.0) <= 0.5   # test/rae2822.jl:24-29

@@ -176,3 +176,38 @@ def test_fas_fixed_point_converges():
     ratio = FAS(lambda l, Q: (b - A @ Q, f32(0.4)), Q, n_iter=200, rtol=f32(1e-6))
     assert ratio < 1e-4
     assert np.allclose(A @ Q, b, atol=1e-4)
+
+
+def test_surface_known_answers(rae_domains):
+    """Surface post-processing (ImmersedBoundary.jl:328-376, :744-766) on the RAE2822 case: the integral of 1 is the
+    length of the (refined) polyline; the least-squares-linear interpolators reproduce a linear field at the control
+    points and at the offset points (weights sum to 1, first moments vanish: nninterp.jl:31-35); the product's builder
+    gives the same Surface as the literal restatement."""
+    dp, do = rae_domains
+    so, sp = do.surfaces["wall"], dp.surfaces["wall"]
+    stl = so.stl
+    seg = stl.points[:, stl.simplices[1] - 1] - stl.points[:, stl.simplices[0] - 1]
+    length = np.sqrt((seg.astype(np.float64) ** 2).sum(axis=0)).sum()
+    one = np.ones(so.points.shape[0], dtype=f32)
+    assert abs(float(od.surface_integral(so, one)) - length) <= 1e-4 * length
+    assert 2.0 < length < 2.1                                           # unit-chord aerofoil
+    X = do.global_centers() if hasattr(do, "global_centers") else dp.global_centers()
+    lin = (f32(0.3) * X[:, 0] - f32(1.7) * X[:, 1] + f32(0.5)).astype(f32)
+    at_pts = f32(0.3) * so.points[:, 0] - f32(1.7) * so.points[:, 1] + f32(0.5)
+    off = so.points + so.normals * (so.offsets * f32(1.5))[:, None]
+    at_off = f32(0.3) * off[:, 0] - f32(1.7) * off[:, 1] + f32(0.5)
+    assert np.abs(so(lin) - at_pts).max() <= 2e-5
+    assert np.abs(od.at_offset(so, lin) - at_off).max() <= 2e-5
+    two = np.stack([lin, one_cells := np.ones_like(lin)], axis=1)
+    got = od.surface_integral(so, so(two))
+    assert got.shape == (2,) and abs(float(got[1]) - length) <= 1e-4 * length
+    # product builder == literal restatement
+    for k in ("points", "offsets", "normals", "areas"):
+        assert np.array_equal(getattr(sp, k), getattr(so, k)), k
+    for name in ("interpolator", "offset_interpolator"):
+        a, b = getattr(sp, name), getattr(so, name)
+        sa, sb = a.stencils, b.stencils
+        assert set(sa) == set(sb)
+        for ln in sa:
+            assert np.array_equal(sa[ln][0], sb[ln][0]) and np.array_equal(sa[ln][1], sb[ln][1])
+            assert np.abs(sa[ln][2] - sb[ln][2]).max() <= 1e-5
