@@ -23,7 +23,11 @@ import torch
 class HaloPlan:
     """Send/recv lists of partition ``pid`` (1-based) against every other partition of ``dom``."""
 
-    def __init__(self, dom, pid):
+    def __init__(self, dom, pid, extra=None):
+        """``extra``: table ``{partition: sorted global ids}`` of cells each partition needs beyond its ``domain`` --
+        the ``impose_bc!`` donor cells of distributed.bc_donor_extras.  They live in rows
+        ``nc .. nc + len(extra[pid])`` of the extended local arrays and are received from their owners with the skirt
+        cells in the same exchange."""
         part = dom.partitions[pid]
         self.pid = pid
         self.nc = part.spacing.shape[0]
@@ -42,6 +46,22 @@ class HaloPlan:
             mine = dq[(dq >= lo) & (dq < hi)]
             if mine.size:
                 self.send[q] = np.searchsorted(domain, mine).astype(np.int32)
+        self.n_extra = 0
+        if extra is not None:
+            mine = np.asarray(extra[pid], dtype=np.int64)
+            self.n_extra = int(mine.size)
+            for q, (qlo, qhi) in dom.images.items():
+                if q == pid:
+                    continue
+                sel = np.nonzero((mine >= qlo) & (mine < qhi))[0]          # my extras owned by q
+                if sel.size:
+                    add = (self.nc + sel).astype(np.int32)
+                    self.recv[q] = np.concatenate([self.recv[q], add]) if q in self.recv else add
+                want = np.asarray(extra[q], dtype=np.int64)
+                want = want[(want >= lo) & (want < hi)]                    # q's extras owned by me
+                if want.size:
+                    add = np.searchsorted(domain, want).astype(np.int32)
+                    self.send[q] = np.concatenate([self.send[q], add]) if q in self.send else add
         self.peers = sorted(set(self.send) | set(self.recv))
         self.n_send = sum(v.size for v in self.send.values())
         self.n_recv = sum(v.size for v in self.recv.values())

@@ -44,12 +44,14 @@ def _update(Q, omega, r):
 
 
 def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level=0, n_iter=50,
-        rtol=1e-1, atol=1e-7):
+        rtol=1e-1, atol=1e-7, norm=None):
     """``FAS!(f, Q; coarseners, prolongators, perscribed_f, multigrid_level, n_iter, rtol, atol)``.
 
     ``f(level, Q) -> (r, omega)`` with device arrays; ``Q`` is updated in place.  Returns the residual-norm
-    reduction ratio like the reference.
+    reduction ratio like the reference.  ``norm``: the norm of a residual array; on a rank of a multi-GPU run pass
+    ``distributed.Reductions(...).norm`` (sum over the owned cells of all ranks, one all-reduce), default = local.
     """
+    _norm = norm if norm is not None else globals()["_norm"]
     l = multigrid_level
     fQ, omega = f(l, Q)
     source = None
@@ -64,7 +66,7 @@ def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level
         Qcold = Qc.clone()
         pfQc = coars(r)
         FAS(f, Qc, coarseners=coarseners[1:], prolongators=prolongators[1:], perscribed_f=pfQc,
-            multigrid_level=multigrid_level + 1, n_iter=n_iter, atol=atol, rtol=rtol)
+            multigrid_level=multigrid_level + 1, n_iter=n_iter, atol=atol, rtol=rtol, norm=norm)
         Q += prolong(Qc - Qcold)
     for _ in range(n_iter):
         r, omega = f(l, Q)
