@@ -36,6 +36,8 @@ WORKLOADS = {
     # 3-D (secondary): unit sphere (icosphere STL) in a [-8,8]^3 box, 8^3 blocks (BASELINE.json configs[3] shape)
     "sphere3d_1.6M": 0.06,
     "sphere3d_4.6M": 0.03,
+    # BASELINE.json configs[3] shape at ~8 M cells: sphere of radius 1.4, immersed-boundary ghosts kept (--step config4)
+    "sphere3d_8M": (0.03, 1.4),
 }
 
 
@@ -70,9 +72,11 @@ def build_mesh(name):
     from ibamd.mesher import DistanceField, Mesh, Stereolitography, feature_regions, merge_points
     f32 = np.float32
     if name.startswith("sphere3d"):
-        msh = Mesh(f32([-8, -8, -8]), f32([16, 16, 16]), ("sphere", icosphere(), f32(WORKLOADS[name])))
-        msh.distance_fields = {}  # the sweep benchmark builds no ghost-cell boundaries
-        return msh
+        w = WORKLOADS[name]
+        h, radius = w if isinstance(w, tuple) else (w, 1.0)
+        # the distance field of the sphere stays on the mesh: `--step config4` builds its ghost cells
+        # (Domain(..., boundaries=False) -- the plain sweep benchmark -- ignores it)
+        return Mesh(f32([-8, -8, -8]), f32([16, 16, 16]), ("sphere", icosphere(radius=radius), f32(h)))
     hw, hf = WORKLOADS[name]
     stl = merge_points(Stereolitography(os.path.join(ROOT, "tests", "golden", "rae2822.dat")))
     features = DistanceField(feature_regions(stl, radius=0.05))
@@ -169,6 +173,10 @@ def main():
                          "reproduces the rccl exchange bit for bit at start-up, else rccl")
     ap.add_argument("--graph-batch", type=int, default=20,
                     help="sweeps captured per HIP graph (launch-bound loop; 0 = eager launches)")
+    ap.add_argument("--step", default="sweep", choices=["sweep", "config4"],
+                    help="config4 (3-D workloads, --residual euler): a step = impose_bc! with FlowBC closures on the "
+                         "immersed sphere and the far field (ghost-layer interpolation) + the Euler residual sweep; one "
+                         "point-implicit linearise + relaxation is timed beside it")
     ap.add_argument("--repeats", type=int, default=20,
                     help="the timed block of --steps sweeps is repeated this many times; the median is reported")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -237,7 +245,12 @@ def main():
     npb = msh.block_size ** msh.ndims
     mps = -(-ncells // world)
     mps = -(-mps // npb) * npb  # block-aligned partitions
-    dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=False, only=[rank + 1])
+    config4 = args.step == "config4"
+    if config4 and (msh.ndims != 3 or args.residual != "euler" or world != 1):
+        raise SystemExit("--step config4 needs a sphere3d workload, --residual euler and one GPU")
+    fam4 = [("farfield", [(d, s_) for d in (1, 2, 3) for s_ in (False, True)])]
+    dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=config4, only=[rank + 1],
+                       hypercube_families=fam4 if config4 else ())
     part = dom.partitions[rank + 1]
     n_image = int(part.image.size)
     u_h, C_h = synthetic_fields(part.centers)
@@ -256,6 +269,10 @@ def main():
         P_h[:, 1] = 288.15 * (1 + 0.05 * rng.uniform(-1, 1, n))
         for k in range(2, nvp):
             P_h[:, k] = 100.0 * (1 + 0.1 * rng.uniform(-1, 1, n))
+        if config4:   # a flow past the sphere: free stream along x with small perturbations (tests/test_config4.py)
+            P_h[:, 0] = 1e5 * (1 + 0.02 * rng.uniform(-1, 1, n))
+            P_h[:, 1] = 288.15 * (1 + 0.02 * rng.uniform(-1, 1, n))
+            P_h[:, 3:] = 10.0 * rng.uniform(-1, 1, (n, nvp - 3))
         P = ibamd.hip(P_h)
         Rres = torch.zeros((nvp, dpart.nc), dtype=torch.float32, device=P.device).T
     flags = (ibamd.IBH_FORCE_GENERAL if args.general else 0) | (ibamd.IBH_EXACT if args.exact else 0)
@@ -303,8 +320,20 @@ def main():
         else:
             ibamd.residual_advection(dpart, u, C, out=ud, flags=flags | extra)
 
+    if config4:
+        from ibamd import cfd as gcfd
+        far_bc = gcfd.FlowBC(gcfd.Fluid(), [1.0e5, 288.15, 100.0, 0.0, 0.0])
+        wall_bc = gcfd.FlowBC(gcfd.Fluid(), [1.0e5, 288.15, 0.0], normal_flow=True)
+        for bname in dom.boundaries:                  # device-resident Boundary structs, built before the timed region
+            for b in dom.boundaries[bname].values():
+                ibamd.to_backend(b, ibamd.hip)
+
     def step():
-        if hx is None:
+        if config4:
+            ibamd.impose_bc(lambda b, ia: far_bc(ia, b.normals), dom, "farfield", P)
+            ibamd.impose_bc(lambda b, ia: wall_bc(ia, b.normals), dom, "sphere", P)
+            sweep()
+        elif hx is None:
             sweep()
         elif comm_stream is not None and euler:
             euler_sweep_overlapped(hx, dpart, P, Rres, comm_stream, flags=flags)
@@ -323,7 +352,7 @@ def main():
     # The sweep is ~10 us of GPU work: a Python/ctypes launch per step would be host-bound, so on one GPU
     # the step loop is captured into HIP graphs of `graph_batch` sweeps each (every sweep still runs in full).
     # (N > 1: only with the xgmi exchange, which is kernels only; RCCL calls are launched eagerly.)
-    graphable = world == 1 or halo_kind == "xgmi-direct"
+    graphable = (world == 1 or halo_kind == "xgmi-direct") and not config4   # (the BC closures launch eagerly)
     batch = args.graph_batch if (graphable and args.graph_batch > 0) else 0
     graph = None
     side = torch.cuda.Stream()
@@ -537,6 +566,31 @@ def main():
                    "block_analysis": dpart.info},
         "roofline": roofline,
     }
+    if config4:
+        from ibamd import point_implicit as pi
+        P0 = P.clone()
+        dtp = 1e-5
+
+        def f_pi(X):
+            return (X - P0) / dtp - ibamd.residual_euler_hll(dpart, X)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lin, bb, prec = pi.linearize(f_pi, P, 1, h=1e-2, seed=1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, ratio = pi.solve(lin, bb, prec, n_iter=1, rtol=1e-9)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out["metric"] = "Mcells*iters/s, config-4 step (impose_bc! FlowBC ghosts + Euler HLL residual sweep), 3D sphere"
+        out["config"]["step"] = {"ghost_cells": {k: int(sum(b.ghost_indices.size for b in v.values()))
+                                                 for k, v in dom.boundaries.items()},
+                                 "point_implicit": {"linearize_ms": round((t1 - t0) * 1e3, 2),
+                                                    "solve_1_iteration_ms": round((t2 - t1) * 1e3, 2),
+                                                    "residual_ratio": round(float(ratio), 4),
+                                                    "residual_finite": bool(torch.isfinite(Rres).all().item()),
+                                                    "what": "pseudo-time step (P - P0)/dt - R(P), Hutchinson block "
+                                                            "estimate with 1 sample per variable (6 sweeps), one two-"
+                                                            "direction relaxation (2 sweeps)"}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler and not is3d:
         cb = cpu_baseline(part, u_h, C_h)
         out["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "Mcells*iters/s", "cores": cb["threads"],

@@ -374,6 +374,22 @@ def _dist_cols(a, b):
     return np.sqrt(s)
 
 
+def _tri_cache(dfield):
+    """Per triangle of a surface: the vertices, the 3 x 2 edge matrix, its pseudo-inverse (one SVD per triangle) and
+    the largest vertex distance from the centre (with a safety margin, Float64)."""
+    pts = dfield.stl.points
+    simp = dfield.stl.simplices - 1
+    T0, T1, T2 = pts[:, simp[0]], pts[:, simp[1]], pts[:, simp[2]]
+    cache = getattr(dfield, "_tri_cache", None)
+    if cache is None:
+        M = np.stack([T1 - T0, T2 - T0], axis=2).transpose(1, 0, 2)          # (nt, 3, 2)
+        pinvM = np.linalg.pinv(M)                                            # (nt, 2, 3)
+        ctr = dfield.centers
+        rmax = np.maximum(np.maximum(_dist_cols(T0, ctr), _dist_cols(T1, ctr)), _dist_cols(T2, ctr))
+        cache = dfield._tri_cache = (M, pinvM, rmax.astype(np.float64) * 1.0001 + 1e-12)
+    return T0, T1, T2, cache
+
+
 def _project_3d(dfield, X, R, chunk=20_000):
     """Vectorised ``projection(dfield, x, R)`` for triangle surfaces (mesher.jl:778-801 with ``proj2simplex``
     :544-596): the (ghost, candidate triangle) pairs of a chunk of ghosts at once -- ``pinv`` of the 3 x 2 edge
@@ -388,18 +404,10 @@ def _project_3d(dfield, X, R, chunk=20_000):
     P = dfield.centers[:, idx].copy()
     if n == 0:
         return P
-    pts = dfield.stl.points
-    simp = dfield.stl.simplices - 1
     eps_ = f32(1e-14)
-    T0, T1, T2 = pts[:, simp[0]], pts[:, simp[1]], pts[:, simp[2]]
-    cache = getattr(dfield, "_tri_cache", None)
-    if cache is None:
-        M = np.stack([T1 - T0, T2 - T0], axis=2).transpose(1, 0, 2)          # (nt, 3, 2)
-        pinvM = np.linalg.pinv(M)                                            # (nt, 2, 3), one SVD per triangle
-        ctr = dfield.centers
-        rmax = np.maximum(np.maximum(_dist_cols(T0, ctr), _dist_cols(T1, ctr)), _dist_cols(T2, ctr))
-        cache = dfield._tri_cache = (M, pinvM, rmax.astype(np.float64) * 1.0001 + 1e-12)
+    T0, T1, T2, cache = _tri_cache(dfield)
     M, pinvM, rmax = cache
+    rmax_all = float(rmax.max())
     use = R > d
     Xt = np.ascontiguousarray(X.T, dtype=np.float64)
     for c0 in range(0, n, chunk):
@@ -407,7 +415,9 @@ def _project_3d(dfield, X, R, chunk=20_000):
         sel = np.nonzero(use[c0:c1])[0] + c0
         if sel.size == 0:
             continue
-        cand = dfield.tree.query_ball_point(Xt[sel], r=R[sel].astype(np.float64), return_sorted=True)
+        # a triangle can only win if |x - centre| < d + rmax (see the docstring): search no farther than that
+        rq = np.minimum(R[sel].astype(np.float64), d[sel].astype(np.float64) + rmax_all)
+        cand = dfield.tree.query_ball_point(Xt[sel], r=rq, return_sorted=True, workers=-1)
         lens = np.fromiter((len(c) for c in cand), dtype=np.int64, count=sel.size)
         if lens.sum() == 0:
             continue
@@ -461,7 +471,14 @@ def ghosts_and_projections(dfield, centers, widths, ghost_layer_ratio=f32(1.5)):
     if centers.shape[0] == 2:
         projs = _project_2d(dfield, Xg, Rg).astype(centers.dtype)
     else:
-        projs = _project_3d(dfield, Xg, Rg).astype(centers.dtype)
+        # A candidate whose nearest simplex centre is farther than the ghost-layer width plus the largest simplex
+        # radius cannot pass the distance test below whatever its projection is: it keeps the nearest centre.
+        rmax_all = float(_tri_cache(dfield)[3][2].max())
+        can = dists[ghosts].astype(np.float64) - rmax_all <= (diams[ghosts] * ratio).astype(np.float64)
+        idx_nn, _ = dfield.nn(Xg)
+        projs = dfield.centers[:, idx_nn].astype(centers.dtype)
+        if can.any():
+            projs[:, can] = _project_3d(dfield, Xg[:, can], Rg[can]).astype(centers.dtype)
     diff = projs - Xg
     d = np.sqrt(_colsum(diff * diff))
     m = d <= diams[ghosts] * ratio

@@ -367,7 +367,7 @@ class DistanceField:
 
     def nn(self, X):
         """Vectorised nearest-centre query: ``X (nd, n)`` -> (idx 0-based, dist)."""
-        _, idx = self.tree.query(np.ascontiguousarray(X.T, dtype=np.float64))
+        _, idx = self.tree.query(np.ascontiguousarray(X.T, dtype=np.float64), workers=-1)
         diff = X - self.centers[:, idx]
         s = diff[0] * diff[0]
         for k in range(1, diff.shape[0]):
