@@ -50,6 +50,34 @@ def dynamic_viscosity(fld, T):
     return _pointwise("ibh_cfd_dynamic_viscosity", fld, T)
 
 
+def JST_sensor(Pim1, Pi, Pip1):
+    """``CFD.JST_sensor(Pim1, Pi, Pip1)`` (cfd.jl:563-573): the three-point form, elementwise."""
+    a, _, _ = B._field(Pim1)
+    b, _, _ = B._field(Pi)
+    c, _, _ = B._field(Pip1)
+    if not (a.shape == b.shape == c.shape):
+        raise ValueError("JST_sensor: the three arrays must have one shape")
+    a, b, c = (x if x.ndim == 1 or x.stride(1) == x.shape[0] else x.T.contiguous().T for x in (a, b, c))
+    out = B._like(a, a.shape[0])
+    B._stream()
+    B.call("ibh_cfd_jst_sensor3", int(a.numel()), B._ptr(a), B._ptr(b), B._ptr(c), B._ptr(out))
+    return out
+
+
+def shock_sensor(velocity_gradients):
+    """``CFD.shock_sensor`` (cfd.jl:575-617): ``velocity_gradients[i][j]`` = device array of d u_i / d x_j."""
+    nd = len(velocity_gradients)
+    arrs = [B._field(velocity_gradients[i][j])[0] for i in range(nd) for j in range(nd)]
+    n = arrs[0].shape[0]
+    if any(a.ndim != 1 or a.shape[0] != n for a in arrs):
+        raise ValueError("shock_sensor: gradients are vectors of one length")
+    ptrs = (B.c_vp * (nd * nd))(*[a.data_ptr() for a in arrs])
+    out = B.colmajor_empty(n)
+    B._stream()
+    B.call("ibh_cfd_shock_sensor", nd, n, ptrs, B._ptr(out))
+    return out
+
+
 def heat_conductivity(fld, T):
     """cfd.jl:84-90"""
     return _pointwise("ibh_cfd_heat_conductivity", fld, T)

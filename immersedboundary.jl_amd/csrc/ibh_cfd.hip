@@ -217,6 +217,33 @@ __global__ void k_flow_bc(ibh_fluid f, int64_t n, const float* __restrict__ P, i
     }
 }
 
+// CFD.JST_sensor(Pim1, Pi, Pip1), cfd.jl:563-573: (|Pim1 + Pip1 - 2 Pi| + eps) / (|Pim1 - Pi| + |Pip1 - Pi| + eps), eps = 1f-14
+__global__ __launch_bounds__(CFD_BLOCK) void k_jst3(int64_t n, const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ c, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float e = 1e-14f, pm = a[i], p0 = b[i], pp = c[i];
+    out[i] = (fabsf(pm + pp - 2.0f * p0) + e) / (fabsf(pm - p0) + fabsf(pp - p0) + e);
+}
+// CFD.shock_sensor(velocity_gradients), cfd.jl:575-617: (div^2 + eps) / (div^2 + |curl|^2 + eps); g[i * nd + j] = d u_i / d x_j
+struct ShockGradPtrs {
+    const float* g[9];
+};
+template <int ND>
+__global__ __launch_bounds__(CFD_BLOCK) void k_shock(int64_t n, ShockGradPtrs G, float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float divu = 0.0f, vort2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int in = (i + 1) % ND, inn = (in + 1) % ND;
+        divu = divu + G.g[i * ND + i][p];
+        const float w = G.g[inn * ND + in][p] - G.g[in * ND + inn][p];
+        vort2 = vort2 + w * w;
+    }
+    divu = divu * divu;
+    out[p] = (divu + 1e-14f) / (divu + vort2 + 1e-14f);
+}
 }  // namespace
 
 #define CHECK_ND(nd, dim) IBH_REQUIRE(((nd) == 2 || (nd) == 3) && (dim) >= 1 && (dim) <= (nd), "bad nd/dim")
@@ -316,6 +343,29 @@ int ibh_cfd_flow_bc(const ibh_fluid* f, int nd, int64_t n, const float* P, int64
     else
         hipLaunchKernelGGL(k_flow_bc<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, n, P, ldp, normals, ldn, p_inf, T_inf,
                            u0, u1, u2, normal_flow, image_distances, dudn, transpiration, transpiration_v, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_cfd_jst_sensor3(int64_t n, const float* Pim1, const float* Pi, const float* Pip1, float* out) {
+    IBH_REQUIRE(Pim1 && Pi && Pip1 && out, "ibh_cfd_jst_sensor3: null argument");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_jst3, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, n, Pim1, Pi, Pip1, out);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_cfd_shock_sensor(int nd, int64_t n, const float* const* velocity_gradients, float* out) {
+    IBH_REQUIRE(velocity_gradients && out, "ibh_cfd_shock_sensor: null argument");
+    CHECK_ND(nd, 1);
+    if (n <= 0) return 0;
+    ShockGradPtrs G;
+    for (int k = 0; k < nd * nd; ++k) {
+        IBH_REQUIRE(velocity_gradients[k], "ibh_cfd_shock_sensor: null gradient array");
+        G.g[k] = velocity_gradients[k];
+    }
+    if (nd == 2) hipLaunchKernelGGL(k_shock<2>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, n, G, out);
+    else hipLaunchKernelGGL(k_shock<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, n, G, out);
     IBH_LAUNCH_CHECK();
     return 0;
 }

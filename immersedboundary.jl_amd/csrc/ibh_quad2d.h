@@ -103,6 +103,13 @@ __device__ __forceinline__ v2f flux_w2(float ua, v2f ub, float Sa, v2f Sb, float
 __device__ __forceinline__ float jst(float g, float a, float rh) {
     return fmaf(fabsf(g), rh, 1e-7f) * __builtin_amdgcn_rcpf(fmaf(a, rh, 1e-7f));
 }
+// max(1e-7, ratio of direction 1, ratio of direction 2) with ONE reciprocal (v_rcp_f32 is a quarter-rate instruction:
+// it costs four issue slots): n1/d1 vs n2/d2 -> max(n1 d2, n2 d1) / (d1 d2); all four terms are positive
+__device__ __forceinline__ float jst_max2(float g1, float a1, float rh1, float g2, float a2, float rh2) {
+    const float n1 = fmaf(fabsf(g1), rh1, 1e-7f), d1 = fmaf(a1, rh1, 1e-7f);
+    const float n2 = fmaf(fabsf(g2), rh2, 1e-7f), d2 = fmaf(a2, rh2, 1e-7f);
+    return fmaxf(fmaxf(n1 * d2, n2 * d1) * __builtin_amdgcn_rcpf(d1 * d2), 1e-7f);
+}
 
 // Lane table of the quad sweep, built at compile time: per lane 8 words, LDS byte offsets packed two per word (see
 // sweep_quad for the meaning of the fields), the lane's cell offset inside the quad and its deeper-cell step.
@@ -326,7 +333,7 @@ __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T
             if (c == 0) ax += fx0;
             if (c == 3) ax += fx3;
             const float ay = (fabsf(dT[c]) + fabsf(dB[c])) + rF[c];
-            D[c] = max3(jst(gx[c], ax, rhx), jst(gy[c], ay, rhy), 1e-7f);
+            D[c] = jst_max2(gx[c], ax, rhx, gy[c], ay, rhy);
         }
     }
     *(v4f*)(G.p_own + QUAD_TILE) = SY;
@@ -356,7 +363,7 @@ __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T
         for (int k = 0; k < 2; ++k) {
             const float an = (fabsf(dm0[k]) + fabsf(dm1[k])) + 2.0f * fabsf(dde[k]);
             const float at = (fabsf(e0[k]) + fabsf(e1[k])) + (fabsf(e2[k]) + fabsf(e3[k]));
-            Dh[k] = max3(jst(gn[k], an, hn), jst(gt[k], at, ht), 1e-7f);
+            Dh[k] = jst_max2(gn[k], an, hn, gt[k], at, ht);
         }
     }
 

@@ -246,6 +246,10 @@ int ibh_cfd_inviscid_fluxes_sensor(const ibh_fluid*, int nd, int dim, int64_t n,
                                    int64_t ld, const float* nuL, const float* nuR, float* F, int64_t ldf);
 /* viscous flux along Cartesian `dim` (cfd.jl:664-736): `Pgrad` = HOST array of nd DEVICE pointers, the
  * gradient of P along each axis, each (n, nd+2) with leading dimension ldg; mu_t per row or NULL (+ constant). */
+/* CFD.JST_sensor(Pim1, Pi, Pip1) (cfd.jl:563-573), elementwise over `n` values, and CFD.shock_sensor (cfd.jl:575-617):
+ * velocity_gradients[i * nd + j] = device array of d u_i / d x_j (n values each). */
+int ibh_cfd_jst_sensor3(int64_t n, const float* Pim1, const float* Pi, const float* Pip1, float* out);
+int ibh_cfd_shock_sensor(int nd, int64_t n, const float* const* velocity_gradients, float* out);
 int ibh_cfd_viscous_fluxes(const ibh_fluid*, int nd, int dim, int64_t n, const float* P, int64_t ldp,
                            const float* const* Pgrad, int64_t ldg, const float* mu_t, float mu_t_const,
                            float* F, int64_t ldf);

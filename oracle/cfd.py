@@ -125,6 +125,21 @@ def JST_sensor3(Pim1, Pi, Pip1):
     return (np.abs(Pim1 + Pip1 - 2 * Pi) + e) / (np.abs(Pim1 - Pi) + np.abs(Pip1 - Pi) + e)
 
 
+def shock_sensor(velocity_gradients):
+    """cfd.jl:575-617; ``velocity_gradients[i][j]`` = d u_i / d x_j (0-based lists of arrays)."""
+    e = f32(1e-14)
+    nd = len(velocity_gradients)
+    vort2 = np.zeros_like(velocity_gradients[0][0])
+    divu = np.zeros_like(velocity_gradients[0][0])
+    for i in range(nd):
+        i_n = (i + 1) % nd
+        i_nn = (i_n + 1) % nd
+        divu = divu + velocity_gradients[i][i]
+        vort2 = vort2 + (velocity_gradients[i_nn][i_n] - velocity_gradients[i_n][i_nn]) ** 2
+    divu = divu ** 2
+    return (divu + e) / (divu + vort2 + e)
+
+
 def viscous_fluxes(fluid, P, Pgrad, dim, mu_t=f32(0.0)):
     """cfd.jl:664-736, Cartesian ``dim`` (1-based); ``Pgrad[j]`` = gradient along axis j+1."""
     T = P[:, 1]

@@ -100,3 +100,20 @@ def test_flow_bc(nd):
     assert rel_inf(got, exp) <= 1e-6
     with pytest.raises(ValueError):
         gcfd.FlowBC(gf, [1.0e5, 288.15, 0.0], normal_flow=True)(dP, dn, du_dn=ibamd.hip(dudn))
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_three_point_jst_and_shock_sensor(nd):
+    """CFD.JST_sensor(Pim1, Pi, Pip1) and CFD.shock_sensor (cfd.jl:563-617) against the oracle."""
+    from ibamd import cfd as gcfd
+    rng = np.random.default_rng(nd)
+    n = 5000
+    a, b, c = (rng.uniform(0.5, 2, (n, 3)).astype(f32) for _ in range(3))
+    b[::11] = a[::11]
+    c[::11] = a[::11]          # flat spots: eps / eps = 1
+    got = ibamd.to_host(gcfd.JST_sensor(ibamd.hip(a), ibamd.hip(b), ibamd.hip(c)))
+    assert np.allclose(got, ocfd.JST_sensor3(a, b, c), rtol=2e-6, atol=0)
+    g = [[rng.normal(size=n).astype(f32) for _ in range(nd)] for _ in range(nd)]
+    got = ibamd.to_host(gcfd.shock_sensor([[ibamd.hip(x) for x in row] for row in g]))
+    exp = ocfd.shock_sensor(g)
+    assert np.allclose(got, exp, rtol=2e-6, atol=0) and (exp > 0).all() and (exp <= 1).all()
