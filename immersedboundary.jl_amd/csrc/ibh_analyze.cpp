@@ -373,7 +373,8 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
 // blocks of the 0.87 M-cell RAE2822 mesh sit in such groups (the four leaf children of a quadtree node).
 // ------------------------------------------------------------------------------------------
 void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<int32_t>& htab,
-                      const std::vector<int32_t>& etab, const std::vector<char>& cand, int32_t nB1, QuadSet2& out) {
+                      const std::vector<int32_t>& etab, const std::vector<char>& cand, int32_t nB1, QuadSet2& out,
+                      int32_t nc) {
     out = QuadSet2();
     const int32_t nb = (int32_t)blocks.size();
     std::unordered_map<int32_t, int32_t> bybase;
@@ -408,8 +409,17 @@ void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<i
             const BlockDesc2& b = blocks[idx[k]];
             ok = b.dt < 0 && b.h[0] == b0.h[0] && b.h[1] == b0.h[1];
             for (int e = 0; e < 2 && ok; ++e) {
-                const int ty = b.type[outer[k][e]];
+                const int s = outer[k][e];
+                const int ty = b.type[s];
                 ok = ty == SIDE_SAME || ty == SIDE_COARSE || ty == SIDE_FINE;
+                // paired gathers of the quad sweep (quad_load_halo_paired): on bottom / top sides the 8-byte load at a
+                // halo cell must stay inside the arrays, and the two sub-face cells of a FINE side must be x neighbours
+                if (ok && s >= 2)
+                    for (int t = 0; t < 8 && ok; ++t) {
+                        const int32_t h0 = htab[(size_t)idx[k] * 64 + (s * 8 + t) * 2], h1 = htab[(size_t)idx[k] * 64 + (s * 8 + t) * 2 + 1];
+                        const int32_t dl = s == 2 ? -8 : 8;
+                        ok = h0 + 1 < nc && h0 + dl >= 0 && h0 + dl + 1 < nc && (ty != SIDE_FINE || h1 == h0 + 1);
+                    }
             }
         }
         if (!ok) continue;

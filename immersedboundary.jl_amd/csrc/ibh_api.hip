@@ -77,8 +77,8 @@ static void analyze2_host(const HostPartView& v, int32_t n_image, const int32_t*
             if (H.needg[b]) { H.ng.push_back(b); H.n_ng_int += b < H.nph[0]; }
         }
     H.info[9] = H.fuse_all ? 0 : (int64_t)H.ng.size();
-    if (H.fuse_all) ibh_build_quads2(H.blocks, H.htab, H.etab, H.fus, H.nph[1], H.quads[0]);
-    if (H.img_all_fz && !H.fuse_all) ibh_build_quads2(H.blocks, H.htab, H.etab, is_imgblk, H.nph[1], H.quads[1]);
+    if (H.fuse_all) ibh_build_quads2(H.blocks, H.htab, H.etab, H.fus, H.nph[1], H.quads[0], nc);
+    if (H.img_all_fz && !H.fuse_all) ibh_build_quads2(H.blocks, H.htab, H.etab, is_imgblk, H.nph[1], H.quads[1], nc);
 }
 
 static int make_view(HostPartView& v, int nd, int32_t nc, const float* spacing, const int32_t* nf,

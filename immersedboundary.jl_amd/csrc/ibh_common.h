@@ -179,7 +179,8 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
 
 // quads among the candidate blocks (cand[b] != 0); blocks < nB1 are interior-phase blocks
 void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<int32_t>& htab,
-                      const std::vector<int32_t>& etab, const std::vector<char>& cand, int32_t nB1, QuadSet2& out);
+                      const std::vector<int32_t>& etab, const std::vector<char>& cand, int32_t nB1, QuadSet2& out,
+                      int32_t nc);
 
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,

@@ -929,6 +929,7 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
                        p->blocks2, p->htab, p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs, ibh_quad_singles_first)
         if (p->n_dt > 0) QUAD_LAUNCH(true, false);
         else if (ibh_quad_variant == 4) QUAD_LAUNCH(false, true);
+        else if (ibh_quad_variant == 126) QUAD_LAUNCH(false, false, 126);  // A/B: seven 4-byte gathers
         else if (ibh_quad_variant == 85) QUAD_LAUNCH(false, false, 85);  // measurement: subsets of the halo gathers
         else if (ibh_quad_variant == 69) QUAD_LAUNCH(false, false, 69);
         else if (ibh_quad_variant == 5) QUAD_LAUNCH(false, false, 5);

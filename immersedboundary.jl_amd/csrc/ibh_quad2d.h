@@ -260,6 +260,39 @@ __device__ __forceinline__ QuadHalo quad_load_halo(const QuadLane& G, const Quad
     return H;
 }
 
+// The same seven values with FOUR full gathers and one that only the lanes of FINE left / right half-sides issue:
+// every gather is 8 bytes per lane.  Left / right lanes: the halo cell and the cell one step deeper are x neighbours
+// (one pair per sub-face slot).  Bottom / top lanes: the two sub-face cells of a FINE half-side are x neighbours (the
+// builder checks it: ibh_build_quads2), so (slot 0, slot 1) of the halo cells, of the deeper cells and of the velocity
+// come as pairs; on SAME / COARSE half-sides slot 1 repeats slot 0 and the second element is not used.
+__device__ __forceinline__ QuadHalo quad_load_halo_paired(const QuadLane& G, const QuadTab& T, const float* __restrict__ u,
+                                                          const float* __restrict__ C, uint32_t ldc) {
+    using blk2::ldg;
+    typedef float v2f_g __attribute__((ext_vector_type(2), aligned(4)));
+    auto pair = [](const float* p, int i) { return *(const v2f_g*)((const char*)p + ((size_t)(uint32_t)i << 2)); };
+    QuadHalo H;
+    const float* Cn = C + (G.dny ? ldc : 0u);
+    const bool isF = ((T.d.cls >> (4 * G.lhs)) & 15u) == SIDE_FINE;
+    const int lo = G.delta < 0 ? G.delta : 0;                       // left side: the pair starts at the deeper cell
+    const v2f PA = pair(u, G.lr ? T.hid.x + lo : T.hid.x);
+    const v2f PB = pair(u, G.lr ? T.hid.y + lo : T.hid.x + G.delta);
+    const v2f PC = pair(Cn, T.hid.x);
+    H.eu = ldg(u, T.eid);
+    float hc1 = 0.0f;
+    if (G.lr && isF) hc1 = ldg(Cn, (uint32_t)T.hid.y);              // few lanes, few quads
+    asm volatile("" : "+v"(hc1));
+    const bool first = G.g0;                                         // left side: (deeper, halo); right side: (halo, deeper)
+    const float huA = first ? PA.y : PA.x, hdA = first ? PA.x : PA.y;
+    const float huB = first ? PB.y : PB.x, hdB = first ? PB.x : PB.y;
+    H.hu.x = G.lr ? huA : PA.x;
+    H.hd.x = G.lr ? hdA : PB.x;
+    H.hu.y = G.lr ? huB : (isF ? PA.y : PA.x);
+    H.hd.y = G.lr ? hdB : (isF ? PB.y : PB.x);
+    H.hc.x = PC.x;
+    H.hc.y = isF ? (G.lr ? hc1 : PC.y) : PC.x;
+    return H;
+}
+
 // ---- the arithmetic of one quad.  STAMP: phase time stamps of the wave (100 MHz ticks) for scripts/wave_timeline.py
 template <bool STAMP>
 __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T, const QuadOwn& O, const QuadHalo& H,
@@ -433,7 +466,7 @@ __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, con
     const QuadLane G = quad_lane(lds, lane);
     const QuadTab T = quad_load_tab(qd, qtab, q, lane);  // everything that needs the quad's index only is in flight
     const QuadOwn O = quad_load_own(G, T, u, C, ldc);
-    const QuadHalo H = quad_load_halo<GM>(G, T, u, C, ldc);
+    const QuadHalo H = GM == 127 ? quad_load_halo_paired(G, T, u, C, ldc) : quad_load_halo<GM == 126 ? 127 : GM>(G, T, u, C, ldc);
     quad_compute<STAMP>(G, T, O, H, ud, stamps);
 }
 

@@ -76,7 +76,7 @@ if os.environ.get("QUAD_TUNE"):  # same-process A/B: alternate, keep the best me
             best[name_] = min(best.get(name_, 1e9), sweep_time())
     _lib.call("ibh_set_tuning", b"quad_parts", 1)
     for _ in range(3):
-        for name_, var in (("quads_only_all_gathers", 0), ("quads_only_k0+ends", 85), ("quads_only_hu0_hd0_ends", 69),
+        for name_, var in (("quads_only_paired_gathers(default)", 0), ("quads_only_seven_gathers", 126), ("quads_only_k0+ends", 85), ("quads_only_hu0_hd0_ends", 69),
                            ("quads_only_hu0_hd0", 5), ("quads_only_no_gathers", 100)):
             _lib.call("ibh_set_tuning", b"quad_variant", var)
             best[name_] = min(best.get(name_, 1e9), sweep_time())
