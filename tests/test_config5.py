@@ -1,0 +1,124 @@
+"""BASELINE.json configs[4] in one piece at reduced size: `FAS!` V-cycle (src/solver.jl:39-91) over the `multigrid`
+hierarchy of a 3-D sphere octree (src/ImmersedBoundary.jl:1355-1407: block sizes 8, 4, 2 on the same block tree) with a
+one-equation turbulence scalar in the residual -- the closure the reference really has, Wray-Agarwal
+(src/turbulence.jl:222-241; F2 of SURVEY.md: there is no Spalart-Allmaras in the reference):
+
+    Q = [p T u v w R];   d/dt [p T u v w] <- Euler HLL residual (JST + MUSCL + CFD.inviscid_fluxes + green_gauss)
+    R_t = -div(u R) + div[(nu + nu_R) grad R] + S,   (nu_t, nu_R, S) = Wray_Agarwal(R, shear_rate(grad u), grad R, grad S)
+
+Device-resident loop (fused 3-D Euler sweep on the fine level, face-list kernels on the coarse ones, operator kernels
+and the turbulence kernels for the scalar, Accumulator SpMV for the transfers) against the oracle's numpy loop."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import ibamd
+from conftest import oracle_view, rel_inf
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+f32 = np.float32
+pytestmark = pytest.mark.gpu
+NU = f32(1.5e-5)
+
+
+def _oracle_acc(acc):
+    from oracle.accumulator import Accumulator as OAcc
+    o = object.__new__(OAcc)
+    o.n_output, o.first_index, o.stencils = acc.n_output, True, acc.stencils
+    return o
+
+
+def test_config5_fas_vcycle_with_turbulence_scalar():
+    import torch
+    import bench
+    from ibamd import turbulence as gt
+    from ibamd.mesher import Mesh
+    from oracle import cfd as ocfd
+    from oracle import domain as od
+    from oracle import turbulence as ot
+    from oracle.solver import FAS as oFAS
+    from test_gpu_residual import oracle_euler_residual
+    msh = Mesh(f32([-4, -4, -4]), f32([8, 8, 8]), ("sphere", bench.icosphere(subdiv=2), f32(0.2)), block_size=8)
+    msh.distance_fields = {}                       # the V-cycle test builds no ghost cells (tests/test_config4.py does)
+    dom = ibamd.Domain(msh, max_partition_size=10 ** 9)
+    cds, prol, coar = ibamd.multigrid(dom, max_levels=2)
+    levels = [dom] + cds
+    sizes = [len(d) for d in levels]
+    assert dom.ndims == 3 and sizes[0] >= 100_000 and sizes[0] == 8 * sizes[1] == 64 * sizes[2]
+    parts = [d.partitions[1] for d in levels]
+    oparts = [oracle_view(p) for p in parts]
+    dparts = [ibamd.to_backend(p, ibamd.hip) for p in parts]
+    assert dparts[0].info["full_blocks"] * 512 == sizes[0]         # fine level: the 3-D block kernels
+    n = sizes[0]
+    rng = np.random.default_rng(5)
+    X = dom.global_centers()
+    Q0 = np.empty((n, 6), dtype=f32)
+    Q0[:, 0] = 1e5 * (1 + 0.02 * rng.uniform(-1, 1, n))
+    Q0[:, 1] = 288.15 * (1 + 0.02 * rng.uniform(-1, 1, n))
+    Q0[:, 2] = 100.0 * (1 + 0.05 * np.sin(X[:, 1]))
+    Q0[:, 3] = 10.0 * np.cos(X[:, 0]) + rng.uniform(-1, 1, n)
+    Q0[:, 4] = 10.0 * np.sin(X[:, 2]) + rng.uniform(-1, 1, n)
+    Q0[:, 5] = 3 * NU * (1 + 0.5 * rng.uniform(0, 1, n))          # R_inf = 3 nu (turbulence.jl:205)
+    omega = f32(2e-7)                                             # pseudo-time step, the same on every level
+
+    def o_f(l, Q):
+        part = oparts[l]
+        r = np.zeros_like(Q)
+        r[:, :5] = oracle_euler_residual(part, np.ascontiguousarray(Q[:, :5]), ocfd.Fluid())
+        R = np.ascontiguousarray(Q[:, 5])
+        gu = [[od.cell_gradient(part, np.ascontiguousarray(Q[:, 2 + i]), j + 1) for j in range(3)] for i in range(3)]
+        S = ot.shear_rate(gu)
+        gR = np.stack([od.cell_gradient(part, R, d + 1) for d in range(3)], axis=1)
+        gS = np.stack([od.cell_gradient(part, S, d + 1) for d in range(3)], axis=1)
+        wa = ot.Wray_Agarwal(R, S, gR, gS)
+        rt = wa["S"].copy()
+        for d in range(3):
+            conv = od.at_faces(part, np.ascontiguousarray(Q[:, 2 + d]) * R, d + 1)
+            diff = od.at_faces(part, NU + wa["nuR"], d + 1) * od.face_gradient(part, R, d + 1)
+            rt += od.green_gauss(part, diff - conv, d + 1)
+        r[:, 5] = rt
+        return r, omega
+
+    def g_f(l, Q):
+        part = dparts[l]
+        r = ibamd.colmajor_empty(Q.shape[0], 6)
+        Pv = Q[:, :5]
+        ibamd.residual_euler_hll(part, Pv, out=r[:, :5])
+        R = Q[:, 5].contiguous()
+        gu = [[ibamd.cell_gradient(part, Q[:, 2 + i].contiguous(), j + 1) for j in range(3)] for i in range(3)]
+        S = gt.shear_rate(gu)
+        gR = torch.stack([ibamd.cell_gradient(part, R, d + 1) for d in range(3)], dim=0).T
+        gS = torch.stack([ibamd.cell_gradient(part, S, d + 1) for d in range(3)], dim=0).T
+        wa = gt.Wray_Agarwal(R, S, gR, gS)
+        rt = wa["S"].clone()
+        for d in range(3):
+            conv = ibamd.at_faces(part, Q[:, 2 + d].contiguous() * R, d + 1)
+            diff = ibamd.at_faces(part, float(NU) + wa["nuR"], d + 1) * ibamd.face_gradient(part, R, d + 1)
+            rt += ibamd.green_gauss(part, diff - conv, d + 1)
+        r[:, 5] = rt
+        return r, omega
+
+    # one evaluation of the residual on every level first (coarse levels through the transfer operators)
+    ocoar, oprol = [_oracle_acc(a) for a in coar], [_oracle_acc(a) for a in prol]
+    Ql_o, Ql_g = Q0.copy(), ibamd.hip(Q0)
+    for l in range(3):
+        ro, _ = o_f(l, Ql_o)
+        rg, _ = g_f(l, Ql_g)
+        for v in range(6):
+            assert rel_inf(ibamd.to_host(rg)[:, v], ro[:, v]) <= 2e-5, (l, v)
+        if l < 2:
+            Ql_o = ocoar[l](Ql_o)
+            Ql_g = ibamd.to_backend(coar[l])(Ql_g)
+            assert rel_inf(ibamd.to_host(Ql_g), Ql_o) <= 1e-6
+    # the V-cycle
+    Qo = Q0.copy()
+    ratio_o = oFAS(o_f, Qo, coarseners=ocoar, prolongators=oprol, n_iter=3, rtol=f32(1e-6))
+    Qg = ibamd.hip(Q0)
+    ratio_g = ibamd.FAS(g_f, Qg, coarseners=coar, prolongators=prol, n_iter=3, rtol=1e-6)
+    got = ibamd.to_host(Qg)
+    assert not np.array_equal(Qo, Q0) and np.isfinite(got).all()
+    for v in range(6):
+        assert rel_inf(got[:, v], Qo[:, v]) <= 2e-5, v
+    assert abs(ratio_g - float(ratio_o)) <= 1e-3 * max(1.0, float(ratio_o))
