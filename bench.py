@@ -173,10 +173,11 @@ def main():
                          "reproduces the rccl exchange bit for bit at start-up, else rccl")
     ap.add_argument("--graph-batch", type=int, default=20,
                     help="sweeps captured per HIP graph (launch-bound loop; 0 = eager launches)")
-    ap.add_argument("--step", default="sweep", choices=["sweep", "config4"],
+    ap.add_argument("--step", default="sweep", choices=["sweep", "config4", "config5"],
                     help="config4 (3-D workloads, --residual euler): a step = impose_bc! with FlowBC closures on the "
                          "immersed sphere and the far field (ghost-layer interpolation) + the Euler residual sweep; one "
-                         "point-implicit linearise + relaxation is timed beside it")
+                         "point-implicit linearise + relaxation is timed beside it; config5: a step = one FAS! V-cycle "
+                         "(3 levels, 2 smoothing iterations each) of the Euler + Wray-Agarwal residual")
     ap.add_argument("--repeats", type=int, default=20,
                     help="the timed block of --steps sweeps is repeated this many times; the median is reported")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -246,8 +247,11 @@ def main():
     mps = -(-ncells // world)
     mps = -(-mps // npb) * npb  # block-aligned partitions
     config4 = args.step == "config4"
-    if config4 and (msh.ndims != 3 or args.residual != "euler" or world != 1):
-        raise SystemExit("--step config4 needs a sphere3d workload, --residual euler and one GPU")
+    config5 = args.step == "config5"
+    if (config4 or config5) and (msh.ndims != 3 or args.residual != "euler" or world != 1):
+        raise SystemExit("--step config4 / config5 need a sphere3d workload, --residual euler and one GPU")
+    if config5:
+        msh.distance_fields = {}  # the V-cycle line builds no ghost cells (config4 does)
     fam4 = [("farfield", [(d, s_) for d in (1, 2, 3) for s_ in (False, True)])]
     dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=config4, only=[rank + 1],
                        hypercube_families=fam4 if config4 else ())
@@ -328,8 +332,25 @@ def main():
             for b in dom.boundaries[bname].values():
                 ibamd.to_backend(b, ibamd.hip)
 
+    if config5:
+        from ibamd.closures import euler_wray_agarwal_residual
+        cds5, prol5, coar5 = ibamd.multigrid(dom, max_levels=2)
+        levels5 = [dpart] + [ibamd.to_backend(d.partitions[1], ibamd.hip) for d in cds5]
+        for a5 in list(prol5) + list(coar5):
+            ibamd.to_backend(a5)                       # transfer operators on the device before the timed region
+        Q5 = ibamd.colmajor_empty(dpart.nc, nvp + 1)
+        Q5[:, :nvp] = P
+        Q5[:, nvp] = 4.5e-5
+        Q5_0 = Q5.clone()
+
+        def f5(level, Q):
+            return euler_wray_agarwal_residual(levels5[level], Q), 2e-7
+
     def step():
-        if config4:
+        if config5:
+            Q5.copy_(Q5_0)
+            ibamd.FAS(f5, Q5, coarseners=coar5, prolongators=prol5, n_iter=2, rtol=1e-9)
+        elif config4:
             ibamd.impose_bc(lambda b, ia: far_bc(ia, b.normals), dom, "farfield", P)
             ibamd.impose_bc(lambda b, ia: wall_bc(ia, b.normals), dom, "sphere", P)
             sweep()
@@ -352,7 +373,7 @@ def main():
     # The sweep is ~10 us of GPU work: a Python/ctypes launch per step would be host-bound, so on one GPU
     # the step loop is captured into HIP graphs of `graph_batch` sweeps each (every sweep still runs in full).
     # (N > 1: only with the xgmi exchange, which is kernels only; RCCL calls are launched eagerly.)
-    graphable = (world == 1 or halo_kind == "xgmi-direct") and not config4   # (the BC closures launch eagerly)
+    graphable = (world == 1 or halo_kind == "xgmi-direct") and not (config4 or config5)   # (closures launch eagerly)
     batch = args.graph_batch if (graphable and args.graph_batch > 0) else 0
     graph = None
     side = torch.cuda.Stream()
@@ -591,6 +612,15 @@ def main():
                                                     "what": "pseudo-time step (P - P0)/dt - R(P), Hutchinson block "
                                                             "estimate with 1 sample per variable (6 sweeps), one two-"
                                                             "direction relaxation (2 sweeps)"}}
+    if config5:
+        out["metric"] = ("Mcells*V-cycles/s, config-5 step (FAS! V-cycle, 3 levels x 2 smoothing iterations, Euler HLL + "
+                         "Wray-Agarwal scalar residual), 3D sphere")
+        out["config"]["step"] = {"levels_cells": [int(l.nc) for l in levels5],
+                                 "residual_evaluations_per_step": 9,
+                                 "what": "solver.jl:39-91 over multigrid() (ImmersedBoundary.jl:1355-1407); residual = fused "
+                                         "3-D Euler sweep (face-list kernels on the coarse levels) + operator-granularity "
+                                         "Wray-Agarwal transport (closures.euler_wray_agarwal_residual); one host sync per "
+                                         "iteration for the convergence test"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler and not is3d:
         cb = cpu_baseline(part, u_h, C_h)
         out["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "Mcells*iters/s", "cores": cb["threads"],

@@ -73,6 +73,7 @@ _SIGS = {
     "ibh_ew_reduce": [c_int, c_i64, c_vp, c_vp],
     "ibh_set_tuning": [C.c_char_p, c_int],
     "ibh_debug_buffer": [c_vp],
+    "ibh_probe_dispatch": [c_int, c_int, c_int],
     "ibh_probe_sweep": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
     "ibh_residual_euler_hll": [c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(ibh_fluid), c_int],
     "ibh_cfd_speed_of_sound": [C.POINTER(ibh_fluid), c_i64, c_vp, c_vp],

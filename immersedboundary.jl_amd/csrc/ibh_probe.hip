@@ -85,7 +85,20 @@ __global__ __launch_bounds__(64 * WPB) void k_probe_sweep(const float* __restric
     else if (r == 123.456f) ud[c] = 0.f;
 }
 
+__global__ void k_probe_dispatch(int flag) {
+    extern __shared__ float dyn[];
+    if (flag == 12345) dyn[threadIdx.x] = 0.f;  // keeps the dynamic LDS allocation
+}
+
 }  // namespace
+
+// dispatch cost of an empty grid: `nwg` workgroups of `threads` threads with `lds_bytes` of LDS each
+extern "C" int ibh_probe_dispatch(int nwg, int threads, int lds_bytes) {
+    IBH_REQUIRE(nwg > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 65536, "ibh_probe_dispatch: bad shape");
+    hipLaunchKernelGGL(k_probe_dispatch, dim3(nwg), dim3(threads), lds_bytes, ibh_stream, 0);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ibh_probe_sweep(ibh_part* p, const float* u, const float* C, int64_t ldc, float* ud, int mode) {
     IBH_REQUIRE(p && u && C && ud, "ibh_probe_sweep: null argument");

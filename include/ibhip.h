@@ -117,6 +117,8 @@ int ibh_debug_buffer(void* device_buffer);
 /* Measurement probe (not on the product path): the launch of the 2-D quad sweep with the work stripped down.
  * mode 0 = dispatch only, 1 = + own-cell loads and the store (16 B per cell), 2 = + tables and halo gathers. */
 int ibh_probe_sweep(ibh_part* part, const float* u, const float* C, int64_t ldc, float* ud, int mode);
+/* Dispatch cost of an empty grid (measurement): nwg workgroups x threads, lds_bytes of LDS per workgroup. */
+int ibh_probe_dispatch(int nwg, int threads, int lds_bytes);
 
 /* Host-only view of the 2-D block analysis ibh_partition_create runs (block table, halo / end tables, the 2x2 block
  * groups of the quad sweep): same inputs, no device needed.  Test infrastructure for the library's host logic; not

@@ -61,6 +61,18 @@ if os.environ.get("PROBE_DETAIL"):
                       (3 + 4 + 16 + 64 + 256, "all_k0"), (3 + 4 + 8 + 16 + 32, "own+tables+hu01+hd01"),
                       (1 + 2 + 256, "own+tables+ends")):
         out[key] = round(timed(lambda: probe(16 + bits)), 3)
+if os.environ.get("PROBE_DISPATCH"):
+    nwaves = 4 * 1119
+
+    def disp(nwg, th, lds):
+        def f():
+            _lib.call("ibh_set_stream", _lib.c_vp(torch.cuda.current_stream().cuda_stream))
+            _lib.call("ibh_probe_dispatch", nwg, th, lds)
+        return round(timed(f), 3)
+    out["dispatch_shapes_us"] = {f"{nwaves * 64 // th}x{th}_lds{lds}": disp(nwaves * 64 // th, th, lds)
+                                 for th in (64, 128, 256, 512, 1024) for lds in (0, min(65536, 6784 * th // 64))}
+    out["dispatch_shapes_us"]["1x64_lds0"] = disp(1, 64, 0)
+    out["dispatch_shapes_us"]["256x256_lds0"] = disp(256, 256, 0)
 out["sweep_us"] = round(timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud)), 3)
 def sweep_time():
     return timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud))

@@ -33,7 +33,6 @@ def _oracle_acc(acc):
 def test_config5_fas_vcycle_with_turbulence_scalar():
     import torch
     import bench
-    from ibamd import turbulence as gt
     from ibamd.mesher import Mesh
     from oracle import cfd as ocfd
     from oracle import domain as od
@@ -82,23 +81,8 @@ def test_config5_fas_vcycle_with_turbulence_scalar():
         return r, omega
 
     def g_f(l, Q):
-        part = dparts[l]
-        r = ibamd.colmajor_empty(Q.shape[0], 6)
-        Pv = Q[:, :5]
-        ibamd.residual_euler_hll(part, Pv, out=r[:, :5])
-        R = Q[:, 5].contiguous()
-        gu = [[ibamd.cell_gradient(part, Q[:, 2 + i].contiguous(), j + 1) for j in range(3)] for i in range(3)]
-        S = gt.shear_rate(gu)
-        gR = torch.stack([ibamd.cell_gradient(part, R, d + 1) for d in range(3)], dim=0).T
-        gS = torch.stack([ibamd.cell_gradient(part, S, d + 1) for d in range(3)], dim=0).T
-        wa = gt.Wray_Agarwal(R, S, gR, gS)
-        rt = wa["S"].clone()
-        for d in range(3):
-            conv = ibamd.at_faces(part, Q[:, 2 + d].contiguous() * R, d + 1)
-            diff = ibamd.at_faces(part, float(NU) + wa["nuR"], d + 1) * ibamd.face_gradient(part, R, d + 1)
-            rt += ibamd.green_gauss(part, diff - conv, d + 1)
-        r[:, 5] = rt
-        return r, omega
+        from ibamd.closures import euler_wray_agarwal_residual
+        return euler_wray_agarwal_residual(dparts[l], Q, nu=NU), omega
 
     # one evaluation of the residual on every level first (coarse levels through the transfer operators)
     ocoar, oprol = [_oracle_acc(a) for a in coar], [_oracle_acc(a) for a in prol]
