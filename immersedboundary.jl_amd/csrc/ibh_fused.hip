@@ -485,6 +485,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 #include "ibh_block2d.h"
 #include "ibh_sweep2d.h"
 #include "ibh_quad2d.h"
+#include "ibh_quad2d_euler.h"
 #include "ibh_block3d.h"
 
 namespace {
@@ -651,6 +652,39 @@ __global__ __launch_bounds__(64 * WPBE) void k_sweep_euler(const float* __restri
     const int32_t nb = __builtin_amdgcn_readfirstlane(min(iters, (nblk - first + WPBE - 1) / WPBE));
     blk2::sweep_euler(blocks, htab, etab, dtab, blist, first, WPBE, nb, P, ldp, R, ldr, blk2::Gas{Rgas, gamma},
                       lds + wave * BLK2_SWEEP_EULER_LDS, lane);
+}
+
+// Quad form of the Euler sweep (quad2::sweep_quad_euler): grid = [quad workgroups | single-block workgroups], like
+// k_sweep_quad
+#define QUADE_WG_LDS (WPBE * (QE_LDS > BLK2_SWEEP_EULER_LDS ? QE_LDS : BLK2_SWEEP_EULER_LDS))
+// 206 VGPRs = 2 waves per SIMD.  Forcing 3 (168 VGPRs, 25 spilled) measured 15.4 us against 12.1 us for the quads of
+// the 0.87 M-cell mesh, 4 (128, 139 spilled) 32.8 us; the quad path is 1441 vector instructions per wave (569 of them
+// packed), i.e. ~80 % of the time of the quad part is VALU issue (profiles/r2_final/probe_euler.json).
+__global__ __launch_bounds__(64 * WPBE) void k_sweep_quad_euler(const float* __restrict__ P, uint32_t ldp,
+                                                                float* __restrict__ R, uint32_t ldr, float Rgas,
+                                                                float gamma, const QuadDesc2* __restrict__ qd,
+                                                                const int32_t* __restrict__ qtab, int32_t nq,
+                                                                int32_t nwgq, const BlockDesc2* __restrict__ blocks,
+                                                                const int32_t* __restrict__ htab,
+                                                                const int32_t* __restrict__ etab,
+                                                                const int32_t* __restrict__ dtab,
+                                                                const int32_t* __restrict__ singles, int32_t ns,
+                                                                int32_t nwgs, int32_t singles_first) {
+    __shared__ __attribute__((aligned(16))) float lds[QUADE_WG_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t wg = singles_first ? ((int32_t)blockIdx.x < nwgs ? (int32_t)blockIdx.x + nwgq : (int32_t)blockIdx.x - nwgs)
+                                     : (int32_t)blockIdx.x;
+    if (wg < nwgq) {
+        const int32_t q = __builtin_amdgcn_readfirstlane(xcd_remap(wg, nwgq) * WPBE + wave);
+        if (q < nq) quad2::sweep_quad_euler(qd, qtab, q, P, ldp, R, ldr, blk2::Gas{Rgas, gamma}, lds + wave * QE_LDS, lane);
+    } else {
+        const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(wg - nwgq, nwgs) * WPBE + wave);
+#ifndef IBH_QE_NO_SINGLES  // (instruction counts of the quad path alone: scripts/isa_count.py)
+        if (first < ns)
+            blk2::sweep_euler(blocks, htab, etab, dtab, singles, first, WPBE, 1, P, ldp, R, ldr, blk2::Gas{Rgas, gamma},
+                              lds + wave * BLK2_SWEEP_EULER_LDS, lane);
+#endif
+    }
 }
 
 // 3-D block kernels: one 512-thread workgroup per 8x8x8 block (the face-list cells get their own launch)
@@ -1063,7 +1097,19 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
         const int32_t nall = p->fuse_all ? p->nblk : p->n_img, nint = p->fuse_all ? p->nB1 : p->n_img_int;
         const int32_t i0 = ph2 ? nint : 0, i1 = ph1 ? nint : nall;
         const int32_t count = i1 - i0;
-        if (count > 0) {
+        const int k = p->fuse_all ? 0 : 1;
+        if (ibh_quad && !(flags & IBH_NO_QUAD) && p->nq[k] > 0) {
+            int32_t s0 = ph2 ? p->nqs_int[k] : 0, s1 = ph1 ? p->nqs_int[k] : p->nqs[k];
+            int32_t q0 = ph2 ? p->nq_int[k] : 0, q1 = ph1 ? p->nq_int[k] : p->nq[k];
+            if (ibh_quad_parts == 1) s1 = s0;  // measurement: quads only / single blocks only
+            if (ibh_quad_parts == 2) q1 = q0;
+            const int32_t nwgq = (q1 - q0 + WPBE - 1) / WPBE, nwgs = (s1 - s0 + WPBE - 1) / WPBE;
+            if (nwgq + nwgs > 0)
+                hipLaunchKernelGGL(k_sweep_quad_euler, dim3(nwgq + nwgs), dim3(64 * WPBE), 0, ibh_stream, P, (uint32_t)ldp,
+                                   R, (uint32_t)ldr, fluid->R, fluid->gamma, p->qd[k] + q0,
+                                   p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq, p->blocks2, p->htab, p->etab, p->dtab,
+                                   p->qsingles[k] + s0, s1 - s0, nwgs, ibh_quad_singles_first);
+        } else if (count > 0) {
             const int32_t iters = ibh_sweep_iters > 0 ? ibh_sweep_iters : std::min(4, std::max(1, count / 6000));
             const int32_t nwg = (count + WPBE * iters - 1) / (WPBE * iters);
             const BlockDesc2* bl = list ? p->blocks2 : p->blocks2 + i0;

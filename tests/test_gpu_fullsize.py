@@ -75,6 +75,7 @@ def test_full_size_euler_sweep_variants_agree(full):
     dP = ibamd.hip(P)
     one = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP))
     two = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP, flags=ibamd.IBH_NO_FUSE))
+    blk = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP, flags=ibamd.IBH_NO_QUAD))      # per-block single kernel
     gen = ibamd.to_host(ibamd.residual_euler_hll(dpart, dP, flags=ibamd.IBH_FORCE_GENERAL))  # literal, Float64 HLL
     from oracle import residual_c as rc
     exp = rc.CPart(part).residual_euler(P)          # the C restatement on the whole mesh
@@ -82,6 +83,7 @@ def test_full_size_euler_sweep_variants_agree(full):
     for v in range(4):
         assert rel_inf(two[:, v], exp[:, v]) <= 1e-5, v
         assert rel_inf(one[:, v], exp[:, v]) <= 1e-5, v
+        assert rel_inf(blk[:, v], exp[:, v]) <= 1e-5, v
 
 
 def test_config3_partitions_image_only_sweep():
@@ -113,6 +115,22 @@ def test_config3_partitions_image_only_sweep():
         per_block = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C),
                                                            flags=ibamd.IBH_IMAGE_ONLY | ibamd.IBH_NO_QUAD))
         assert rel_inf(got[img], per_block[img]) <= 2e-6
+        if k == 4:   # the Euler sweep of the same rank: quad form (quad2::sweep_quad_euler) over the image quads
+            rng = np.random.default_rng(7)
+            n = u.shape[0]
+            P = np.stack([1e5 * (1 + 0.05 * rng.uniform(-1, 1, n)), 288.15 * (1 + 0.05 * rng.uniform(-1, 1, n)),
+                          100.0 * (1 + 0.1 * rng.uniform(-1, 1, n)), 100.0 * (1 + 0.1 * rng.uniform(-1, 1, n))],
+                         axis=1).astype(f32)
+            expE = rc.CPart(part).residual_euler(P)
+            outE = torch.full((4, n), float("nan"), dtype=torch.float32, device="cuda").T          # column-major
+            ibamd.residual_euler_hll(dpart, ibamd.hip(P), out=outE, flags=ibamd.IBH_IMAGE_ONLY)
+            gotE = ibamd.to_host(outE)
+            blkE = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P),
+                                                          flags=ibamd.IBH_IMAGE_ONLY | ibamd.IBH_NO_QUAD))
+            assert np.isnan(gotE[:, 0]).sum() == n - img.size
+            for v in range(4):
+                assert rel_inf(gotE[img, v], expE[img, v]) <= 1e-5, v
+                assert rel_inf(gotE[img, v], blkE[img, v]) <= 5e-6, v
 
 
 def test_full_size_per_cell_error_percentiles(full, capsys):

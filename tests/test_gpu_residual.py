@@ -208,10 +208,14 @@ def test_single_kernel_euler_sweep(rae_mesh_small):
     exp = oracle_euler_residual(oracle_view(part), P, ocfd.Fluid())
     one = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P)))
     two = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=ibamd.IBH_NO_FUSE))
+    blk = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=ibamd.IBH_NO_QUAD))  # per-block sweep
+    assert dpart.info["quads"] > 0                       # `one` is the quad form (quad2::sweep_quad_euler)
     for v in range(4):
         assert rel_inf(two[:, v], exp[:, v]) <= TOL, v
         assert rel_inf(one[:, v], exp[:, v]) <= TOL, v
+        assert rel_inf(blk[:, v], exp[:, v]) <= TOL, v
         assert rel_inf(one[:, v], two[:, v]) <= 5e-6, v
+        assert rel_inf(one[:, v], blk[:, v]) <= 5e-6, v
 
 
 def test_image_only_sweep_on_partitions(rae_domains):
