@@ -492,10 +492,12 @@ def main():
     mixed = (not euler and not is3d and base_flags == 0 and not fused and not image_only
              and inf["fusable_blocks"] >= 12000 and 4 * inf["fusable_blocks"] >= inf["full_blocks"])
     fused_e = euler and not is3d and flags == 0 and inf["irregular_cells"] == 0 and inf["fusable_blocks"] == inf["full_blocks"] > 0
+    # 3-D scalar sweep: single kernel over the eligible blocks (+ the two-kernel form over the rest, same sweep)
+    fused3 = (is3d and not euler and flags == 0 and inf["irregular_cells"] == 0 and inf["fusable_blocks"] > 0)
     if image_only:
         tB, tA = time_pass(0, reps), None
         cells_launch = n_image
-    elif fused or fused_e:
+    elif fused or fused_e or fused3:
         tB, tA = time_pass(0, reps), None
     elif mixed:
         tB, tA = time_pass(ibamd.IBH_SWEEP_ONLY, reps), None
@@ -513,7 +515,7 @@ def main():
     # calibrated against the kernel's known tile loads); null if not profiled.
     kernel = ("k_passB3e_blk" if (euler and is3d) else ("k_sweep_quad_euler" if inf.get("image_quads" if image_only else "quads", 0) > 0 and os.environ.get("IBH_QUAD", "1") != "0"
                else "k_sweep_euler") if (fused_e or (image_only and euler)) else "k_passB_euler_blk" if euler else
-              "k_passB3_adv_blk" if is3d else
+              "k_sweep3_adv" if fused3 else "k_passB3_adv_blk" if is3d else
               "k_sweep_quad" if ((fused and inf.get("quads", 0) > 0) or
                                  (image_only and not euler and inf.get("image_quads", 0) > 0)) else
               "k_sweep_adv" if (fused or mixed or (image_only and not euler)) else "k_passB_adv<2,false>")
@@ -531,7 +533,10 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                 "kernel_us": round(tB * 1e6, 3), "passA_us": None if tA is None else round(tA * 1e6, 3),
-                "frac_priced_on": "pass A + pass B" if tA is not None else "the one kernel of the sweep",
+                "frac_priced_on": ("pass A + pass B" if tA is not None else
+                                   "the whole sweep: single kernel over %d blocks + two-kernel form over %d" %
+                                   (inf["fusable_blocks"], inf["full_blocks"] - inf["fusable_blocks"])
+                                   if fused3 and inf["fusable_blocks"] < inf["full_blocks"] else "the one kernel of the sweep"),
                 "alg_bytes_per_cell": b_alg, "cells_per_launch": cells_launch,
                 "sweep_frac": round(b_alg * cells_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
     if pmc_extra:

@@ -26,7 +26,7 @@ inline int coord(int pos, int d) { return (pos / STR[d]) % 8; }
 
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
-                         std::vector<int32_t>& htab, std::vector<int32_t>& ftab) {
+                         std::vector<int32_t>& htab, std::vector<int32_t>& ftab, Sweep3Host* sw) {
     const int32_t nc = v.nc;
     const float* hh[3] = {v.spacing, v.spacing + nc, v.spacing + 2 * (size_t)nc};
     auto gid = [&](int32_t c) { return (int64_t)v.domain[c] - v.index_base; };
@@ -248,6 +248,77 @@ void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks,
                 else cell = b.base + pos3(d, low ? 0 : 7, t1, t2);
                 htab[bi * 384 + s * 64 + t] = cell;
             }
+        }
+    }
+    // ---- single-kernel sweep (blk3::sweep_adv): the workgroup of a block also computes slope + sensor of its halo
+    // cells, so it needs the cell one step deeper behind every halo cell (same neighbour block: index arithmetic) and
+    // the lateral neighbours of the halo cells: other halo cells of the same side, except along the rim of the side,
+    // where they lie across a side of the NEIGHBOUR block -> rim table rtab[blk][side][64]: entry r*n + i = the cell
+    // beyond rim r (tangential dim a low / high, dim b low / high) at position i along it, n = 8 (SAME / COARSE) or
+    // 16 (FINE: the rims of the 16 x 16 patch of fine halo cells); >= 0: a cell (the halo cell itself at the domain
+    // boundary), < 0: -(k + 1) = row k of r4tab, the four finer cells beyond.  The sweep is used when EVERY block
+    // qualifies (sides SAME / COARSE / FINE / MIRROR towards verified full blocks, rim neighbours 1 or 4 cells).
+    if (sw) {
+        std::unordered_map<int32_t, int32_t> base2bi;
+        for (size_t bi = 0; bi < blocks.size(); ++bi) base2bi[blocks[bi].base] = (int32_t)bi;
+        bool all = irr.empty() && !blocks.empty();
+        sw->rtab.assign(blocks.size() * 384, 0);
+        for (size_t bi = 0; bi < blocks.size() && all; ++bi) {
+            const BlockDesc3& b = blocks[bi];
+            int32_t* row = sw->rtab.data() + bi * 384;
+            for (int s = 0; s < 6 && all; ++s) {
+                const int ty = b.type[s];
+                const int d = s / 2;
+                int a, bb2;
+                tang(d, a, bb2);
+                for (int r = 0; r < 64; ++r) row[s * 64 + r] = b.base;
+                if (ty == SIDE_MIRROR) continue;
+                if (ty != SIDE_SAME && ty != SIDE_COARSE && ty != SIDE_FINE) { all = false; break; }
+                if (ty != SIDE_FINE && !base2bi.count(b.nb[s])) { all = false; break; }
+                if (ty == SIDE_FINE)
+                    for (int32_t fb : fine_nb[((int64_t)b.base << 3) | s])
+                        if (!base2bi.count(fb)) all = false;
+                if (!all) break;
+                const int n = ty == SIDE_FINE ? 16 : 8;
+                // halo cell at position (f1, f2) of the side's plane
+                auto halo = [&](int f1, int f2) -> int32_t {
+                    if (ty != SIDE_FINE) return htab[bi * 384 + s * 64 + f1 + 8 * f2];
+                    const int t = (f1 >> 1) + 8 * (f2 >> 1), k = (f1 & 1) + 2 * (f2 & 1);
+                    return k == 0 ? htab[bi * 384 + s * 64 + t]
+                                  : ftab[((size_t)b.fine * 6 + s) * 64 * 3 + t * 3 + (k - 1)];
+                };
+                for (int r = 0; r < 4 && all; ++r) {
+                    const int dim = r < 2 ? a : bb2;
+                    const bool lo = (r & 1) == 0;
+                    const std::vector<int32_t>& off = lo ? v.loff[dim] : v.roff[dim];
+                    const std::vector<int32_t>& idx = lo ? v.lidx[dim] : v.ridx[dim];
+                    for (int i = 0; i < n && all; ++i) {
+                        const int e = lo ? 0 : n - 1;
+                        const int32_t h = r < 2 ? halo(e, i) : halo(i, e);
+                        if (ty == SIDE_FINE && !in_full[h]) { all = false; break; }
+                        const int cnt = off[h + 1] - off[h];
+                        if (cnt != 1 && cnt != 4) { all = false; break; }
+                        int32_t o4[4];
+                        for (int k = 0; k < cnt; ++k) {
+                            const int32_t f = idx[off[h] + k];
+                            const int32_t me = lo ? v.neighbors[dim][f] : v.owners[dim][f];
+                            if (me != h) all = false;
+                            o4[k] = lo ? v.owners[dim][f] : v.neighbors[dim][f];
+                        }
+                        if (cnt == 1) {
+                            row[s * 64 + r * n + i] = o4[0];  // o == h: domain boundary, the difference is zero
+                        } else {
+                            row[s * 64 + r * n + i] = -(int32_t)(sw->r4tab.size() / 4 + 1);
+                            sw->r4tab.insert(sw->r4tab.end(), o4, o4 + 4);
+                        }
+                    }
+                }
+            }
+        }
+        sw->all = all;
+        if (!all) {
+            sw->rtab.clear();
+            sw->r4tab.clear();
         }
     }
     info[0] = (int64_t)blocks.size();

@@ -251,8 +251,15 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         int32_t nph[2] = {0, 0};
         std::vector<int32_t> none;
         const bool have_img = n_image > 0 && image_in_domain;
+        Sweep3Host sw;
         ibh_analyze_blocks3(v, blocks, irr, p->info, have_img ? image_in_domain : none.data(), have_img ? n_image : 0,
-                            nph, htab, ftab);
+                            nph, htab, ftab, &sw);
+        p->sweep3 = sw.all ? 1 : 0;
+        p->info[8] = sw.all ? (int64_t)blocks.size() : 0;   // blocks of the single-kernel sweep
+        p->info[9] = sw.all ? 0 : (int64_t)blocks.size();   // blocks whose gradients go through the workspace
+        if (sw.r4tab.empty()) sw.r4tab.assign(4, 0);
+        if ((rc = ibh_upload(&p->rtab3, sw.rtab.data(), sw.rtab.size()))) return rc;
+        if ((rc = ibh_upload(&p->r4tab3, sw.r4tab.data(), sw.r4tab.size()))) return rc;
         if ((rc = ibh_upload(&p->ftab3, ftab.data(), ftab.size()))) return rc;
         p->nA1 = nph[0];
         p->nB1 = nph[1];
@@ -374,6 +381,8 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->blocks3);
     hipFree(p->htab3);
     hipFree(p->ftab3);
+    hipFree(p->rtab3);
+    hipFree(p->r4tab3);
     hipFree(p->irr_cells);
     hipFree(p->irr_rec);
     hipFree(p->G);

@@ -267,6 +267,241 @@ __device__ __forceinline__ void passB_adv(const BlockDesc3* __restrict__ blocks,
 }
 
 // ------------------------------------------------------------------------------------------
+// Single-kernel scalar sweep in 3-D (the closure of test/advection.jl:67-83 on an octree partition): the scheme of
+// blk2::sweep_adv / quad2.  The workgroup of a block computes the undivided slopes and the JST sensor of its own cells
+// AND of its halo cells (slope along the side normal only), so nothing goes through the gradient workspace: 20 B per
+// cell moved instead of 60.
+//   * wavefront s (0..5) owns side s: its lane t holds the halo cell(s) behind boundary cell t -- one (SAME / COARSE /
+//     MIRROR) or the 2 x 2 finer cells of a FINE side ("chunks" k = 0..3) -- computes their slope and sensor, then the
+//     flux of the sub-face(s) and hands the boundary cell their mean (ex).  The cells' own threads compute the three
+//     high faces inside the block only.
+//   * a halo cell needs the block's boundary cells, the cell one step deeper (same neighbour block: index arithmetic)
+//     and its four lateral neighbours: other halo cells of the same side, staged in the side's plane
+//     ((n + 2)^2, n = 8 or 16 halo cells along the side), whose border comes from the rim table (ibh_analyze3.cpp).
+// LDS (floats): fU 896 | fD 512 | tS 3x512 | tC 3x512 | ex 6x64 | FF 3x512 | planes 6 x 18x18 | planeA 6x64
+// ------------------------------------------------------------------------------------------
+#define BLK3_SWEEP_LDS (896 + 512 + 1536 + 1536 + 384 + 1536 + 6 * 324 + 384)
+
+__device__ __forceinline__ float jst_ratio(float g, float a, float rh) {
+    return fmaf(fabsf(g), rh, 1e-7f) * __builtin_amdgcn_rcpf(fmaf(a, rh, 1e-7f));
+}
+
+__device__ __forceinline__ void sweep_adv(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                          const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
+                                          const int32_t* __restrict__ r4tab, int32_t blk, const float* __restrict__ u,
+                                          const float* __restrict__ C, uint32_t ldc, float* __restrict__ ud, float* lds,
+                                          int tid) {
+    const BlockDesc3 bb = blocks[blk];
+    const uint32_t c = (uint32_t)bb.base + tid;
+    float* fU = lds;                  // [tile 512 | halo 384]: halo part for SAME / COARSE / MIRROR sides
+    float* fD = fU + 896;             // [512]
+    float* tS = fD + 512;             // [3][512] undivided slopes of the block's cells
+    float* tC = tS + 1536;            // [3][512]
+    float* ex = tC + 1536;            // [6][64]  mean flux through the sub-face(s) of every boundary cell
+    float* FF = ex + 384;             // [3][512]
+    float* plane = FF + 1536;         // [6][18 x 18]
+    float* planeA = plane + 6 * 324;  // [6][64]  rim neighbours: mean |difference| to the halo cell next to them
+    // ---- this thread's halo slot: side = wavefront index, boundary cell t
+    const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int ty = SIDE_MIRROR;
+    float qs = 0.5f;
+    switch (sw) {  // scalar registers, no dynamic indexing
+        case 0: ty = bb.type[0]; qs = bb.q[0]; break;
+        case 1: ty = bb.type[1]; qs = bb.q[1]; break;
+        case 2: ty = bb.type[2]; qs = bb.q[2]; break;
+        case 3: ty = bb.type[3]; qs = bb.q[3]; break;
+        case 4: ty = bb.type[4]; qs = bb.q[4]; break;
+        case 5: ty = bb.type[5]; qs = bb.q[5]; break;
+        default: break;
+    }
+    const int dnh = sw >> 1;                         // normal dim of the slot's side (3: the two idle wavefronts)
+    const bool low = (sw & 1) == 0, slotw = sw < 6;
+    const bool isC = ty == SIDE_COARSE, isF = ty == SIDE_FINE, mirror = ty == SIDE_MIRROR;
+    const int sd = dnh == 0 ? 1 : dnh == 1 ? 8 : 64, sa = dnh == 0 ? 8 : 1, sb = dnh == 2 ? 8 : 64;
+    const int t = tid & 63, t1 = t & 7, t2 = t >> 3;
+    const int n = isF ? 16 : 8;                      // halo cells along the side
+    const int dd = mirror ? 0 : (low ? -sd : sd);    // deeper cell of a halo cell
+    const float* Cn = C + (size_t)(dnh < 3 ? dnh : 0) * ldc;
+    // ---- loads: own cell; halo chunk(s): value, deeper value, normal velocity; rim cells
+    const float uc = ldg(u, c);
+    float cc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) cc[d] = ldg(C + (size_t)d * ldc, c);
+    float hu[4], hde[4], hc[4];
+    {
+        const uint32_t h0 = halo_cell3(bb, htab, blk, tid);
+        hu[0] = ldg(u, h0);
+        hde[0] = ldg(u, (uint32_t)((int)h0 + dd));
+        hc[0] = ldg(Cn, h0);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            hu[k] = hu[0];
+            hde[k] = hde[0];
+            hc[k] = hc[0];
+        }
+        if (isF) {  // wave-uniform
+            const int32_t* ft = ftab + (((size_t)bb.fine * 6 + sw) * 64 + t) * 3;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const uint32_t hk = (uint32_t)ft[k - 1];
+                hu[k] = ldg(u, hk);
+                hde[k] = ldg(u, (uint32_t)((int)hk + dd));
+                hc[k] = ldg(Cn, hk);
+            }
+        }
+    }
+    float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool rimw = slotw && t < 4 * n;
+    if (rimw) {
+        const int32_t rid = rtab[sw * 64 + t];
+        if (rid >= 0) {
+            rv[0] = rv[1] = rv[2] = rv[3] = ldg(u, (uint32_t)rid);
+        } else {
+            const int32_t* r4 = r4tab + (size_t)(-rid - 1) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv[k] = ldg(u, (uint32_t)r4[k]);
+        }
+    }
+    // ---- stage
+    fU[tid] = uc;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) tC[d * 512 + tid] = cc[d];
+    float* pl = plane + (slotw ? sw : 0) * 324;
+    int radj = 0;  // plane position of the halo cell next to this lane's rim cell
+    if (slotw) {
+        fU[512 + tid] = hu[0];
+        if (isF) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pl[(2 * t1 + (k & 1) + 1) + 18 * (2 * t2 + (k >> 1) + 1)] = hu[k];
+        } else {
+            pl[(t1 + 1) + 18 * (t2 + 1)] = hu[0];
+        }
+        if (rimw) {
+            const int r = isF ? t >> 4 : t >> 3, i = isF ? t & 15 : t & 7;
+            const int p1 = r == 0 ? 0 : r == 1 ? n + 1 : i + 1, p2 = r == 2 ? 0 : r == 3 ? n + 1 : i + 1;
+            const int a1 = r == 0 ? 1 : r == 1 ? n : i + 1, a2 = r == 2 ? 1 : r == 3 ? n : i + 1;
+            pl[p1 + 18 * p2] = 0.25f * ((rv[0] + rv[1]) + (rv[2] + rv[3]));
+            radj = a1 + 18 * a2;
+        }
+    }
+    const Lane3 L = lane_info(bb, tid);
+    __syncthreads();
+    if (rimw) {
+        const float ha = pl[radj];
+        planeA[sw * 64 + t] = 0.25f * ((fabsf(rv[0] - ha) + fabsf(rv[1] - ha)) + (fabsf(rv[2] - ha) + fabsf(rv[3] - ha)));
+    }
+    // ---- own cells: undivided slopes S = fr - fl and the sensor
+    float S[3], D = 1e-7f;
+    const int tt[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float vm[2], am[2];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int s = 2 * d + side;
+            const float v0 = fU[L.nidx[s]];
+            vm[side] = v0;
+            am[side] = fabsf(v0 - uc);
+            if (bb.type[s] == SIDE_FINE) {  // workgroup-uniform: four finer cells behind every boundary cell
+                if (L.edge[s]) {
+                    const float* ps = plane + s * 324 + (2 * (tt[d] & 7) + 1) + 18 * (2 * (tt[d] >> 3) + 1);
+                    const float w0 = ps[0], w1 = ps[1], w2 = ps[18], w3 = ps[19];
+                    vm[side] = 0.25f * ((w0 + w1) + (w2 + w3));
+                    am[side] = 0.25f * ((fabsf(w0 - uc) + fabsf(w1 - uc)) + (fabsf(w2 - uc) + fabsf(w3 - uc)));
+                }
+            }
+        }
+        const float dr = vm[1] - uc, dl = uc - vm[0];
+        S[d] = L.q[2 * d + 1] * dr + L.q[2 * d] * dl;
+        D = fmaxf(D, jst_ratio(dr - dl, am[1] + am[0], bb.rh[d]));
+        tS[d * 512 + tid] = S[d];
+    }
+    fD[tid] = D;
+    // ---- halo cells of this thread's slot: slope along the normal, sensor
+    float Sh[4], Dh[4];
+    const int nrm = (low ? 0 : 7) * sd;
+    const int pos = nrm + t1 * sa + t2 * sb;  // the slot's boundary cell
+    if (slotw) {
+        blk2::wave_lds_sync();  // planeA of this side (written by this wavefront)
+        // the block's cells behind the halo cell: one, or the 2 x 2 group in front of a coarse cell
+        const int cm = isC ? 1 : 0;
+        const int pa = t1 & ~cm, pb = t1 | cm, qa = t2 & ~cm, qb = t2 | cm;
+        const float m0 = fU[nrm + pa * sa + qa * sb], m1 = fU[nrm + pb * sa + qa * sb];
+        const float m2 = fU[nrm + pa * sa + qb * sb], m3 = fU[nrm + pb * sa + qb * sb];
+        const float irt = isC ? 0.5f : isF ? 2.0f : 1.0f;  // h / h_halo
+        float rn, ra, rb;  // reciprocal widths of the halo cell along the normal and the two tangential dims
+        if (dnh == 0) { rn = bb.rh[0]; ra = bb.rh[1]; rb = bb.rh[2]; }
+        else if (dnh == 1) { rn = bb.rh[1]; ra = bb.rh[0]; rb = bb.rh[2]; }
+        else { rn = bb.rh[2]; ra = bb.rh[0]; rb = bb.rh[1]; }
+        rn *= irt;
+        ra *= irt;
+        rb *= irt;
+        const float* pA = planeA + sw * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            Sh[k] = 0.0f;
+            Dh[k] = 1e-7f;
+            if (k == 0 || isF) {  // wave-uniform
+                const float h = hu[k];
+                const float din = 0.25f * ((m0 + m1) + (m2 + m3)) - h;
+                const float ain = 0.25f * ((fabsf(m0 - h) + fabsf(m1 - h)) + (fabsf(m2 - h) + fabsf(m3 - h)));
+                const float dde = hde[k] - h;
+                const float x = (1.0f - qs) * din - 0.5f * dde;
+                Sh[k] = low ? x : -x;
+                // position in the plane; a coarse cell spans 2 x 2 slots
+                const int f1 = isF ? 2 * t1 + (k & 1) : t1, f2 = isF ? 2 * t2 + (k >> 1) : t2;
+                const int fa = f1 & ~cm, fb = f1 | cm, ga = f2 & ~cm, gb = f2 | cm;
+                const float ea0 = pl[fa + 18 * (f2 + 1)] - h, ea1 = pl[fb + 2 + 18 * (f2 + 1)] - h;
+                const float eb0 = pl[(f1 + 1) + 18 * ga] - h, eb1 = pl[(f1 + 1) + 18 * (gb + 2)] - h;
+                const float aa0 = fa == 0 ? pA[f2] : fabsf(ea0), aa1 = fb == n - 1 ? pA[n + f2] : fabsf(ea1);
+                const float ab0 = ga == 0 ? pA[2 * n + f1] : fabsf(eb0), ab1 = gb == n - 1 ? pA[3 * n + f1] : fabsf(eb1);
+                float dh = jst_ratio(din + dde, ain + fabsf(dde), rn);
+                dh = fmaxf(dh, jst_ratio(ea0 + ea1, aa0 + aa1, ra));
+                dh = fmaxf(dh, jst_ratio(eb0 + eb1, ab0 + ab1, rb));
+                Dh[k] = fmaxf(dh, 1e-7f);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the +x, +y, +z face of every cell inside the block (block faces: from ex below)
+    float F[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int ni = L.edge[2 * d + 1] ? tid : L.nidx[2 * d + 1];
+        F[d] = flux_w(uc, fU[ni], S[d], tS[d * 512 + ni], D, fD[ni], cc[d], tC[d * 512 + ni], 0.5f);
+    }
+    // ---- block faces: the sub-face(s) of this thread's slot, halo cell <-> boundary cell
+    if (slotw) {
+        const float ub = fU[pos], Sb = tS[dnh * 512 + pos], Db = fD[pos], Cb = tC[dnh * 512 + pos];
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k == 0 || isF) {  // wave-uniform
+                const float sh = mirror ? Sb : Sh[k], dh = mirror ? Db : Dh[k];
+                const float ua = low ? hu[k] : ub, ubb = low ? ub : hu[k];
+                const float Sa = low ? sh : Sb, Sbb = low ? Sb : sh;
+                const float Da = low ? dh : Db, Dbb = low ? Db : dh;
+                const float Ca = low ? hc[k] : Cb, Cbb = low ? Cb : hc[k];
+                acc += flux_w(ua, ubb, Sa, Sbb, Da, Dbb, Ca, Cbb, low ? 1.0f - qs : qs);
+            }
+        }
+        ex[tid] = isF ? 0.25f * acc : acc;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) FF[d * 512 + tid] = F[d];
+    __syncthreads();
+    const int offm[3] = {1, 8, 64};
+    float res = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float Fl = L.edge[2 * d] ? ex[2 * d * 64 + tt[d]] : FF[d * 512 + tid - offm[d]];
+        const float Fh = L.edge[2 * d + 1] ? ex[(2 * d + 1) * 64 + tt[d]] : F[d];
+        res = res - (Fh - Fl) * bb.rh[d];
+    }
+    stg(ud, c, res);
+}
+
+// ------------------------------------------------------------------------------------------
 // Euler sweep in 3-D (P = [p T u v w], cfd.jl:106-151 / :459-508), the block form of the R2 residual.
 // pass A: gradients of the NV primitives along x, y, z + JST sensor of the pressure.
 //   G layout as the face-list kernels: grad of var v along dim d at G[(d*NV + v)*nc + c], sensor at G[3*NV*nc + c].

@@ -114,6 +114,9 @@ struct ibh_part {
     BlockDesc3* blocks3 = nullptr;  // 3-D block table (nd == 3)
     int32_t* htab3 = nullptr;    // [nblk][384]
     int32_t* ftab3 = nullptr;    // [nfine][6][64][3] sub-faces 1..3 of FINE sides
+    // 3-D single-kernel sweep: used when every block qualifies (sweep3 != 0)
+    int32_t *rtab3 = nullptr, *r4tab3 = nullptr;
+    int32_t sweep3 = 0;
     int32_t n_irr = 0;           // cells handled by the general kernels when the fast path is on
     int32_t* irr_cells = nullptr;
     // Flattened stencils of the face-list cells (built when every such cell has <= 4 faces per direction):
@@ -182,9 +185,15 @@ void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<i
                       const std::vector<int32_t>& etab, const std::vector<char>& cand, int32_t nB1, QuadSet2& out,
                       int32_t nc);
 
+// tables of the 3-D single-kernel sweep (blk3::sweep_adv), see ibh_analyze3.cpp
+struct Sweep3Host {
+    bool all = false;            // every block qualifies: the sweep is one launch, nothing through the workspace
+    std::vector<int32_t> rtab;   // [nblk][6][64] rim table
+    std::vector<int32_t> r4tab;  // [n][4] rim neighbours that are four finer cells
+};
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
-                         std::vector<int32_t>& htab, std::vector<int32_t>& ftab);
+                         std::vector<int32_t>& htab, std::vector<int32_t>& ftab, Sweep3Host* sw);
 
 static inline int ibh_grid(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;

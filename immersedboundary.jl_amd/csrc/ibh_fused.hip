@@ -717,11 +717,12 @@ __global__ __launch_bounds__(512) void k_passB3_adv_blk(PartView p, const float*
                                                         const int32_t* __restrict__ htab,
                                                         const int32_t* __restrict__ ftab, int32_t nblk,
                                                         const int32_t* __restrict__ cells, int32_t ncells,
-                                                        FlatRec flat) {
+                                                        FlatRec flat, const int32_t* __restrict__ blist) {
     __shared__ float lds[BLK3_PASSB_LDS];
     const int32_t gI = (ncells + 511) / 512;
     if ((int32_t)blockIdx.x >= gI) {
-        const int32_t blk = xcd_remap(blockIdx.x - gI, nblk);
+        int32_t blk = xcd_remap(blockIdx.x - gI, nblk);
+        if (blist) blk = blist[blk];
         blk3::passB_adv(blocks, htab, ftab, blk, (uint32_t)p.nc, u, C, (uint32_t)ldc, G, ud, lds, threadIdx.x);
         return;
     }
@@ -732,19 +733,33 @@ __global__ __launch_bounds__(512) void k_passB3_adv_blk(PartView p, const float*
     }
 }
 
+// 3-D single-kernel scalar sweep (blk3::sweep_adv): one 512-thread workgroup per block, every block of the partition
+__global__ __launch_bounds__(512) void k_sweep3_adv(const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
+                                                    float* __restrict__ ud, const BlockDesc3* __restrict__ blocks,
+                                                    const int32_t* __restrict__ htab, const int32_t* __restrict__ ftab,
+                                                    const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab,
+                                                    int32_t n) {
+    __shared__ float lds[BLK3_SWEEP_LDS];
+    const int32_t blk = xcd_remap(blockIdx.x, n);
+    blk3::sweep_adv(blocks, htab, ftab, rtab + (size_t)blk * 384, r4tab, blk, u, C, ldc, ud, lds, threadIdx.x);
+}
+
 // wave-per-block form of the 3-D scalar pass A (blk3::passA_wave): 4 blocks per 256-thread workgroup
 __global__ __launch_bounds__(256) void k_passA3_wave(PartView p, const float* __restrict__ u, float* __restrict__ G,
                                                      const BlockDesc3* __restrict__ blocks,
                                                      const int32_t* __restrict__ htab,
                                                      const int32_t* __restrict__ ftab, int32_t nblk, int32_t nwg,
-                                                     const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat) {
+                                                     const int32_t* __restrict__ cells, int32_t ncells, FlatRec flat,
+                                                     const int32_t* __restrict__ blist) {
     __shared__ float lds[4 * BLK3W_PASSA_LDS];
     const int32_t gI = (ncells + 255) / 256;
     if ((int32_t)blockIdx.x >= gI) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-        const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x - gI, nwg) * 4 + wave);
-        if (blk < nblk)
+        const int32_t pos = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x - gI, nwg) * 4 + wave);
+        if (pos < nblk) {
+            const int32_t blk = blist ? __builtin_amdgcn_readfirstlane(blist[pos]) : pos;
             blk3::passA_wave(blocks, htab, ftab, blk, (uint32_t)p.nc, u, G, lds + wave * BLK3W_PASSA_LDS, lane);
+        }
         return;
     }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -901,10 +916,18 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     if (p->nc == 0) return 0;
     int rc = 0;
     if (p->nd == 3 && p->bs == 8 && p->blocks3 && p->nblk > 0 && !(flags & (IBH_FORCE_GENERAL | IBH_EXACT))) {
-        if ((rc = ensure_G(p))) return rc;
-        // 3-D block path: block kernels over the requested block range + face-list kernels over the rest
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
         IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
+        if (p->sweep3 && !ph1 && !ph2 &&
+            !(flags & (IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY | IBH_IMAGE_ONLY))) {
+            // every block qualifies for the single-kernel sweep: one launch, nothing through the workspace
+            hipLaunchKernelGGL(k_sweep3_adv, dim3(p->nblk), dim3(512), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->blocks3,
+                               p->htab3, p->ftab3, p->rtab3, p->r4tab3, p->nblk);
+            IBH_LAUNCH_CHECK();
+            return 0;
+        }
+        if ((rc = ensure_G(p))) return rc;
+        // 3-D block path: block kernels over the requested block range + face-list kernels over the rest
         const int32_t a0 = ph2 ? p->nA1 : 0, a1 = ph1 ? p->nA1 : p->nblk;
         const int32_t b0 = ph2 ? p->nB1 : 0, b1 = ph1 ? p->nB1 : p->nblk;
         const int32_t nI = ph1 ? 0 : p->n_irr;
@@ -915,13 +938,14 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
             const int32_t nwgA = (a1 - a0 + 3) / 4, gIw = (nI + 255) / 256;
             hipLaunchKernelGGL(k_passA3_wave, dim3(nwgA + gIw), dim3(256), 0, ibh_stream, v, u, p->G, p->blocks3 + a0,
                                p->htab3 + (size_t)a0 * 384, p->ftab3, a1 - a0, nwgA, p->irr_cells, nI,
-                               flat_of(p, p->irr_cells));
+                               flat_of(p, p->irr_cells), (const int32_t*)nullptr);
         } else if (doA && (a1 > a0 || gI))
             hipLaunchKernelGGL(k_passA3_blk, dim3(a1 - a0 + gI), dim3(512), 0, ibh_stream, v, u, p->G, p->blocks3 + a0,
                                p->htab3 + (size_t)a0 * 384, p->ftab3, a1 - a0, p->irr_cells, nI, flat_of(p, p->irr_cells));
         if (doB && (b1 > b0 || gI))
             hipLaunchKernelGGL(k_passB3_adv_blk, dim3(b1 - b0 + gI), dim3(512), 0, ibh_stream, v, u, C, ldc, p->G, ud,
-                               p->blocks3 + b0, p->htab3 + (size_t)b0 * 384, p->ftab3, b1 - b0, p->irr_cells, nI, flat_of(p, p->irr_cells));
+                               p->blocks3 + b0, p->htab3 + (size_t)b0 * 384, p->ftab3, b1 - b0, p->irr_cells, nI,
+                               flat_of(p, p->irr_cells), (const int32_t*)nullptr);
         IBH_LAUNCH_CHECK();
         return 0;
     }

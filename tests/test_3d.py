@@ -178,6 +178,12 @@ def test_3d_block_path(octree8_mesh, nparts):
                 exp -= od.green_gauss(op, (uL + uR) * Cf / f32(2) + np.abs(Cf) * (uL - uR) / f32(2), dim)
             assert rel_inf(gen, exp) <= 1e-5
             assert rel_inf(fast, exp) <= 1e-5
+            # `fast` is the single-kernel sweep (blk3::sweep_adv) on the eligible blocks + the two-kernel form on
+            # the rest; the two-kernel form alone agrees with it
+            assert 0 < info["fusable_blocks"] <= info["full_blocks"]
+            two = ibamd.to_host(ibamd.residual_advection(dpart, ud_, Cd, flags=ibamd.IBH_NO_FUSE))
+            assert rel_inf(two, exp) <= 1e-5
+            assert rel_inf(fast, two) <= 2e-6
         else:
             # overlap phases reproduce the single sweep bit for bit, interior phase reads no skirt cell
             import torch
