@@ -486,6 +486,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 #include "ibh_sweep2d.h"
 #include "ibh_quad2d.h"
 #include "ibh_quad2d_euler.h"
+#include "ibh_strip3d.h"
 #include "ibh_block3d.h"
 
 namespace {
@@ -744,6 +745,24 @@ __global__ __launch_bounds__(512) void k_sweep3_adv(const float* __restrict__ u,
     blk3::sweep_adv(blocks, htab, ftab, rtab + (size_t)blk * 384, r4tab, blk, u, C, ldc, ud, lds, threadIdx.x);
 }
 
+// Strip form of the 3-D scalar sweep (strip3::sweep_strip): one wavefront per block
+#ifndef WPB3S
+#define WPB3S 2
+#endif
+template <int WAVES>
+__global__ __launch_bounds__(64 * WPB3S) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_sweep3_strip(const float* __restrict__ u, const float* __restrict__ C,
+                                                             uint32_t ldc, float* __restrict__ ud,
+                                                             const BlockDesc3* __restrict__ blocks,
+                                                             const int32_t* __restrict__ htab,
+                                                             const int32_t* __restrict__ ftab,
+                                                             const int32_t* __restrict__ rtab,
+                                                             const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg) {
+    __shared__ __attribute__((aligned(16))) float lds[WPB3S * S3_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3S + wave);
+    if (blk < n) strip3::sweep_strip(blocks, htab, ftab, rtab, r4tab, blk, u, C, ldc, ud, lds + wave * S3_LDS, lane);
+}
+
 // wave-per-block form of the 3-D scalar pass A (blk3::passA_wave): 4 blocks per 256-thread workgroup
 __global__ __launch_bounds__(256) void k_passA3_wave(PartView p, const float* __restrict__ u, float* __restrict__ G,
                                                      const BlockDesc3* __restrict__ blocks,
@@ -921,6 +940,16 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         if (p->sweep3 && !ph1 && !ph2 &&
             !(flags & (IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY | IBH_IMAGE_ONLY))) {
             // every block qualifies for the single-kernel sweep: one launch, nothing through the workspace
+            if (ibh_quad_variant != 512) {
+                const int32_t nwg = (p->nblk + WPB3S - 1) / WPB3S;
+#define S3_LAUNCH(W)                                                                                                  \
+    hipLaunchKernelGGL(k_sweep3_strip<W>, dim3(nwg), dim3(64 * WPB3S), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->blocks3, \
+                       p->htab3, p->ftab3, p->rtab3, p->r4tab3, p->nblk, nwg)
+                if (ibh_quad_variant == 515) S3_LAUNCH(2);
+                else if (ibh_quad_variant == 514) S3_LAUNCH(4);
+                else S3_LAUNCH(3);
+#undef S3_LAUNCH
+            } else  // A/B: thread-per-cell form
             hipLaunchKernelGGL(k_sweep3_adv, dim3(p->nblk), dim3(512), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->blocks3,
                                p->htab3, p->ftab3, p->rtab3, p->r4tab3, p->nblk);
             IBH_LAUNCH_CHECK();
