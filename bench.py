@@ -493,7 +493,7 @@ def main():
              and inf["fusable_blocks"] >= 12000 and 4 * inf["fusable_blocks"] >= inf["full_blocks"])
     fused_e = euler and not is3d and flags == 0 and inf["irregular_cells"] == 0 and inf["fusable_blocks"] == inf["full_blocks"] > 0
     # 3-D scalar sweep: single kernel over the eligible blocks (+ the two-kernel form over the rest, same sweep)
-    fused3 = (is3d and not euler and flags == 0 and inf["irregular_cells"] == 0 and inf["fusable_blocks"] > 0)
+    fused3 = (is3d and flags == 0 and inf["irregular_cells"] == 0 and inf["fusable_blocks"] == inf["full_blocks"] > 0)
     if image_only:
         tB, tA = time_pass(0, reps), None
         cells_launch = n_image
@@ -513,9 +513,9 @@ def main():
     # HBM-side traffic of one launch of the dominant kernel from the committed PMC passes of this build (separate
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
     # calibrated against the kernel's known tile loads); null if not profiled.
-    kernel = ("k_passB3e_blk" if (euler and is3d) else ("k_sweep_quad_euler" if inf.get("image_quads" if image_only else "quads", 0) > 0 and os.environ.get("IBH_QUAD", "1") != "0"
+    kernel = ("k_sweep3_euler" if (euler and fused3) else "k_passB3e_blk" if (euler and is3d) else ("k_sweep_quad_euler" if inf.get("image_quads" if image_only else "quads", 0) > 0 and os.environ.get("IBH_QUAD", "1") != "0"
                else "k_sweep_euler") if (fused_e or (image_only and euler)) else "k_passB_euler_blk" if euler else
-              "k_sweep3_adv" if fused3 else "k_passB3_adv_blk" if is3d else
+              "k_sweep3_strip" if fused3 else "k_passB3_adv_blk" if is3d else
               "k_sweep_quad" if ((fused and inf.get("quads", 0) > 0) or
                                  (image_only and not euler and inf.get("image_quads", 0) > 0)) else
               "k_sweep_adv" if (fused or mixed or (image_only and not euler)) else "k_passB_adv<2,false>")
@@ -581,7 +581,7 @@ def main():
                    "cells_total": ncells, "cells_per_rank_with_skirt": int(dpart.nc),
                    "path": "face-list" if args.general else ("block-fast-path-literal" if args.exact else
                             "block-fast-path, single kernel on the image blocks" if image_only else
-                            "block-fast-path, single kernel" if (fused or fused_e) else
+                            "block-fast-path, single kernel" if (fused or fused_e or fused3) else
                             "block-fast-path, single kernel on %d of %d blocks" % (inf["fusable_blocks"], inf["full_blocks"])
                             if mixed else "block-fast-path, two kernels"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",

@@ -794,6 +794,313 @@ __device__ __forceinline__ void passB_euler(const BlockDesc3* __restrict__ block
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Single-kernel Euler sweep in 3-D (P = [p T u v w]; JST sensor of the pressure, MUSCL(high_order), HLL, Green-Gauss):
+// the scheme of blk3::sweep_adv with five variables.  Nothing goes through the gradient workspace (40 B per cell moved
+// instead of 40 + 128).  Wavefront s (0..5) owns side s: halo values (all five primitives), deeper values, the slope of
+// every primitive along the side normal and the pressure sensor of its halo cell(s) stay in its registers; only the
+// pressure needs the side's plane (lateral neighbours of the sensor).  The slopes of the block's own cells are staged
+// one direction at a time.
+// LDS (floats): fP 5x896 | fD 512 | tS 5x512 | ex 5x384 | FF 5x512 | planes 6 x 18x18 | planeA 6x64
+// ------------------------------------------------------------------------------------------
+#define BLK3_SWEEP_EULER_LDS (5 * 896 + 512 + 2560 + 1920 + 2560 + 6 * 324 + 384)
+
+// MUSCL states from undivided slopes, then HLL (blk2::euler_flux_w with five primitives)
+__device__ __forceinline__ void euler_flux_w3(const float* Pa, const float* Pb, const float* Sa, const float* Sb, float Da,
+                                              float Db, float wa, int dn, const Gas3& gas, float* F) {
+    float PL[5], PR[5];
+    const float Df = fmaxf(fmaxf(Da, Db), 1e-7f);
+    const float wb = 1.0f - wa;
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        const float d = Pb[v] - Pa[v];
+        const float gu = Sa[v] - d * wa;
+        const float Du = Sb[v] - d * wb;
+        const float s = __builtin_amdgcn_fmed3f(Du, gu, 0.0f);
+        const float t16 = (Sa[v] - Sb[v]) * 0.0625f;
+        const float uf = (Pa[v] + wa * d) + t16;
+        PL[v] = uf + Df * ((s - wa * d) - t16);
+        PR[v] = uf + Df * ((wb * d - s) - t16);
+    }
+    float QL[5], FL[5], QR[5], FR[5], uL, aL, uR, aR;
+    euler_side3(PL, dn, gas, QL, FL, uL, aL);
+    euler_side3(PR, dn, gas, QR, FR, uR, aR);
+    const float SR = fminf(uR - aR, 0.0f);
+    const float SL = fmaxf(uL + aL, 0.0f);
+    const float rs = __builtin_amdgcn_rcpf(SL - SR);
+#pragma unroll
+    for (int v = 0; v < 5; ++v) F[v] = (SL * FL[v] - SR * FR[v] + SR * SL * (QR[v] - QL[v])) * rs;
+}
+
+__device__ __forceinline__ void sweep_euler(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                            const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
+                                            const int32_t* __restrict__ r4tab, int32_t blk, const float* __restrict__ P,
+                                            uint32_t ldp, float* __restrict__ Rr, uint32_t ldr, Gas3 gas, float* lds,
+                                            int tid) {
+    const BlockDesc3 bb = blocks[blk];
+    const uint32_t c = (uint32_t)bb.base + tid;
+    float* fP = lds;                  // [5][tile 512 | halo 384]: halo part = mean value behind every boundary cell
+    float* fD = fP + 5 * 896;         // [512]
+    float* tS = fD + 512;             // [5][512] undivided slopes of the block's cells along the current direction
+    float* ex = tS + 2560;            // [5][6][64] mean flux through the sub-face(s) of every boundary cell
+    float* FF = ex + 1920;            // [5][512]
+    float* plane = FF + 2560;         // [6][18 x 18] pressure
+    float* planeA = plane + 6 * 324;  // [6][64]
+    // ---- this thread's halo slot: side = wavefront index, boundary cell t
+    const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int ty = SIDE_MIRROR;
+    float qs = 0.5f;
+    switch (sw) {  // scalar registers, no dynamic indexing
+        case 0: ty = bb.type[0]; qs = bb.q[0]; break;
+        case 1: ty = bb.type[1]; qs = bb.q[1]; break;
+        case 2: ty = bb.type[2]; qs = bb.q[2]; break;
+        case 3: ty = bb.type[3]; qs = bb.q[3]; break;
+        case 4: ty = bb.type[4]; qs = bb.q[4]; break;
+        case 5: ty = bb.type[5]; qs = bb.q[5]; break;
+        default: break;
+    }
+    const int dnh = sw >> 1;                         // normal dim of the slot's side (3: the two idle wavefronts)
+    const bool low = (sw & 1) == 0, slotw = sw < 6;
+    const bool isC = ty == SIDE_COARSE, isF = ty == SIDE_FINE, mirror = ty == SIDE_MIRROR;
+    const int sd = dnh == 0 ? 1 : dnh == 1 ? 8 : 64, sa = dnh == 0 ? 8 : 1, sb = dnh == 2 ? 8 : 64;
+    const int t = tid & 63, t1 = t & 7, t2 = t >> 3;
+    const int n = isF ? 16 : 8;
+    const int dd = mirror ? 0 : (low ? -sd : sd);
+    // ---- loads: own cell; halo chunk(s): the five primitives and their values one step deeper; rim cells (pressure)
+    float Pc[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) Pc[v] = ldg(P + (size_t)v * ldp, c);
+    // chunk 0 of the slot stays in registers; the other three finer cells of a FINE side are fetched where needed
+    float hu[5], hde[5], hmean[5];
+    const int32_t* ft = ftab + (((size_t)(isF ? bb.fine : 0) * 6 + (slotw ? sw : 0)) * 64 + t) * 3;
+    float pf[4];  // pressure of the chunks (plane)
+    {
+        const uint32_t h0 = halo_cell3(bb, htab, blk, tid);
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            hu[v] = ldg(P + (size_t)v * ldp, h0);
+            hde[v] = ldg(P + (size_t)v * ldp, (uint32_t)((int)h0 + dd));
+            hmean[v] = hu[v];
+        }
+        pf[0] = pf[1] = pf[2] = pf[3] = hu[0];
+        if (isF) {  // wave-uniform
+            float acc[5];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) acc[v] = hu[v];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const uint32_t hk = (uint32_t)ft[k - 1];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    const float w = ldg(P + (size_t)v * ldp, hk);
+                    acc[v] += w;
+                    if (v == 0) pf[k] = w;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 5; ++v) hmean[v] = 0.25f * acc[v];
+        }
+    }
+    float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool rimw = slotw && t < 4 * n;
+    if (rimw) {
+        const int32_t rid = rtab[sw * 64 + t];
+        if (rid >= 0) {
+            rv[0] = rv[1] = rv[2] = rv[3] = ldg(P, (uint32_t)rid);
+        } else {
+            const int32_t* r4 = r4tab + (size_t)(-rid - 1) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv[k] = ldg(P, (uint32_t)r4[k]);
+        }
+    }
+    // ---- stage
+#pragma unroll
+    for (int v = 0; v < 5; ++v) fP[v * 896 + tid] = Pc[v];
+    float* pl = plane + (slotw ? sw : 0) * 324;
+    int radj = 0;
+    if (slotw) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) fP[v * 896 + 512 + tid] = hmean[v];
+        if (isF) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pl[(2 * t1 + (k & 1) + 1) + 18 * (2 * t2 + (k >> 1) + 1)] = pf[k];
+        } else {
+            pl[(t1 + 1) + 18 * (t2 + 1)] = hu[0];
+        }
+        if (rimw) {
+            const int r = isF ? t >> 4 : t >> 3, i = isF ? t & 15 : t & 7;
+            const int p1 = r == 0 ? 0 : r == 1 ? n + 1 : i + 1, p2 = r == 2 ? 0 : r == 3 ? n + 1 : i + 1;
+            const int a1 = r == 0 ? 1 : r == 1 ? n : i + 1, a2 = r == 2 ? 1 : r == 3 ? n : i + 1;
+            pl[p1 + 18 * p2] = 0.25f * ((rv[0] + rv[1]) + (rv[2] + rv[3]));
+            radj = a1 + 18 * a2;
+        }
+    }
+    const Lane3 L = lane_info(bb, tid);
+    __syncthreads();
+    if (rimw) {
+        const float ha = pl[radj];
+        planeA[sw * 64 + t] = 0.25f * ((fabsf(rv[0] - ha) + fabsf(rv[1] - ha)) + (fabsf(rv[2] - ha) + fabsf(rv[3] - ha)));
+    }
+    const int tt[3] = {L.j + 8 * L.k, L.i + 8 * L.k, L.i + 8 * L.j};
+    // ---- own cells: pressure sensor
+    float D = 1e-7f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float vm[2], am[2];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int s = 2 * d + side;
+            const float v0 = fP[L.nidx[s]];
+            vm[side] = v0;
+            am[side] = fabsf(v0 - Pc[0]);
+            if (bb.type[s] == SIDE_FINE) {  // workgroup-uniform
+                if (L.edge[s]) {
+                    const float* ps = plane + s * 324 + (2 * (tt[d] & 7) + 1) + 18 * (2 * (tt[d] >> 3) + 1);
+                    const float w0 = ps[0], w1 = ps[1], w2 = ps[18], w3 = ps[19];
+                    am[side] = 0.25f * ((fabsf(w0 - Pc[0]) + fabsf(w1 - Pc[0])) + (fabsf(w2 - Pc[0]) + fabsf(w3 - Pc[0])));
+                }
+            }
+        }
+        const float dr = vm[1] - Pc[0], dl = Pc[0] - vm[0];
+        D = fmaxf(D, jst_ratio(dr - dl, am[1] + am[0], bb.rh[d]));
+    }
+    fD[tid] = D;
+    // ---- halo cell (chunk k) of this thread's slot: slopes of the five primitives along the normal, pressure sensor
+    const int nrm = (low ? 0 : 7) * sd;
+    const int pos = nrm + t1 * sa + t2 * sb;  // the slot's boundary cell
+    const int cm = isC ? 1 : 0;
+    const float irt = isC ? 0.5f : isF ? 2.0f : 1.0f;  // h / h_halo
+    float rn, ra, rb;  // reciprocal widths of the halo cell along the normal and the two tangential dims
+    if (dnh == 0) { rn = bb.rh[0]; ra = bb.rh[1]; rb = bb.rh[2]; }
+    else if (dnh == 1) { rn = bb.rh[1]; ra = bb.rh[0]; rb = bb.rh[2]; }
+    else { rn = bb.rh[2]; ra = bb.rh[0]; rb = bb.rh[1]; }
+    rn *= irt;
+    ra *= irt;
+    rb *= irt;
+    // mean[v]: the block's cells in front of the halo cell (one, or the 2 x 2 group of a coarse cell); m4: their pressures
+    auto halo_eval = [&](int k, const float* h, const float* hd, const float* mean, const float* m4, float* Sh, float& Dh) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const float x = (1.0f - qs) * (mean[v] - h[v]) - 0.5f * (hd[v] - h[v]);
+            Sh[v] = low ? x : -x;
+        }
+        const float* pA = planeA + sw * 64;
+        const float p = h[0];
+        const float din = mean[0] - p;
+        const float ain = 0.25f * ((fabsf(m4[0] - p) + fabsf(m4[1] - p)) + (fabsf(m4[2] - p) + fabsf(m4[3] - p)));
+        const float dde = hd[0] - p;
+        const int f1 = isF ? 2 * t1 + (k & 1) : t1, f2 = isF ? 2 * t2 + (k >> 1) : t2;
+        const int fa = f1 & ~cm, fb = f1 | cm, ga = f2 & ~cm, gb = f2 | cm;
+        const float ea0 = pl[fa + 18 * (f2 + 1)] - p, ea1 = pl[fb + 2 + 18 * (f2 + 1)] - p;
+        const float eb0 = pl[(f1 + 1) + 18 * ga] - p, eb1 = pl[(f1 + 1) + 18 * (gb + 2)] - p;
+        const float aa0 = fa == 0 ? pA[f2] : fabsf(ea0), aa1 = fb == n - 1 ? pA[n + f2] : fabsf(ea1);
+        const float ab0 = ga == 0 ? pA[2 * n + f1] : fabsf(eb0), ab1 = gb == n - 1 ? pA[3 * n + f1] : fabsf(eb1);
+        float dh = jst_ratio(din + dde, ain + fabsf(dde), rn);
+        dh = fmaxf(dh, jst_ratio(ea0 + ea1, aa0 + aa1, ra));
+        dh = fmaxf(dh, jst_ratio(eb0 + eb1, ab0 + ab1, rb));
+        Dh = fmaxf(dh, 1e-7f);
+    };
+    float Sh0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, Dh0 = 1e-7f;
+    if (slotw) {
+        blk2::wave_lds_sync();  // planeA of this side (written by this wavefront)
+        const int pa = t1 & ~cm, pb = t1 | cm, qa = t2 & ~cm, qb = t2 | cm;
+        const int g0 = nrm + pa * sa + qa * sb, g1 = nrm + pb * sa + qa * sb, g2 = nrm + pa * sa + qb * sb,
+                  g3 = nrm + pb * sa + qb * sb;
+        float mean[5], m4[4];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const float* f = fP + v * 896;
+            const float m0 = f[g0], m1 = f[g1], m2 = f[g2], m3 = f[g3];
+            mean[v] = 0.25f * ((m0 + m1) + (m2 + m3));
+            if (v == 0) { m4[0] = m0; m4[1] = m1; m4[2] = m2; m4[3] = m3; }
+        }
+        halo_eval(0, hu, hde, mean, m4, Sh0, Dh0);
+    }
+    // ---- one direction after the other: own slopes -> LDS, inner faces by the cells, block faces by the two side waves
+    float res[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int offm[3] = {1, 8, 64};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float S[5];
+        {
+            const int n0 = L.nidx[2 * d], n1 = L.nidx[2 * d + 1];
+            const float q0 = L.q[2 * d], q1 = L.q[2 * d + 1];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const float* f = fP + v * 896;
+                S[v] = q1 * (f[n1] - Pc[v]) + q0 * (Pc[v] - f[n0]);
+                tS[v * 512 + tid] = S[v];
+            }
+        }
+        __syncthreads();  // slopes of this direction (first time: fD too); the previous direction's FF / ex are consumed
+        float F[5];
+        {
+            const int ni = L.edge[2 * d + 1] ? tid : L.nidx[2 * d + 1];
+            float Pb[5], Sb[5];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                Pb[v] = fP[v * 896 + ni];
+                Sb[v] = tS[v * 512 + ni];
+            }
+            euler_flux_w3(Pc, Pb, S, Sb, D, fD[ni], 0.5f, d, gas, F);
+        }
+        if (dnh == d) {  // wave-uniform: this wavefront's side is normal to d
+            float Pbc[5], Sbc[5];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                Pbc[v] = fP[v * 896 + pos];
+                Sbc[v] = tS[v * 512 + pos];
+            }
+            const float Dbc = fD[pos];
+            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            auto face = [&](const float* h, const float* sh_, float dh_) {
+                float Pa[5], Pb[5], Sa[5], Sb[5], X[5];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    const float sh = mirror ? Sbc[v] : sh_[v];
+                    Pa[v] = low ? h[v] : Pbc[v];
+                    Pb[v] = low ? Pbc[v] : h[v];
+                    Sa[v] = low ? sh : Sbc[v];
+                    Sb[v] = low ? Sbc[v] : sh;
+                }
+                const float dh = mirror ? Dbc : dh_;
+                euler_flux_w3(Pa, Pb, Sa, Sb, low ? dh : Dbc, low ? Dbc : dh, low ? 1.0f - qs : qs, d, gas, X);
+#pragma unroll
+                for (int v = 0; v < 5; ++v) acc[v] += X[v];
+            };
+            face(hu, Sh0, Dh0);
+            if (isF) {  // wave-uniform: the other three finer cells behind this boundary cell, fetched again (L2)
+                const float m4[4] = {Pbc[0], Pbc[0], Pbc[0], Pbc[0]};
+#pragma unroll 1
+                for (int k = 1; k < 4; ++k) {
+                    const uint32_t hk = (uint32_t)ft[k - 1];
+                    float hk_u[5], hk_d[5], shk[5], dhk;
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) {
+                        hk_u[v] = ldg(P + (size_t)v * ldp, hk);
+                        hk_d[v] = ldg(P + (size_t)v * ldp, (uint32_t)((int)hk + dd));
+                    }
+                    halo_eval(k, hk_u, hk_d, Pbc, m4, shk, dhk);
+                    face(hk_u, shk, dhk);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 5; ++v) ex[v * 384 + tid] = isF ? 0.25f * acc[v] : acc[v];
+        }
+#pragma unroll
+        for (int v = 0; v < 5; ++v) FF[v * 512 + tid] = F[v];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const float Fl = L.edge[2 * d] ? ex[v * 384 + 2 * d * 64 + tt[d]] : FF[v * 512 + tid - offm[d]];
+            const float Fh = L.edge[2 * d + 1] ? ex[v * 384 + (2 * d + 1) * 64 + tt[d]] : F[v];
+            res[v] = res[v] - (Fh - Fl) * bb.rh[d];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 5; ++v) stg(Rr + (size_t)v * ldr, c, res[v]);
+}
+
 // ==========================================================================================
 // Wave-per-block form ("plane marching"): ONE wavefront per 8x8x8 block, lane = (i, j), the eight z-planes of the
 // block handled in turn.  Each lane keeps its whole z-column in registers; x/y neighbours go through wave-private

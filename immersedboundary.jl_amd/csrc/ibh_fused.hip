@@ -745,6 +745,19 @@ __global__ __launch_bounds__(512) void k_sweep3_adv(const float* __restrict__ u,
     blk3::sweep_adv(blocks, htab, ftab, rtab + (size_t)blk * 384, r4tab, blk, u, C, ldc, ud, lds, threadIdx.x);
 }
 
+// 3-D single-kernel Euler sweep (blk3::sweep_euler): one 512-thread workgroup per block, every block of the partition
+__global__ __launch_bounds__(512) void k_sweep3_euler(const float* __restrict__ P, uint32_t ldp, float* __restrict__ R,
+                                                      uint32_t ldr, float Rgas, float gamma,
+                                                      const BlockDesc3* __restrict__ blocks,
+                                                      const int32_t* __restrict__ htab, const int32_t* __restrict__ ftab,
+                                                      const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab,
+                                                      int32_t n) {
+    __shared__ float lds[BLK3_SWEEP_EULER_LDS];
+    const int32_t blk = xcd_remap(blockIdx.x, n);
+    blk3::sweep_euler(blocks, htab, ftab, rtab + (size_t)blk * 384, r4tab, blk, P, ldp, R, ldr, blk3::Gas3{Rgas, gamma}, lds,
+                      threadIdx.x);
+}
+
 // Strip form of the 3-D scalar sweep (strip3::sweep_strip): one wavefront per block
 #ifndef WPB3S
 #define WPB3S 2
@@ -1171,6 +1184,15 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
             hipLaunchKernelGGL(k_sweep_euler, dim3(nwg), dim3(64 * WPBE), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,
                                fluid->R, fluid->gamma, bl, ht, et, p->dtab, count, nwg, iters, list ? list + i0 : nullptr);
         }
+        IBH_LAUNCH_CHECK();
+        return 0;
+    }
+    if (p->nd == 3 && p->sweep3 && p->bs == 8 && p->blocks3 && p->nblk > 0 &&
+        !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY | IBH_IMAGE_ONLY |
+                   IBH_PHASE_INTERIOR | IBH_PHASE_BOUNDARY))) {
+        // 3-D, every block qualifies for the single-kernel sweep: one launch, nothing through the workspace
+        hipLaunchKernelGGL(k_sweep3_euler, dim3(p->nblk), dim3(512), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,
+                           fluid->R, fluid->gamma, p->blocks3, p->htab3, p->ftab3, p->rtab3, p->r4tab3, p->nblk);
         IBH_LAUNCH_CHECK();
         return 0;
     }

@@ -158,6 +158,11 @@ def test_3d_block_path(octree8_mesh, nparts):
         egen = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=ibamd.IBH_FORCE_GENERAL))
         for v in range(5):
             assert rel_inf(efast[:, v], egen[:, v]) <= 1e-5, v
+        if nparts == 1:   # `efast` is the single kernel (blk3::sweep_euler); the two-kernel form agrees with it
+            etwo = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=ibamd.IBH_NO_FUSE))
+            for v in range(5):
+                assert rel_inf(etwo[:, v], egen[:, v]) <= 1e-5, v
+                assert rel_inf(efast[:, v], etwo[:, v]) <= 5e-6, v
         if nparts == 1:
             op = _oracle_view(part)
             fluid = ocfd.Fluid()
