@@ -801,9 +801,9 @@ __device__ __forceinline__ void passB_euler(const BlockDesc3* __restrict__ block
 // every primitive along the side normal and the pressure sensor of its halo cell(s) stay in its registers; only the
 // pressure needs the side's plane (lateral neighbours of the sensor).  The slopes of the block's own cells are staged
 // one direction at a time.
-// LDS (floats): fP 5x896 | fD 512 | tS 5x512 | ex 5x384 | FF 5x512 | planes 6 x 18x18 | planeA 6x64
+// LDS (floats): fP 5x896 | fD 512 | tS 2 x 5x512 | ex 5x384 | FF 5x512 | planes 6 x 18x18 | planeA 6x64
 // ------------------------------------------------------------------------------------------
-#define BLK3_SWEEP_EULER_LDS (5 * 896 + 512 + 2560 + 1920 + 2560 + 6 * 324 + 384)
+#define BLK3_SWEEP_EULER_LDS (5 * 896 + 512 + 2 * 2560 + 1920 + 2560 + 6 * 324 + 384)
 
 // MUSCL states from undivided slopes, then HLL (blk2::euler_flux_w with five primitives)
 __device__ __forceinline__ void euler_flux_w3(const float* Pa, const float* Pb, const float* Sa, const float* Sb, float Da,
@@ -841,8 +841,8 @@ __device__ __forceinline__ void sweep_euler(const BlockDesc3* __restrict__ block
     const uint32_t c = (uint32_t)bb.base + tid;
     float* fP = lds;                  // [5][tile 512 | halo 384]: halo part = mean value behind every boundary cell
     float* fD = fP + 5 * 896;         // [512]
-    float* tS = fD + 512;             // [5][512] undivided slopes of the block's cells along the current direction
-    float* ex = tS + 2560;            // [5][6][64] mean flux through the sub-face(s) of every boundary cell
+    float* tS2 = fD + 512;            // 2 x [5][512] undivided slopes of the block's cells along the current direction
+    float* ex = tS2 + 2 * 2560;       // [5][6][64] mean flux through the sub-face(s) of every boundary cell
     float* FF = ex + 1920;            // [5][512]
     float* plane = FF + 2560;         // [6][18 x 18] pressure
     float* planeA = plane + 6 * 324;  // [6][64]
@@ -1018,9 +1018,9 @@ __device__ __forceinline__ void sweep_euler(const BlockDesc3* __restrict__ block
     }
     // ---- one direction after the other: own slopes -> LDS, inner faces by the cells, block faces by the two side waves
     float res[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    const int offm[3] = {1, 8, 64};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
+        float* tS = tS2 + (d & 1) * 2560;  // double buffered: one barrier per direction
         float S[5];
         {
             const int n0 = L.nidx[2 * d], n1 = L.nidx[2 * d + 1];
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void sweep_euler(const BlockDesc3* __restrict__ block
                 tS[v * 512 + tid] = S[v];
             }
         }
-        __syncthreads();  // slopes of this direction (first time: fD too); the previous direction's FF / ex are consumed
+        __syncthreads();  // slopes of this direction (first time: fD too)
         float F[5];
         {
             const int ni = L.edge[2 * d + 1] ? tid : L.nidx[2 * d + 1];
@@ -1087,15 +1087,33 @@ __device__ __forceinline__ void sweep_euler(const BlockDesc3* __restrict__ block
 #pragma unroll
             for (int v = 0; v < 5; ++v) ex[v * 384 + tid] = isF ? 0.25f * acc[v] : acc[v];
         }
+        // the faces inside the block now (x, y: the low face is the high face of lane - 1 / lane - 8 of this wavefront;
+        // z: through LDS after the last barrier); the block faces (ex) at the end
+        if (d < 2) {
 #pragma unroll
-        for (int v = 0; v < 5; ++v) FF[v * 512 + tid] = F[v];
-        __syncthreads();
+            for (int v = 0; v < 5; ++v) {
+                const float Fh = L.edge[2 * d + 1] ? 0.0f : F[v];
+                const float Fs = __shfl_up(Fh, d == 0 ? 1 : 8, 64);
+                res[v] = res[v] - (Fh - (L.edge[2 * d] ? 0.0f : Fs)) * bb.rh[d];
+            }
+        } else {
 #pragma unroll
-        for (int v = 0; v < 5; ++v) {
-            const float Fl = L.edge[2 * d] ? ex[v * 384 + 2 * d * 64 + tt[d]] : FF[v * 512 + tid - offm[d]];
-            const float Fh = L.edge[2 * d + 1] ? ex[v * 384 + (2 * d + 1) * 64 + tt[d]] : F[v];
-            res[v] = res[v] - (Fh - Fl) * bb.rh[d];
+            for (int v = 0; v < 5; ++v) {
+                FF[v * 512 + tid] = F[v];
+                res[v] = res[v] - (L.edge[5] ? 0.0f : F[v]) * bb.rh[2];
+            }
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        float r = res[v] + (L.edge[4] ? 0.0f : FF[v * 512 + tid - 64]) * bb.rh[2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float elo = ex[v * 384 + 2 * d * 64 + tt[d]], ehi = ex[v * 384 + (2 * d + 1) * 64 + tt[d]];
+            r += ((L.edge[2 * d] ? elo : 0.0f) - (L.edge[2 * d + 1] ? ehi : 0.0f)) * bb.rh[d];
+        }
+        res[v] = r;
     }
 #pragma unroll
     for (int v = 0; v < 5; ++v) stg(Rr + (size_t)v * ldr, c, res[v]);
