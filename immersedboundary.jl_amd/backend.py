@@ -203,7 +203,10 @@ class DevicePartition:
                          sides_coarse=info[4], sides_fine=info[5], sides_general=info[6], interior_blocks=info[7],
                          fusable_blocks=info[8], workspace_blocks=info[9],
                          image_blocks_all_eligible=bool(info[10]), image_blocks=info[11],
-                         quads=info[12], quad_singles=info[13], image_quads=info[14], image_quad_singles=info[15])
+                         quads=info[12] if self.nd == 2 else 0, quad_singles=info[13], image_quads=info[14],
+                         image_quad_singles=info[15],
+                         # 3-D single-kernel sweeps: rim neighbours of halo cells that are four finer cells
+                         rim4_rows=info[12] if self.nd == 3 else 0)
 
     @property
     def ndims(self):

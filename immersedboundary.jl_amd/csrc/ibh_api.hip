@@ -257,6 +257,7 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         p->sweep3 = sw.all ? 1 : 0;
         p->info[8] = sw.all ? (int64_t)blocks.size() : 0;   // blocks of the single-kernel sweep
         p->info[9] = sw.all ? 0 : (int64_t)blocks.size();   // blocks whose gradients go through the workspace
+        p->info[12] = (int64_t)(sw.r4tab.size() / 4);         // rim neighbours made of four finer cells
         if (sw.r4tab.empty()) sw.r4tab.assign(4, 0);
         if ((rc = ibh_upload(&p->rtab3, sw.rtab.data(), sw.rtab.size()))) return rc;
         if ((rc = ibh_upload(&p->r4tab3, sw.r4tab.data(), sw.r4tab.size()))) return rc;

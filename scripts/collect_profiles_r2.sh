@@ -11,6 +11,10 @@ say euler; $B --residual euler > $O/bench_euler.json 2>>$O/bench.err
 say 3d; $B --workload sphere3d_4.6M > $O/bench_3d_4.6M.json 2>>$O/bench.err
 say 3d euler; $B --steps 100 --warmup 10 --residual euler --workload sphere3d_1.6M > $O/bench_3d_euler_1.6M.json 2>>$O/bench.err
 say config4; $B --workload sphere3d_8M --residual euler --step config4 --steps 20 --warmup 3 --repeats 5 > $O/bench_config4_8M.json 2>>$O/bench.err
+say config5; $B --workload sphere3d_4.6M --residual euler --step config5 --steps 5 --warmup 1 --repeats 3 > $O/bench_config5_4.6M.json 2>>$O/bench.err
+say 28M; $B --workload rae2822_28M --steps 50 --warmup 5 --repeats 5 > $O/bench_28M.json 2>>$O/bench.err
+say probes 3d / euler; python3 scripts/probe_3d.py > $O/probe_3d_4.6M.json 2>>$O/bench.err
+python3 scripts/probe_euler.py > $O/probe_euler.json 2>>$O/bench.err
 say probe; python3 scripts/probe_sweep.py > $O/probe_0.87M.json 2>>$O/bench.err
 QUAD_TUNE=1 python3 scripts/probe_sweep.py > $O/probe_parts_0.87M.json 2>>$O/bench.err
 python3 scripts/probe_sweep.py rae2822_3.47M > $O/probe_3.47M.json 2>>$O/bench.err

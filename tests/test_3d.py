@@ -185,7 +185,8 @@ def test_3d_block_path(octree8_mesh, nparts):
             assert rel_inf(fast, exp) <= 1e-5
             # `fast` is the single-kernel sweep (blk3::sweep_adv) on the eligible blocks + the two-kernel form on
             # the rest; the two-kernel form alone agrees with it
-            assert 0 < info["fusable_blocks"] <= info["full_blocks"]
+            assert info["fusable_blocks"] == info["full_blocks"] and info["workspace_blocks"] == 0
+            assert info["rim4_rows"] > 0      # halo cells whose lateral neighbour is four finer cells are exercised
             two = ibamd.to_host(ibamd.residual_advection(dpart, ud_, Cd, flags=ibamd.IBH_NO_FUSE))
             assert rel_inf(two, exp) <= 1e-5
             assert rel_inf(fast, two) <= 2e-6

@@ -152,3 +152,51 @@ def test_full_size_per_cell_error_percentiles(full, capsys):
     with capsys.disabled():
         print("\nper-cell relative error of the tuned sweep (0.87 M cells):", json.dumps(pct))
     assert pct["p99.9"] <= 2e-6 and pct["max"] <= 2e-5 and pct["norm_wise"] <= 1e-5
+
+
+def test_3d_single_kernel_sweeps_at_bench_size():
+    """The 3-D workloads of bench.py at full size (sphere-in-box octree, 1 667 072 cells, every kind of block side): the
+    single-kernel sweeps -- strip form (scalar), workgroup form (Euler) -- against the C restatement on the whole mesh,
+    against the thread-per-cell and the two-kernel forms, and the size-independent properties of the closure."""
+    import bench
+    from ibamd import _lib
+    from oracle import residual_c as rc
+    msh = bench.build_mesh("sphere3d_1.6M")
+    assert len(msh) == 1667072
+    dom = ibamd.Domain(msh, max_partition_size=10 ** 9, boundaries=False)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    info = dpart.info
+    assert info["fusable_blocks"] == info["full_blocks"] == 3256 and info["sides_fine"] > 0 and info["rim4_rows"] > 0
+    u, C = bench.synthetic_fields(part.centers)
+    n = u.shape[0]
+    cpart = rc.CPart(part)
+    exp = cpart.residual_advection(u, C)
+    du, dC = ibamd.hip(u), ibamd.hip(C)
+    strip = ibamd.to_host(ibamd.residual_advection(dpart, du, dC))
+    _lib.call("ibh_set_tuning", b"quad_variant", 512)            # thread-per-cell single kernel
+    try:
+        cellk = ibamd.to_host(ibamd.residual_advection(dpart, du, dC))
+    finally:
+        _lib.call("ibh_set_tuning", b"quad_variant", 0)
+    two = ibamd.to_host(ibamd.residual_advection(dpart, du, dC, flags=ibamd.IBH_NO_FUSE))
+    gen = ibamd.to_host(ibamd.residual_advection(dpart, du, dC, flags=ibamd.IBH_FORCE_GENERAL))
+    assert np.array_equal(gen, exp)                      # literal arithmetic: bit for bit
+    for got in (strip, cellk, two):
+        assert rel_inf(got, exp) <= 1e-5
+    assert rel_inf(strip, cellk) <= 2e-6 and rel_inf(strip, two) <= 2e-6
+    const = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(np.full(n, 3.25, dtype=f32)), dC))
+    assert np.array_equal(const, np.zeros(n, dtype=f32))            # constant field: exactly zero
+    r4 = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(f32(4.0) * u), dC))
+    assert rel_inf(r4, f32(4.0) * strip) <= 1e-5                    # positively homogeneous, degree one
+    rng = np.random.default_rng(5)
+    P = np.stack([1e5 * (1 + 0.05 * rng.uniform(-1, 1, n)), 288.15 * (1 + 0.05 * rng.uniform(-1, 1, n)),
+                  100.0 * (1 + 0.1 * rng.uniform(-1, 1, n)), 60.0 * (1 + 0.1 * rng.uniform(-1, 1, n)),
+                  -40.0 * (1 + 0.1 * rng.uniform(-1, 1, n))], axis=1).astype(f32)
+    expE = cpart.residual_euler(P)
+    one = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P)))
+    twoE = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=ibamd.IBH_NO_FUSE))
+    for v in range(5):
+        assert rel_inf(one[:, v], expE[:, v]) <= 1e-5, v
+        assert rel_inf(twoE[:, v], expE[:, v]) <= 1e-5, v
+        assert rel_inf(one[:, v], twoE[:, v]) <= 5e-6, v
