@@ -431,6 +431,9 @@ __device__ __forceinline__ void sweep_strip(const BlockDesc3* __restrict__ block
     // ---- (b) block faces, side after side (the Hm rows become the edge fluxes)
     {
         float hu[6], hde[6], hc[6], rv[6];
+        // (the asm keeps the compiler from forming the 64-bit addresses of these loads before the slope phase and
+        // carrying them -- twice the registers of the ids -- through it)
+        asm volatile("" : "+v"(hid[0]), "+v"(hid[1]), "+v"(hid[2]), "+v"(hid[3]), "+v"(hid[4]), "+v"(hid[5]));
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const int d = s >> 1, sd = d == 0 ? 1 : d == 1 ? 8 : 64;
