@@ -187,10 +187,12 @@ def _relax(A, s, r, x, sc):
     call("ibh_pi_update", n, _p(sc.dots), EPS32, _p(s), _p(As), _p(x), _p(r))
 
 
-def solve(A, b, prec, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=None, verbose=False):
+def solve(A, b, prec, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=None, verbose=False, check_every=1):
     """:250-329 -- block-preconditioned two-direction minimal-residual relaxation; returns ``(x, |r|/|r0|)``.
     ``multigrid``: object with ``coarseners`` / ``prolongators`` (callables on device arrays, e.g. the
-    ``DeviceAccumulator``s of ``ibamd.multigrid``), cycled from the coarsest level to none like the reference."""
+    ``DeviceAccumulator``s of ``ibamd.multigrid``), cycled from the coarsest level to none like the reference.
+    ``check_every``: the residual norm is read back (the one host round trip of a step) every that many inner steps and
+    after the last one; 1 = the reference's loop."""
     b = _dense(b)
     n = _numel(b)
     sc = _Scalars(b.device)
@@ -217,10 +219,12 @@ def solve(A, b, prec, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=Non
             call("ibh_maxabs", n, _p(r), _p(sc.mx))
             call("ibh_pi_normalize", n, _p(r), _p(sc.mx), EPS32, _p(s))
             _relax(A, s, r, x, sc)
-            nr = norm(r)
-            if verbose:
-                print(f"{(nit - 1) * n_inner + nin}       {nr / (nr0 + EPS32)}")
-            if nr < nr0 * rtol + atol:
-                return x, nr / (nr0 + EPS32)
+            step = (nit - 1) * n_inner + nin
+            if step % max(1, int(check_every)) == 0 or step == n_iter * n_inner:
+                nr = norm(r)
+                if verbose:
+                    print(f"{step}       {nr / (nr0 + EPS32)}")
+                if nr < nr0 * rtol + atol:
+                    return x, nr / (nr0 + EPS32)
         n_mgrid = n_levels if n_mgrid == 0 else n_mgrid - 1
     return x, nr / (nr0 + EPS32)

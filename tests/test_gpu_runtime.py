@@ -202,6 +202,21 @@ def test_fas_multigrid_matches_oracle(adv_mesh_coarse):
     assert rel_inf(ibamd.to_host(Qg), Qo) <= 1e-5
     assert abs(rg - float(ro)) <= 1e-4 * max(1.0, float(ro))
     assert not np.array_equal(Qo, Q0)
+    # check_every: the convergence test (the host round trip of an iteration) every k iterations; with a tolerance that
+    # is never met the iterates are the same and the norm is read 1 + 1 times per level instead of 1 + n_iter
+    from ibamd import solver as _solver
+    calls = {"n": 0}
+
+    def counting_norm(r):
+        calls["n"] += 1
+        return _solver._norm(r)
+    Q1, Qk = ibamd.hip(Q0), ibamd.hip(Q0)
+    r1 = ibamd.FAS(g_f, Q1, coarseners=coar_p, prolongators=prol_p, n_iter=8, rtol=0.0, atol=0.0, norm=counting_norm)
+    n1, calls["n"] = calls["n"], 0
+    rk = ibamd.FAS(g_f, Qk, coarseners=coar_p, prolongators=prol_p, n_iter=8, rtol=0.0, atol=0.0, norm=counting_norm,
+                   check_every=8)
+    assert np.array_equal(ibamd.to_host(Q1), ibamd.to_host(Qk)) and r1 == rk
+    assert n1 == 2 * 9 and calls["n"] == 2 * 2      # two levels are visited (the last supplied level never is)
 
 
 def test_flow_bc_in_impose_bc(rae_domains):
