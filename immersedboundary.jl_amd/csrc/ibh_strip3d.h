@@ -43,9 +43,9 @@ using quad2::v4f_g;
 #define S3_FACE 0                     // [4: U, S_normal, D, C_normal][6 sides][64] boundary cells by slot
 #define S3_HM (S3_FACE + 4 * 384)     // [6][64] mean halo value behind boundary cell t; later the edge fluxes
 #define S3_HA (S3_HM + 384)           // [6][64] mean |halo - boundary cell|
-#define S3_PLANE (S3_HA + 384)        // [18 x 18]
-#define S3_PLANEA (S3_PLANE + 324)    // [64] rim neighbours: mean |difference| to the halo cell next to them
-#define S3_LDS (S3_PLANEA + 64)
+#define S3_PLANE S3_HA                // [18 x 18] over Ha, which is dead after the slope phase (a wave's LDS operations
+#define S3_PLANEA (S3_PLANE + 324)    // [64]      execute in order); rim neighbours: mean |difference| to the next halo cell
+#define S3_LDS (S3_PLANEA + 64)       // 2 308 floats = 9.0 KB per wave
 
 // one quantity of this lane's strip into the face rows of the sides the strip touches
 template <int Q>
@@ -218,19 +218,13 @@ __device__ __forceinline__ void side_flux(const BlockDesc3& bb, const LaneGeo& L
             out = slot_eval<true>(pl, pA, hu0, hde0, hc0, m0, m1, m2, m3, ub, Sb, Db, Cb, la, ha, lb, hb, t1 <= 1, t1 >= 6,
                                   t2 <= 1, t2 >= 6, t1, t2, 8, qs, rn, ra, rb, low, false);
         }
-    } else {  // the 2 x 2 finer cells behind this boundary cell
+    } else {  // the 2 x 2 finer cells behind this boundary cell, one after the other (rolled loops: few registers)
         const int32_t* ft = ftab + (((size_t)bb.fine * 6 + S) * 64 + lane) * 3;
         const int dd = low ? -sd : sd;
-        float hu[4] = {hu0, 0.f, 0.f, 0.f}, hde[4] = {hde0, 0.f, 0.f, 0.f}, hc[4] = {hc0, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            const uint32_t hk = (uint32_t)ft[k - 1];
-            hu[k] = ldg(u, hk);
-            hde[k] = ldg(u, (uint32_t)((int)hk + dd));
-            hc[k] = ldg(Cn, hk);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pl[(2 * t1 + (k & 1) + 1) + 18 * (2 * t2 + (k >> 1) + 1)] = hu[k];
+        pl[(2 * t1 + 1) + 18 * (2 * t2 + 1)] = hu0;
+#pragma unroll 1
+        for (int k = 1; k < 4; ++k)
+            pl[(2 * t1 + (k & 1) + 1) + 18 * (2 * t2 + (k >> 1) + 1)] = ldg(u, (uint32_t)ft[k - 1]);
         pl[LG.rpos16] = rmean;
         wave_lds_sync();
         {
@@ -239,12 +233,19 @@ __device__ __forceinline__ void side_flux(const BlockDesc3& bb, const LaneGeo& L
         }
         wave_lds_sync();
         float acc = 0.0f;
-#pragma unroll
+#pragma unroll 1
         for (int k = 0; k < 4; ++k) {
+            float hk = hu0, hdk = hde0, hck = hc0;
+            if (k > 0) {
+                const uint32_t c = (uint32_t)ft[k - 1];
+                hk = ldg(u, c);
+                hdk = ldg(u, (uint32_t)((int)c + dd));
+                hck = ldg(Cn, c);
+            }
             const int f1 = 2 * t1 + (k & 1), f2 = 2 * t2 + (k >> 1);
-            acc += slot_eval<false>(pl, pA, hu[k], hde[k], hc[k], ub, ub, ub, ub, ub, Sb, Db, Cb, f1 + 18 * (f2 + 1),
-                             f1 + 2 + 18 * (f2 + 1), (f1 + 1) + 18 * f2, (f1 + 1) + 18 * (f2 + 2), f1 == 0, f1 == 15,
-                             f2 == 0, f2 == 15, f1, f2, 16, qs, rn, ra, rb, low, false);
+            acc += slot_eval<false>(pl, pA, hk, hdk, hck, ub, ub, ub, ub, ub, Sb, Db, Cb, f1 + 18 * (f2 + 1),
+                                    f1 + 2 + 18 * (f2 + 1), (f1 + 1) + 18 * f2, (f1 + 1) + 18 * (f2 + 2), f1 == 0, f1 == 15,
+                                    f2 == 0, f2 == 15, f1, f2, 16, qs, rn, ra, rb, low, false);
         }
         out = 0.25f * acc;
     }
