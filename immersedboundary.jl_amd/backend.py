@@ -450,7 +450,13 @@ def cell_gradient(part, u, dim=None):
     """:965 / :980"""
     part = _part(part)
     if dim is None:
-        return tuple(cell_gradient(part, u, d) for d in range(1, part.nd + 1))
+        # the tuple form: all dimensions in one sweep per field (ibh_cell_gradient_nd)
+        u, nv, ld = _field(u, part.nc)
+        nd = part.nd
+        buf = colmajor_empty(part.nc, nd * nv)
+        _stream()
+        call("ibh_cell_gradient_nd", part.handle, _ptr(u), nv, ld, _ptr(buf), part.nc, None, 0)
+        return tuple(buf[:, d * nv] if u.ndim == 1 else buf[:, d * nv:(d + 1) * nv] for d in range(nd))
     u, nv, ld = _field(u, part.nc)
     out = _like(u, part.nc)
     _stream()

@@ -25,10 +25,11 @@ def euler_wray_agarwal_residual(part, Q, nu=1.5e-5, out=None):
     B.residual_euler_hll(part, Q[:, :nvp], out=r[:, :nvp])
     R = Q[:, nvp].contiguous()
     vel = [Q[:, 2 + i].contiguous() for i in range(nd)]
-    gu = [[B.cell_gradient(part, vel[i], j + 1) for j in range(nd)] for i in range(nd)]
+    # cell_gradient(part, u): the tuple form, one sweep per field for all dimensions
+    gu = [list(B.cell_gradient(part, vel[i])) for i in range(nd)]
     S = T.shear_rate(gu)
-    gR = torch.stack([B.cell_gradient(part, R, d + 1) for d in range(nd)], dim=0).T
-    gS = torch.stack([B.cell_gradient(part, S, d + 1) for d in range(nd)], dim=0).T
+    gR = torch.stack(B.cell_gradient(part, R), dim=0).T
+    gS = torch.stack(B.cell_gradient(part, S), dim=0).T
     wa = T.Wray_Agarwal(R, S, gR, gS)
     rt = wa["S"].clone()
     for d in range(nd):

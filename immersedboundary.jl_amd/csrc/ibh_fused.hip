@@ -1148,6 +1148,43 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     return 0;
 }
 
+// cell_gradient(part, u) -- the tuple form (ImmersedBoundary.jl:980-988): the gradients of `nv` fields along ALL
+// dimensions in one sweep per field, and (optionally) the JST sensor of every field (JST_sensor(part, u), :1077-1097, the
+// maximum over the dimensions).  On a block-structured partition this is pass A of the two-kernel sweeps (block kernels,
+// face-list threads for the cells outside blocks; tuned arithmetic: reciprocal spacings, inside 5e-6 norm-wise of the
+// operator-by-operator kernels); elsewhere it falls back to ibh_cell_gradient / ibh_jst_sensor per dimension.
+//   out:    (nc, nd*nv) column-major, gradient of field v along dimension d in column d*nv + v
+//   sensor: (nc, nv) or null
+int ibh_cell_gradient_nd(ibh_part* p, const float* u, int nv, int64_t ldu, float* out, int64_t ldo, float* sensor,
+                         int64_t lds) {
+    IBH_REQUIRE(p && u && out && nv >= 1, "ibh_cell_gradient_nd: bad argument");
+    if (p->nc == 0) return 0;
+    const int nd = p->nd;
+    const bool blocks = p->bs == 8 && p->nblk > 0 && (nd == 2 ? p->blocks2 != nullptr : p->blocks3 != nullptr);
+    if (!blocks) {
+        for (int d = 0; d < nd; ++d) {
+            int rc = ibh_cell_gradient(p, d + 1, u, nv, ldu, out + (size_t)d * nv * ldo, ldo);
+            if (rc) return rc;
+        }
+        if (sensor) return ibh_jst_sensor(p, 0, u, nv, ldu, sensor, lds);
+        return 0;
+    }
+    int rc = ensure_G(p);
+    if (rc) return rc;
+    for (int v = 0; v < nv; ++v) {
+        const float* uv = u + (size_t)v * ldu;
+        // pass A of the scalar sweep: G = [grad_1 .. grad_nd, sensor], each nc floats (velocity / output are not touched)
+        if ((rc = ibh_residual_advection(p, uv, uv, p->nc, p->G, IBH_PASS_A_ONLY | IBH_NO_FUSE))) return rc;
+        for (int d = 0; d < nd; ++d)
+            IBH_HIP(hipMemcpyAsync(out + (size_t)(d * nv + v) * ldo, p->G + (size_t)d * p->nc, sizeof(float) * p->nc,
+                                   hipMemcpyDeviceToDevice, ibh_stream));
+        if (sensor)
+            IBH_HIP(hipMemcpyAsync(sensor + (size_t)v * lds, p->G + (size_t)nd * p->nc, sizeof(float) * p->nc,
+                                   hipMemcpyDeviceToDevice, ibh_stream));
+    }
+    return 0;
+}
+
 int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, int64_t ldr, const ibh_fluid* fluid,
                            int flags) {
     IBH_REQUIRE(p && P && R && fluid, "ibh_residual_euler_hll: null argument");

@@ -153,6 +153,12 @@ int ibh_at_faces(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, 
 int ibh_green_gauss(const ibh_part*, int dim, const float* uf, int nv, int64_t ldf, float* out, int64_t ldo,
                     int unsigned_sum);                                                                         /* :918, :934 */
 int ibh_cell_gradient(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo); /* :965 */
+/* cell_gradient(part, u): the tuple form, src/ImmersedBoundary.jl:980-988 -- all dimensions in one sweep per field:
+ * out (nc, nd*nv), gradient of field v along dimension d in column d*nv + v; sensor (nc, nv) or NULL: JST_sensor(part, u)
+ * (:1077-1097, dim = 0) of every field for free.  Block-structured partitions: pass A of the two-kernel sweeps (tuned
+ * arithmetic, inside 5e-6 norm-wise of ibh_cell_gradient / ibh_jst_sensor); others: those kernels, one dimension at a time. */
+int ibh_cell_gradient_nd(ibh_part*, const float* u, int nv, int64_t ldu, float* out, int64_t ldo, float* sensor,
+                         int64_t lds);
 int ibh_face_distance(const ibh_part*, int dim, float* out);     /* :995  */
 int ibh_owner_distance(const ibh_part*, int dim, float* out);    /* :1010 */
 int ibh_neighbor_distance(const ibh_part*, int dim, float* out); /* :1024 */

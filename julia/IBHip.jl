@@ -250,7 +250,17 @@ function cell_gradient(part::HipPartition, u::HipArray, dim::Int)
         part.handle, dim, u.ptr, nv(u), ld(u), out.ptr, ld(out)))
     out
 end
-cell_gradient(part::HipPartition, u::HipArray) = tuple((cell_gradient(part, u, d) for d = 1:ndims(part))...)
+# the tuple form (ImmersedBoundary.jl:980-988): all dimensions in one sweep per field (ibh_cell_gradient_nd); the
+# gradients along dimension d are the columns (d-1)*nv+1 : d*nv of one (nc, nd*nv) buffer, returned as aliasing views
+function cell_gradient(part::HipPartition, u::HipArray{Float32, N}) where {N}
+    nd, n, k = ndims(part), part.nc, nv(u)
+    buf = HipArray{Float32, 2}(undef, (n, nd * k))
+    check(ccall((:ibh_cell_gradient_nd, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+        part.handle, u.ptr, k, ld(u), buf.ptr, n, C_NULL, 0))
+    dims = N == 1 ? (n,) : (n, k)
+    tuple((HipArray{Float32, N}(buf.ptr + (d - 1) * k * n * sizeof(Float32), dims, buf) for d = 1:nd)...)
+end
 
 function _gg(part::HipPartition, uf::HipArray, dim::Int, uns::Int)
     out = out_like(uf, part.nc)

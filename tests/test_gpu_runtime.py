@@ -215,7 +215,7 @@ def test_fas_multigrid_matches_oracle(adv_mesh_coarse):
     n1, calls["n"] = calls["n"], 0
     rk = ibamd.FAS(g_f, Qk, coarseners=coar_p, prolongators=prol_p, n_iter=8, rtol=0.0, atol=0.0, norm=counting_norm,
                    check_every=8)
-    assert np.array_equal(ibamd.to_host(Q1), ibamd.to_host(Qk)) and r1 == rk
+    assert np.array_equal(ibamd.to_host(Q1), ibamd.to_host(Qk)) and abs(r1 - rk) <= 1e-9 * r1   # (atomic sum order)
     assert n1 == 2 * 9 and calls["n"] == 2 * 2      # two levels are visited (the last supplied level never is)
 
 
