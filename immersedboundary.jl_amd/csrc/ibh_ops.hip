@@ -220,6 +220,40 @@ __global__ void k_accumulate(int32_t n_out, const int32_t* __restrict__ off, con
     }
 }
 
+// The same for several fields at once: one thread per row, the row's indices and weights read once for up to NVB
+// fields (the per-(row, field) form reads them once per field).  Same sum order per field.
+template <int NVB>
+__global__ void k_accumulate_rows(int32_t n_out, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                  const float* __restrict__ w, const int32_t* __restrict__ remap,
+                                  const float* __restrict__ v, int64_t ldv, float* __restrict__ out, int64_t ldo, int nv) {
+    const int v0 = blockIdx.y * NVB;
+    const int nb = min(NVB, nv - v0);
+    const float* vv = v + (int64_t)v0 * ldv;
+    float* oo = out + (int64_t)v0 * ldo;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t b = off[r], e = off[r + 1];
+        float s[NVB];
+#pragma unroll
+        for (int q = 0; q < NVB; ++q) s[q] = 0.0f;
+        for (int32_t k = b; k < e; ++k) {
+            int32_t j = idx[k];
+            if (remap) j = remap[j];
+            const float wk = w ? w[k] : 1.0f;
+#pragma unroll
+            for (int q = 0; q < NVB; ++q) {
+                if (q < nb) {
+                    const float x = vv[j + (int64_t)q * ldv];
+                    const float t = w ? x * wk : x;
+                    s[q] = (k == b) ? t : s[q] + t;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NVB; ++q)
+            if (q < nb) oo[r + (int64_t)q * ldo] = s[q];
+    }
+}
+
 // a[ghost] = eta*ia + (1-eta)*ba (:1242-1245); ba from array, constant, or ia (copy BC)
 __global__ void k_bc_blend(int32_t ng, const int32_t* __restrict__ ghost, const float* __restrict__ eta,
                            float* __restrict__ a, int64_t lda, const float* __restrict__ ia, int64_t ldi,
@@ -263,6 +297,20 @@ __global__ void k_sumsq(int64_t n, const float* __restrict__ x, double* __restri
 }
 
 inline dim3 grid2(int64_t n, int nv) { return dim3(ibh_grid(n, OPS_BLOCK) > 4096 ? 4096 : ibh_grid(n, OPS_BLOCK), nv); }
+
+// launch of the accumulation kernels: per (row, field) for one field, per row over blocks of up to 4 fields otherwise
+static inline void launch_accumulate(int32_t n_out, const int32_t* off, const int32_t* idx, const float* w,
+                                     const int32_t* remap, const float* v, int64_t ldv, float* out, int64_t ldo, int nv) {
+    if (nv == 1) {
+        hipLaunchKernelGGL(k_accumulate, grid2(n_out, 1), dim3(OPS_BLOCK), 0, ibh_stream, n_out, off, idx, w, remap, v, ldv,
+                           out, ldo);
+    } else {
+        dim3 g = grid2(n_out, (nv + 3) / 4);
+        hipLaunchKernelGGL(k_accumulate_rows<4>, g, dim3(OPS_BLOCK), 0, ibh_stream, n_out, off, idx, w, remap, v, ldv, out,
+                           ldo, nv);
+    }
+}
+
 
 }  // namespace
 
@@ -386,8 +434,7 @@ int ibh_accumulate(const ibh_acc* a, const float* v, int nv, int64_t ldv, float*
     IBH_REQUIRE(a, "ibh_accumulate: null accumulator");
     CHECK_NV(nv);
     if (a->n_out == 0) return 0;
-    hipLaunchKernelGGL(k_accumulate, grid2(a->n_out, nv), dim3(OPS_BLOCK), 0, ibh_stream, a->n_out, a->off, a->idx,
-                       a->w, (const int32_t*)nullptr, v, ldv, out, ldo);
+    launch_accumulate(a->n_out, a->off, a->idx, a->w, (const int32_t*)nullptr, v, ldv, out, ldo, nv);
     IBH_LAUNCH_CHECK();
     return 0;
 }
@@ -396,8 +443,7 @@ int ibh_bc_interp(const ibh_bc* b, const float* a, int nv, int64_t lda, float* i
     IBH_REQUIRE(b, "ibh_bc_interp: null boundary");
     CHECK_NV(nv);
     if (b->ng == 0) return 0;
-    hipLaunchKernelGGL(k_accumulate, grid2(b->ng, nv), dim3(OPS_BLOCK), 0, ibh_stream, b->ng, b->interp.off,
-                       b->interp.idx, b->interp.w, b->image_domain, a, lda, ia, ldi);
+    launch_accumulate(b->ng, b->interp.off, b->interp.idx, b->interp.w, b->image_domain, a, lda, ia, ldi, nv);
     IBH_LAUNCH_CHECK();
     return 0;
 }
