@@ -72,6 +72,7 @@ _SIGS = {
     "ibh_ew_unary": [c_int, c_i64, c_vp, c_vp],
     "ibh_ew_fill": [c_i64, C.c_float, c_vp],
     "ibh_ew_reduce": [c_int, c_i64, c_vp, c_vp],
+    "ibh_ew_eval": [c_i64, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp],
     "ibh_set_tuning": [C.c_char_p, c_int],
     "ibh_debug_buffer": [c_vp],
     "ibh_probe_dispatch": [c_int, c_int, c_int],

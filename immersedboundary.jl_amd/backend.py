@@ -599,6 +599,9 @@ def impose_bc(f, dom, bname, *args, conv_to_backend=None, conv_from_backend=None
         raise AssertionError("Backend converters must be provided at the same time")
     from .hiparray import HipArray
     wrapped = any(isinstance(a, HipArray) for a in args)
+    for a in args:
+        if isinstance(a, HipArray):
+            a._flush_readers()   # the arrays are written in place: pending broadcasts that read them go first
     args = tuple(a.t if isinstance(a, HipArray) else a for a in args)
     host_args = None
     if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in args):

@@ -43,6 +43,48 @@ __global__ __launch_bounds__(256) void k_ew_fill(int64_t total, float v, float* 
         out[t] = v;
 }
 
+// A postfix program evaluated per element (ibh_ew_eval): the top of the stack in a register, the rest in LDS
+// (conflict-free: one column per thread); the program is wave-uniform, so the interpreter loop does not diverge.
+struct EwProg {
+    int32_t nprog;
+    int32_t prog[48];
+    const float* arr[8];
+    int32_t arr_nv[8];
+    float scal[8];
+};
+__global__ __launch_bounds__(256) void k_ew_eval(int64_t n, int nv, EwProg P, float* out) {
+    __shared__ float stk[7][256];
+    const int64_t total = n * nv;
+    const int tid = threadIdx.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + tid; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t % n;
+        float tos = 0.0f;
+        int sp = 0;  // entries on the stack, the last one in `tos`
+        for (int pc = 0; pc < P.nprog; ++pc) {
+            const int ins = P.prog[pc], op = ins & 255, k = ins >> 8;
+            if (op >= IBH_EW_PUSH_ARRAY) {
+                if (sp > 0) stk[sp - 1][tid] = tos;
+                tos = op == IBH_EW_PUSH_ARRAY ? (P.arr_nv[k] == 1 ? P.arr[k][i] : P.arr[k][t]) : P.scal[k];
+                ++sp;
+            } else if (op >= IBH_EW_ABS) {
+                tos = op == IBH_EW_ABS ? fabsf(tos) : op == IBH_EW_NEG ? -tos : op == IBH_EW_SQRT ? sqrtf(tos) : tos;
+            } else {
+                const float a = stk[sp - 2][tid];
+                --sp;
+                switch (op) {
+                    case IBH_EW_ADD: tos = a + tos; break;
+                    case IBH_EW_SUB: tos = a - tos; break;
+                    case IBH_EW_MUL: tos = a * tos; break;
+                    case IBH_EW_DIV: tos = a / tos; break;
+                    case IBH_EW_MAX: tos = fmaxf(a, tos); break;
+                    default: tos = fminf(a, tos); break;
+                }
+            }
+        }
+        out[t] = tos;
+    }
+}
+
 template <int OP>
 __device__ __forceinline__ float red2(float a, float b) {
     return OP == IBH_EW_SUM ? a + b : OP == IBH_EW_MAX ? fmaxf(a, b) : fminf(a, b);
@@ -130,6 +172,46 @@ int ibh_ew_binary(int op, int64_t n, int nv, const float* a, int nva, float sa, 
         default: return ibh_fail(-1, "ibh_ew_binary: unknown operation", __FILE__, __LINE__);
     }
 #undef EW2
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_ew_eval(int64_t n, int nv, int nprog, const int32_t* prog, int narr, const float* const* arrays,
+                const int32_t* arr_nv, int nscal, const float* scalars, float* out) {
+    IBH_REQUIRE(out && prog && n >= 0 && nv >= 1, "ibh_ew_eval: bad argument");
+    IBH_REQUIRE(nprog >= 1 && nprog <= 48 && narr >= 0 && narr <= 8 && nscal >= 0 && nscal <= 8,
+                "ibh_ew_eval: at most 48 instructions, 8 arrays and 8 scalars");
+    EwProg P;
+    P.nprog = nprog;
+    int sp = 0;
+    for (int pc = 0; pc < nprog; ++pc) {
+        const int op = prog[pc] & 255, k = prog[pc] >> 8;
+        if (op == IBH_EW_PUSH_ARRAY) {
+            IBH_REQUIRE(k >= 0 && k < narr && arrays && arrays[k] && arr_nv && (arr_nv[k] == nv || arr_nv[k] == 1),
+                        "ibh_ew_eval: array operand out of range, null, or neither a field of the result's shape nor a "
+                        "column vector");
+            ++sp;
+        } else if (op == IBH_EW_PUSH_SCALAR) {
+            IBH_REQUIRE(k >= 0 && k < nscal && scalars, "ibh_ew_eval: scalar operand out of range");
+            ++sp;
+        } else if (op == IBH_EW_ABS || op == IBH_EW_NEG || op == IBH_EW_SQRT || op == IBH_EW_COPY) {
+            IBH_REQUIRE(sp >= 1, "ibh_ew_eval: unary operation on an empty stack");
+        } else {
+            IBH_REQUIRE(op >= IBH_EW_ADD && op <= IBH_EW_MIN, "ibh_ew_eval: unknown operation");
+            IBH_REQUIRE(sp >= 2, "ibh_ew_eval: binary operation needs two operands");
+            --sp;
+        }
+        IBH_REQUIRE(sp <= 8, "ibh_ew_eval: stack deeper than 8");
+        P.prog[pc] = prog[pc];
+    }
+    IBH_REQUIRE(sp == 1, "ibh_ew_eval: the program must leave exactly one value");
+    for (int k = 0; k < 8; ++k) {
+        P.arr[k] = k < narr ? arrays[k] : nullptr;
+        P.arr_nv[k] = k < narr ? arr_nv[k] : 1;
+        P.scal[k] = k < nscal ? scalars[k] : 0.0f;
+    }
+    if (n * nv == 0) return 0;
+    hipLaunchKernelGGL(k_ew_eval, dim3(ibh_grid(n * nv, 256 * 4)), dim3(256), 0, ibh_stream, n, nv, P, out);
     IBH_LAUNCH_CHECK();
     return 0;
 }

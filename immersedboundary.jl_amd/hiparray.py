@@ -7,6 +7,7 @@ does the same through Python's operator protocol, so that the very same expressi
 entry points.  torch only owns the memory (column-major Float32).
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -23,11 +24,20 @@ def _B():
     return backend
 
 
+PUSH_ARRAY, PUSH_SCALAR = 32, 33
+_MAX_PROG, _MAX_ARR, _MAX_SCAL, _MAX_DEPTH = 48, 8, 8, 8
+
+
 class HipArray:
-    """Device array ``(n,)`` or ``(n, nv)``, column-major Float32; arithmetic = one ``ibh_ew_*`` launch per node.
+    """Device array ``(n,)`` or ``(n, nv)``, column-major Float32.  Arithmetic between HipArrays and scalars builds an
+    expression (as a Julia broadcast does before it is materialised); the whole expression runs as ONE launch
+    (``ibh_ew_eval``: Julia's broadcast fusion) when its value is needed -- by an operator, ``to_host``, an in-place
+    update (``ud -= expr`` evaluates ``ud - expr`` straight into ``ud``).  ``HipArray.fuse = False`` evaluates node by
+    node (``ibh_ew_binary`` / ``ibh_ew_unary``), bit-identical.
     The class itself is the ``conv_to_backend`` converter: ``dom(f, args..., conv_to_backend=ibamd.HipArray, ...)``."""
 
     __array_priority__ = 1000
+    fuse = True
 
     def __init__(self, t):
         B = _B()
@@ -38,31 +48,135 @@ class HipArray:
         t, _, ld = B._field(t)
         if t.ndim == 2 and t.shape[1] > 1 and ld != t.shape[0]:
             t = t.T.contiguous().T  # broadcast kernels want the columns back to back
-        self.t = t
+        self._t = t
+        self._expr = None               # pending (op, a, b) / (op, a): operands HipArray or float
+        self._meta = (int(t.shape[0]), 1 if t.ndim == 1 else int(t.shape[1]), t.ndim)
+        self._deps = weakref.WeakSet()  # pending expressions that read this array (materialised before it is written)
+
+    @classmethod
+    def _pending(cls, expr, n, nv, ndim):
+        self = cls.__new__(cls)
+        self._t = None
+        self._expr = expr
+        self._meta = (n, nv, ndim)
+        self._deps = weakref.WeakSet()
+        for leaf in self._leaves():
+            leaf._deps.add(self)
+        return self
+
+    # ---- the value: materialises a pending expression (one launch)
+    @property
+    def t(self):
+        if self._t is None:
+            n, nv, ndim = self._meta
+            out = _B().colmajor_empty(n) if ndim == 1 else _B().colmajor_empty(n, nv)
+            self._evaluate_into(out)
+            self._t, self._expr = out, None
+        return self._t
+
+    @t.setter
+    def t(self, value):
+        self._t, self._expr = value, None
+
+    def _leaves(self):
+        """Materialised arrays a pending expression reads."""
+        if self._expr is None:
+            return [self]
+        out = []
+        for x in self._expr[1:]:
+            if isinstance(x, HipArray):
+                out += x._leaves()
+        return out
+
+    def _flush_readers(self):
+        """Before this array's memory is written: evaluate the pending expressions that read it."""
+        for d in list(self._deps):
+            if d._t is None:
+                d.t  # noqa: B018 (materialises)
+        self._deps.clear()
+
+    def _emit(self, prog, arrs, scal):
+        """Postfix program of this node; returns the stack depth it needs (None: does not fit one launch)."""
+        if self._expr is None:
+            key = self._t.data_ptr()
+            for k, a in enumerate(arrs):
+                if a._t.data_ptr() == key and a._meta == self._meta:
+                    break
+            else:
+                if len(arrs) == _MAX_ARR:
+                    return None
+                arrs.append(self)
+                k = len(arrs) - 1
+            prog.append(PUSH_ARRAY | (k << 8))
+            return 1
+        op, depth, width = self._expr[0], 0, 0
+        for x in self._expr[1:]:
+            if isinstance(x, HipArray):
+                d = x._emit(prog, arrs, scal)
+                if d is None:
+                    return None
+            else:
+                if x in scal:
+                    k = scal.index(x)
+                else:
+                    if len(scal) == _MAX_SCAL:
+                        return None
+                    scal.append(x)
+                    k = len(scal) - 1
+                prog.append(PUSH_SCALAR | (k << 8))
+                d = 1
+            depth = max(depth, width + d)
+            width += 1
+        prog.append(op)
+        if len(prog) > _MAX_PROG or depth > _MAX_DEPTH:
+            return None
+        return depth
+
+    def _evaluate_into(self, out):
+        """Value of the pending expression into the tensor ``out`` (may alias an operand: the kernel is elementwise)."""
+        B = _B()
+        prog, arrs, scal = [], [], []
+        if self._emit(prog, arrs, scal) is None:
+            # too large for one launch: materialise the operands that are expressions themselves, then this node
+            for x in self._expr[1:]:
+                if isinstance(x, HipArray):
+                    x.t  # noqa: B018
+            prog, arrs, scal = [], [], []
+            if self._emit(prog, arrs, scal) is None:
+                raise RuntimeError("broadcast expression does not fit ibh_ew_eval")
+        n, nv, _ = self._meta
+        P = (C.c_int32 * len(prog))(*prog)
+        A = (C.c_void_p * max(len(arrs), 1))(*[a._t.data_ptr() for a in arrs])
+        V = (C.c_int32 * max(len(arrs), 1))(*[a._meta[1] for a in arrs])
+        S = (C.c_float * max(len(scal), 1))(*scal)
+        B._stream()
+        call("ibh_ew_eval", n, nv, len(prog), P, len(arrs), A, V, len(scal), S, c_vp(out.data_ptr()))
 
     # ---- array protocol
     @property
     def shape(self):
-        return tuple(self.t.shape)
+        n, nv, ndim = self._meta
+        return (n,) if ndim == 1 else (n, nv)
 
     @property
     def ndim(self):
-        return self.t.ndim
+        return self._meta[2]
 
     def __len__(self):
-        return self.t.shape[0]
+        return self._meta[0]
 
     @property
     def n(self):
-        return int(self.t.shape[0])
+        return self._meta[0]
 
     @property
     def nv(self):
-        return 1 if self.t.ndim == 1 else int(self.t.shape[1])
+        return self._meta[1]
 
     def similar(self):
         """``similar(a)``."""
-        return HipArray(_B()._like(self.t, self.n))
+        n, nv, ndim = self._meta
+        return HipArray(_B().colmajor_empty(n) if ndim == 1 else _B().colmajor_empty(n, nv))
 
     def copy(self):
         out = self.similar()
@@ -74,10 +188,13 @@ class HipArray:
         """``@view a[:, j]`` (1-based like the reference): aliases the parent's memory."""
         if self.ndim != 2:
             raise IndexError("col() of a vector")
-        return HipArray(self.t[:, j - 1])
+        v = HipArray(self.t[:, j - 1])
+        v._deps = self._deps   # a write through either name flushes the readers of both
+        return v
 
     def fill(self, value):
         """``a .= value``."""
+        self._flush_readers()
         _B()._stream()
         call("ibh_ew_fill", self.t.numel(), C.c_float(float(value)), c_vp(self.t.data_ptr()))
         return self
@@ -89,27 +206,47 @@ class HipArray:
         raise TypeError("scalar indexing of a HipArray; copy it back with to_host()")
 
     # ---- broadcast nodes
-    def _binary(self, op, other, reverse=False, out=None):
-        B = _B()
-        a, b = (other, self) if reverse else (self, other)
+    @staticmethod
+    def _operand(x):
+        if isinstance(x, HipArray):
+            return x
+        if isinstance(x, (int, float, np.floating, np.integer)):
+            return float(np.float32(x))
+        raise TypeError(f"cannot broadcast a HipArray with {type(x).__name__} (convert with HipArray(...))")
 
-        def operand(x):
-            if isinstance(x, HipArray):
-                return x, 0.0
-            if isinstance(x, (int, float, np.floating, np.integer)):
-                return None, float(x)
-            raise TypeError(f"cannot broadcast a HipArray with {type(x).__name__} (convert with HipArray(...))")
-        (fa, sa), (fb, sb) = operand(a), operand(b)
-        fields = [f for f in (fa, fb) if f is not None]
+    def _binary(self, op, other, reverse=False, out=None):
+        a, b = (other, self) if reverse else (self, other)
+        a, b = self._operand(a), self._operand(b)
+        fields = [f for f in (a, b) if isinstance(f, HipArray)]
         n = fields[0].n
         nv = max(f.nv for f in fields)
         for f in fields:
             if f.n != n or f.nv not in (1, nv):
                 raise ValueError(f"shapes {tuple(x.shape for x in fields)} do not broadcast")
-        if out is None:
-            out = HipArray(B.colmajor_empty(n) if nv == 1 and all(f.ndim == 1 for f in fields) else B.colmajor_empty(n, nv))
-        elif out.n != n or out.nv != nv:
+        ndim = 1 if nv == 1 and all(f.ndim == 1 for f in fields) else 2
+        if out is not None and (out.n != n or out.nv != nv):
             raise ValueError("in-place broadcast changes the shape")
+        if HipArray.fuse:
+            node = HipArray._pending((op, a, b), n, nv, ndim)
+            if out is None:
+                return node
+            # `out .= out op other`: the fused expression straight into out's memory
+            out.t  # noqa: B018 (out is an operand: it must hold a value)
+            readers = [d for d in out._deps if d is not node]
+            for d in readers:
+                if d._t is None:
+                    d.t  # noqa: B018
+            node._evaluate_into(out._t)
+            node._t, node._expr = out._t, None
+            out._deps.clear()
+            return out
+        B = _B()
+        if out is None:
+            out = HipArray(B.colmajor_empty(n) if ndim == 1 else B.colmajor_empty(n, nv))
+        else:
+            out._flush_readers()
+        fa, sa = (a, 0.0) if isinstance(a, HipArray) else (None, a)
+        fb, sb = (b, 0.0) if isinstance(b, HipArray) else (None, b)
         B._stream()
         call("ibh_ew_binary", op, n, nv, c_vp(fa.t.data_ptr()) if fa is not None else c_vp(None),
              fa.nv if fa is not None else 0, C.c_float(sa), c_vp(fb.t.data_ptr()) if fb is not None else c_vp(None),
@@ -117,6 +254,9 @@ class HipArray:
         return out
 
     def _unary(self, op):
+        if HipArray.fuse:
+            n, nv, ndim = self._meta
+            return HipArray._pending((op, self), n, nv, ndim)
         out = self.similar()
         _B()._stream()
         call("ibh_ew_unary", op, self.t.numel(), c_vp(self.t.data_ptr()), c_vp(out.t.data_ptr()))

@@ -108,6 +108,15 @@ int ibh_ew_binary(int op, int64_t n, int nv, const float* a, int nva, float sa, 
 int ibh_ew_unary(int op, int64_t total, const float* a, float* out);
 int ibh_ew_fill(int64_t total, float value, float* out);
 int ibh_ew_reduce(int op, int64_t total, const float* a, float* out_device);
+/* A whole broadcast expression in ONE launch -- what Julia's broadcast fusion makes of
+ * `@. (uL + uR) * Cf / 2 + abs(Cf) * (uL - uR) / 2` (test/advection.jl:76-80): a postfix program over up to 8 arrays
+ * (fields (n, nv) or column vectors, nv* = 1) and 8 scalars; instruction = opcode | operand << 8 with opcodes
+ * IBH_EW_ADD..MIN, IBH_EW_ABS..SQRT, IBH_EW_PUSH_ARRAY (operand = array index), IBH_EW_PUSH_SCALAR; at most 48
+ * instructions, stack depth 8.  Every node is evaluated in Float32 exactly as the one-node kernels do (no contraction),
+ * so the result equals the node-by-node evaluation bit for bit.  `out` may alias an array. */
+enum { IBH_EW_PUSH_ARRAY = 32, IBH_EW_PUSH_SCALAR = 33 };
+int ibh_ew_eval(int64_t n, int nv, int nprog, const int32_t* prog, int narr, const float* const* arrays,
+                const int32_t* arr_nv, int nscal, const float* scalars, float* out);
 
 /* Measurement switches of the kernels (A/B runs inside one process); key "quad_variant": variant of the quad sweep. */
 int ibh_set_tuning(const char* key, int value);

@@ -139,9 +139,83 @@ _node(f, a) = a isa HipArray ? _ew(f, a) : f(a)
 _node(f, a, b) = _ew(f, a, b)
 _node(f::Union{typeof(+), typeof(*)}, a, b, c, rest...) = _node(f, _ew(f, a, b), c, rest...)
 
-Base.copy(bc::Base.Broadcast.Broadcasted{HipStyle}) = _eval(bc)
+# ---- the whole (fused) Broadcasted tree as ONE launch: a postfix program for ibh_ew_eval (at most 48 instructions,
+# 8 arrays, 8 scalars, stack depth 8); n-ary + and * fold left like Julia does.  `nothing` = does not fit / unsupported
+# node: the caller falls back to the node-by-node evaluation above (same bits).
+const EW_PUSH_ARRAY, EW_PUSH_SCALAR = Cint(32), Cint(33)
+mutable struct _Prog
+    code::Vector{Int32}
+    arrs::Vector{HipArray}
+    scal::Vector{Float32}
+end
+function _push!(P::_Prog, a::HipArray)
+    k = findfirst(x -> x.ptr == a.ptr && size(x) == size(a), P.arrs)
+    if isnothing(k)
+        length(P.arrs) == 8 && return nothing
+        push!(P.arrs, a)
+        k = length(P.arrs)
+    end
+    push!(P.code, EW_PUSH_ARRAY | Int32((k - 1) << 8))
+    1
+end
+function _push!(P::_Prog, x::Number)
+    v = Float32(x)
+    k = findfirst(==(v), P.scal)
+    if isnothing(k)
+        length(P.scal) == 8 && return nothing
+        push!(P.scal, v)
+        k = length(P.scal)
+    end
+    push!(P.code, EW_PUSH_SCALAR | Int32((k - 1) << 8))
+    1
+end
+_push!(P::_Prog, x::Base.RefValue) = _push!(P, x[])
+_push!(P::_Prog, x) = nothing
+function _push!(P::_Prog, bc::Base.Broadcast.Broadcasted)
+    f, args = bc.f, bc.args
+    if length(args) == 1
+        haskey(_unop, f) || return nothing
+        d = _push!(P, args[1])
+        isnothing(d) && return nothing
+        push!(P.code, _unop[f])
+        return d
+    end
+    (haskey(_binop, f) && (length(args) == 2 || f === (+) || f === (*))) || return nothing
+    depth = _push!(P, args[1])
+    isnothing(depth) && return nothing
+    for a in args[2:end]
+        d = _push!(P, a)
+        isnothing(d) && return nothing
+        depth = max(depth, 1 + d)
+        push!(P.code, _binop[f])
+    end
+    depth
+end
+"Evaluate `bc` into `dest` (or a new array) with one `ibh_ew_eval`; `nothing` if the tree does not fit one program."
+function _fused(bc::Base.Broadcast.Broadcasted, dest::Union{HipArray, Nothing})
+    P = _Prog(Int32[], HipArray[], Float32[])
+    depth = _push!(P, bc)
+    (isnothing(depth) || depth > 8 || length(P.code) > 48 || isempty(P.arrs)) && return nothing
+    big = P.arrs[argmax(map(length, P.arrs))]
+    n, k = _rows(big), nv(big)
+    all(a -> _rows(a) == n && (nv(a) == k || nv(a) == 1), P.arrs) || return nothing
+    o = isnothing(dest) ? similar(big) : dest
+    (size(o, 1) == n && nv(o) == k) || return nothing
+    ptrs = Ptr{Cvoid}[a.ptr for a in P.arrs]
+    nvs = Int32[nv(a) for a in P.arrs]
+    GC.@preserve P ptrs nvs check(ccall((:ibh_ew_eval, lib), Cint,
+        (Int64, Cint, Cint, Ptr{Int32}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Int32}, Cint, Ptr{Cfloat}, Ptr{Cvoid}),
+        n, k, length(P.code), P.code, length(ptrs), ptrs, nvs, length(P.scal), P.scal, o.ptr))
+    o
+end
+
+function Base.copy(bc::Base.Broadcast.Broadcasted{HipStyle})
+    r = _fused(bc, nothing)
+    isnothing(r) ? _eval(bc) : r
+end
 function Base.copyto!(dest::HipArray, bc::Base.Broadcast.Broadcasted{HipStyle})
-    # `dest .= f.(dest, x)` / `dest .-= x`: the top node writes straight into dest
+    # `dest .= f.(dest, x)` / `dest .-= x`: one launch straight into dest (elementwise: dest may be an operand)
+    isnothing(_fused(bc, dest)) || return dest
     if length(bc.args) == 2 && haskey(_binop, bc.f)
         a, b = map(_eval, bc.args)
         _ew(bc.f, a, b, dest)

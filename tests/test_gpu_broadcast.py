@@ -103,3 +103,43 @@ def test_advection_closure_verbatim(adv_domains):
         ibamd.impose_bc(lambda b, ui: ui.copy(), dp, "outlet", dev)
         ug = dev.to_host()
         assert rel_inf(ug, uo) <= 1e-5
+
+
+def test_fused_broadcast_equals_node_by_node():
+    """A broadcast expression runs as ONE launch (ibh_ew_eval, Julia's broadcast fusion); evaluated node by node
+    (HipArray.fuse = False: ibh_ew_binary / ibh_ew_unary) it gives the same bits.  In-place forms, column-vector
+    operands, scalars on either side, an expression too large for one program, and a write to an operand while an
+    expression that reads it is still pending."""
+    rng = np.random.default_rng(0)
+    n = 10007
+    A, B, Cc = (rng.uniform(-2, 2, (n, 3)).astype(f32) for _ in range(3))
+    v = rng.uniform(0.5, 2, n).astype(f32)
+
+    def run():
+        a, b, c, w = ibamd.HipArray(A), ibamd.HipArray(B), ibamd.HipArray(Cc), ibamd.HipArray(v)
+        r1 = (a + b) * c / 2 + abs(c) * (a - b) / 2               # advection.jl:76-80
+        r2 = (3.0 - a * w) / (abs(b) + 1.5) - (-c).maximum_with(w).minimum_with(2.0)
+        r3 = (w * w + 1.0).sqrt()
+        big = a
+        for k in range(30):                                      # 60 nodes: more than one program holds
+            big = big * 0.99 + b * (0.01 * (k + 1))
+        acc = ibamd.HipArray(A.copy())
+        acc -= r1 * 0.25
+        acc += w
+        acc *= 0.5
+        pend = a + 1.0                                           # pending, reads a ...
+        a.fill(7.0)                                              # ... a is overwritten: pend must hold the old values
+        return [x.to_host() for x in (r1, r2, r3, big, acc, pend)]
+
+    ibamd.HipArray.fuse = True
+    fused = run()
+    ibamd.HipArray.fuse = False
+    try:
+        nodes = run()
+    finally:
+        ibamd.HipArray.fuse = True
+    for f, g in zip(fused, nodes):
+        assert np.array_equal(f, g)
+    ref1 = (A + B) * Cc / f32(2) + np.abs(Cc) * (A - B) / f32(2)
+    assert np.array_equal(fused[0], ref1.astype(f32))
+    assert np.array_equal(fused[5], A + f32(1.0))
