@@ -38,6 +38,9 @@ WORKLOADS = {
     "sphere3d_4.6M": 0.03,
     # BASELINE.json configs[3] shape at ~8 M cells: sphere of radius 1.4, immersed-boundary ghosts kept (--step config4)
     "sphere3d_8M": (0.03, 1.4),
+    # BASELINE.json configs[4] size (the surface spacing snaps to octree levels: 4.6 M -> 15 M; the radius does the rest)
+    "sphere3d_15M": 0.015,
+    "sphere3d_33M": (0.015, 1.5),
 }
 
 

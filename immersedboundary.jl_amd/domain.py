@@ -508,7 +508,7 @@ def ghosts_and_projections_hcube(hfaces, hc_origin, hc_widths, centers, widths, 
 
 def knn_sorted(tree, Xq, k):
     """k nearest neighbours of the rows of ``Xq (n, nd)`` ordered by (distance, index)."""
-    d, idx = tree.query(np.ascontiguousarray(Xq, dtype=np.float64), k=k)
+    d, idx = tree.query(np.ascontiguousarray(Xq, dtype=np.float64), k=k, workers=-1)
     if k == 1:
         d, idx = d[:, None], idx[:, None]
     order = np.lexsort((idx, d), axis=1)

@@ -12,6 +12,10 @@ say 3d; $B --workload sphere3d_4.6M > $O/bench_3d_4.6M.json 2>>$O/bench.err
 say 3d euler; $B --steps 100 --warmup 10 --residual euler --workload sphere3d_1.6M > $O/bench_3d_euler_1.6M.json 2>>$O/bench.err
 say config4; $B --workload sphere3d_8M --residual euler --step config4 --steps 20 --warmup 3 --repeats 5 > $O/bench_config4_8M.json 2>>$O/bench.err
 say config5; $B --workload sphere3d_4.6M --residual euler --step config5 --steps 5 --warmup 1 --repeats 3 > $O/bench_config5_4.6M.json 2>>$O/bench.err
+say config5 33M; bash scripts/with_heartbeat.sh $O/progress.log $B --workload sphere3d_33M --residual euler --step config5 --steps 3 --warmup 1 --repeats 2 > $O/bench_config5_33M.json 2>>$O/bench.err
+say 3d 33M; bash scripts/with_heartbeat.sh $O/progress.log $B --workload sphere3d_33M --steps 50 --warmup 5 --repeats 5 > $O/bench_3d_33M.json 2>>$O/bench.err
+say 3d euler 33M; bash scripts/with_heartbeat.sh $O/progress.log $B --workload sphere3d_33M --residual euler --steps 20 --warmup 3 --repeats 5 > $O/bench_3d_euler_33M.json 2>>$O/bench.err
+say closure; python3 scripts/probe_closure.py > $O/probe_closure.json 2>>$O/bench.err
 say 28M; $B --workload rae2822_28M --steps 50 --warmup 5 --repeats 5 > $O/bench_28M.json 2>>$O/bench.err
 say probes 3d / euler; python3 scripts/probe_3d.py > $O/probe_3d_4.6M.json 2>>$O/bench.err
 python3 scripts/probe_euler.py > $O/probe_euler.json 2>>$O/bench.err
