@@ -46,3 +46,24 @@ def test_compute_fails_loudly_without_gpu():
     import numpy as np
     with pytest.raises(_lib.IbhError):
         ibamd.hip(np.zeros(4, dtype=np.float32))
+
+
+def test_ew_eval_validates_its_program_on_the_host():
+    """ibh_ew_eval checks the postfix program before anything is launched (no GPU needed to be told it is malformed)."""
+    lib = _lib.load()
+    PUSH_A, PUSH_S, ADD, ABS = 32, 33, 0, 16
+    buf = (ctypes.c_float * 4)()
+    arrs = (ctypes.c_void_p * 1)(ctypes.addressof(buf))
+    nvs = (ctypes.c_int32 * 1)(1)
+    sc = (ctypes.c_float * 1)(2.0)
+
+    def run(prog, narr=1, nscal=1):
+        P = (ctypes.c_int32 * len(prog))(*prog)
+        return lib.ibh_ew_eval(0, 1, len(prog), P, narr, arrs, nvs, nscal, sc, ctypes.addressof(buf))
+
+    assert run([PUSH_A, PUSH_S, ADD]) == 0                     # n = 0 rows: valid program, nothing to launch
+    assert run([PUSH_A, ABS, PUSH_S | (0 << 8), ADD]) == 0
+    for bad, what in (([ADD], b"two operands"), ([PUSH_A, PUSH_A], b"exactly one value"), ([PUSH_A | (3 << 8)], b"array"),
+                      ([PUSH_S | (1 << 8)], b"scalar"), ([PUSH_A, 99], b"unknown"), ([PUSH_A] * 9 + [ADD] * 8, b"deeper"),
+                      ([PUSH_A, ABS] * 25, b"48 instructions")):
+        assert run(bad) != 0 and what in lib.ibh_last_error(), (bad, lib.ibh_last_error())
