@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
                                                          const int32_t* __restrict__ etab,
                                                          const int32_t* __restrict__ dtab,
                                                          const int32_t* __restrict__ singles, int32_t ns, int32_t nwgs,
-                                                         int32_t singles_first) {
+                                                         int32_t singles_first, int32_t siters) {
     __shared__ __attribute__((aligned(16))) float lds[QUAD_WG_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t slot = blockIdx.x * WPB + wave;
@@ -623,10 +623,12 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
                                          STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr);
     } else {
         const int32_t wgs = singles_first ? (int32_t)blockIdx.x : (int32_t)blockIdx.x - nwgq;
-        const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(wgs, nwgs) * WPB + wave);
-        if (first < ns)
-            blk2::sweep_adv<DT>(blocks, htab, etab, dtab, singles, first, WPB, 1, u, C, ldc, ud,
+        const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(wgs, nwgs) * (WPB * siters) + wave);
+        if (first < ns) {
+            const int32_t nb = __builtin_amdgcn_readfirstlane(min(siters, (ns - first + WPB - 1) / WPB));
+            blk2::sweep_adv<DT>(blocks, htab, etab, dtab, singles, first, WPB, nb, u, C, ldc, ud,
                                 lds + wave * BLK2_SWEEP_LDS, lane);
+        }
     }
     if constexpr (STAMP) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -888,7 +890,7 @@ const int ibh_sweep_iters = getenv("IBH_SWEEP_ITERS") ? atoi(getenv("IBH_SWEEP_I
 const int ibh_quad = getenv("IBH_QUAD") ? atoi(getenv("IBH_QUAD")) : 1;
 // ibh_set_tuning(key, v): "quad_variant" 4 = wave time stamps (scripts/wave_timeline.py); "quad_parts" 1 / 2 = only the
 // quads / only the single blocks of a quad sweep (measurement); "quad_singles_first" = grid order
-int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_first = 0;
+int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_first = 0, ibh_quad_singles_iters = 1;
 
 PartView view(const ibh_part* p) {
     PartView v;
@@ -939,6 +941,7 @@ int ibh_set_tuning(const char* key, int value) {
     if (!strcmp(key, "quad_variant")) ibh_quad_variant = value;
     else if (!strcmp(key, "quad_parts")) ibh_quad_parts = value;
     else if (!strcmp(key, "quad_singles_first")) ibh_quad_singles_first = value;
+    else if (!strcmp(key, "quad_singles_iters")) ibh_quad_singles_iters = value;
     else return ibh_fail(-1, "ibh_set_tuning: unknown key", __FILE__, __LINE__);
     return 0;
 }
@@ -1021,12 +1024,13 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         if (q1 - q0 + s1 - s0 <= 0) return;
         if (ibh_quad_parts == 1) s1 = s0;  // measurement: quads only / single blocks only
         if (ibh_quad_parts == 2) q1 = q0;
-        const int32_t nwgq = (q1 - q0 + WPB - 1) / WPB, nwgs = (s1 - s0 + WPB - 1) / WPB;
+        const int32_t siters = ibh_quad_singles_iters > 0 ? ibh_quad_singles_iters : 1;
+        const int32_t nwgq = (q1 - q0 + WPB - 1) / WPB, nwgs = (s1 - s0 + WPB * siters - 1) / (WPB * siters);
         if (nwgq + nwgs == 0) return;
 #define QUAD_LAUNCH(DT, STAMP, ...)                                                                                    \
     hipLaunchKernelGGL((k_sweep_quad<DT, STAMP, ##__VA_ARGS__>), dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C,              \
                        (uint32_t)ldc, ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq,            \
-                       p->blocks2, p->htab, p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs, ibh_quad_singles_first)
+                       p->blocks2, p->htab, p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs, ibh_quad_singles_first, siters)
         if (p->n_dt > 0) QUAD_LAUNCH(true, false);
         else if (ibh_quad_variant == 4) QUAD_LAUNCH(false, true);
         else if (ibh_quad_variant == 126) QUAD_LAUNCH(false, false, 126);  // A/B: seven 4-byte gathers

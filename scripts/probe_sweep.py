@@ -86,6 +86,13 @@ if os.environ.get("QUAD_TUNE"):  # same-process A/B: alternate, keep the best me
             _lib.call("ibh_set_tuning", b"quad_parts", parts)
             _lib.call("ibh_set_tuning", b"quad_singles_first", sf)
             best[name_] = min(best.get(name_, 1e9), sweep_time())
+    _lib.call("ibh_set_tuning", b"quad_parts", 3)
+    _lib.call("ibh_set_tuning", b"quad_singles_first", 0)
+    for _ in range(3):
+        for it in (1, 2, 3):
+            _lib.call("ibh_set_tuning", b"quad_singles_iters", it)
+            best[f"both_singles_{it}_per_wave"] = min(best.get(f"both_singles_{it}_per_wave", 1e9), sweep_time())
+    _lib.call("ibh_set_tuning", b"quad_singles_iters", 1)
     _lib.call("ibh_set_tuning", b"quad_parts", 1)
     for _ in range(3):
         for name_, var in (("quads_only_paired_gathers(default)", 0), ("quads_only_seven_gathers", 126), ("quads_only_k0+ends", 85), ("quads_only_hu0_hd0_ends", 69),
