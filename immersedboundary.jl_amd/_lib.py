@@ -155,7 +155,7 @@ def load():
 
 
 def call(name, *args):
-    lib = load()
+    lib = _lib if _lib is not None else load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise IbhError(f"{name} failed (code {rc}): {lib.ibh_last_error().decode()}")

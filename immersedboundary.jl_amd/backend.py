@@ -42,19 +42,34 @@ IBH_NO_QUAD = 1024
 _initialised = {}
 
 
+_have_gpu = None
+
+
 def _dev():
-    if not torch.cuda.is_available():
+    global _have_gpu
+    if _have_gpu is None:
+        _have_gpu = bool(torch.cuda.is_available())
+    if not _have_gpu:
         raise _lib.IbhError("no HIP device visible: the ImmersedBoundary hot path runs on the GPU only "
                             "(there is no CPU fallback)")
     d = torch.cuda.current_device()
-    if d not in _initialised:
+    dev = _initialised.get(d)
+    if dev is None:
         call("ibh_init", d)
-        _initialised[d] = True
-    return torch.device("cuda", d)
+        dev = _initialised[d] = torch.device("cuda", d)
+    return dev
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _stream():
-    call("ibh_set_stream", c_vp(torch.cuda.current_stream().cuda_stream))
+    """The library launches on torch's current stream (asked for through the raw-handle query: the operators of a user
+    closure are host-bound, and `torch.cuda.current_stream()` alone costs as much as a launch)."""
+    if _raw_stream is not None:
+        call("ibh_set_stream", c_vp(_raw_stream(torch.cuda.current_device())))
+    else:
+        call("ibh_set_stream", c_vp(torch.cuda.current_stream().cuda_stream))
 
 
 def _ptr(t):
@@ -103,18 +118,28 @@ def _hipaware(fn):
     called with one: the Python form of Julia's dispatch on the array type (julia/IBHip.jl)."""
     import functools
 
+    H = {}
+
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
-        from .hiparray import HipArray, rewrap, unwrap
+        if not H:
+            from . import hiparray
+            H["A"], H["rewrap"] = hiparray.HipArray, hiparray.rewrap
+        HipArray = H["A"]
+        hit = False
 
         def un(x):
+            nonlocal hit
+            if isinstance(x, HipArray):
+                hit = True
+                return x.t
             if isinstance(x, tuple):
                 return tuple(un(v) for v in x)
-            return unwrap(x)
-        hit = any(isinstance(a, HipArray) or (isinstance(a, tuple) and any(isinstance(v, HipArray) for v in a))
-                  for a in list(args) + list(kwargs.values()))
-        out = fn(*[un(a) for a in args], **{k: un(v) for k, v in kwargs.items()})
-        return rewrap(out, hit)
+            return x
+        a = [un(x) for x in args]
+        k = {key: un(v) for key, v in kwargs.items()} if kwargs else kwargs
+        out = fn(*a, **k)
+        return H["rewrap"](out, True) if hit else out
     return wrapper
 
 

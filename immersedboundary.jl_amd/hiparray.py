@@ -19,9 +19,15 @@ ADD, SUB, MUL, DIV, MAX, MIN, SUM = range(7)
 ABS, NEG, SQRT, COPY = 16, 17, 18, 19
 
 
+_backend = None
+
+
 def _B():
-    from . import backend
-    return backend
+    global _backend
+    if _backend is None:
+        from . import backend
+        _backend = backend
+    return _backend
 
 
 PUSH_ARRAY, PUSH_SCALAR = 32, 33
