@@ -234,3 +234,52 @@ def test_vectorised_surface_projection_matches_the_per_ghost_loop():
     dv, dl = D._dist_cols(Pv, Xg), D._dist_cols(Pl, Xg)
     assert np.array_equal(dv <= diams[pick] * ratio, dl <= diams[pick] * ratio)
     assert (dv <= diams[pick] * ratio).sum() > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["one_block", "eight_blocks", "corner_refined"])
+def test_3d_single_kernels_on_small_octrees(kind):
+    """Edge cases of the 3-D single-kernel sweeps: a domain of ONE 8^3 block (six MIRROR sides), 2 x 2 x 2 uniform blocks
+    (SAME + MIRROR), and a refinement in a corner of the box (FINE / COARSE sides on domain-boundary blocks, rim cells on
+    the boundary).  Strip form, thread-per-cell form and the Euler kernel against the face-list kernels."""
+    from ibamd import _lib
+    f32_ = np.float32
+    regions = {"one_block": [],
+               "eight_blocks": [(Ball(np.array([0.0, 0.0, 0.0]), 5.0), f32_(0.3))],
+               "corner_refined": [(Ball(np.array([-2.0, -2.0, -2.0]), 0.1), f32_(0.1))]}[kind]
+    msh = Mesh(f32_([-2, -2, -2]), f32_([4, 4, 4]), block_size=8, refinement_regions=regions)
+    assert len(msh) == {"one_block": 512, "eight_blocks": 4096, "corner_refined": 32768}[kind]
+    dom = ibamd.Domain(msh, max_partition_size=10 ** 9, boundaries=False)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    info = dpart.info
+    assert info["fusable_blocks"] == info["full_blocks"] == len(msh) // 512 and info["irregular_cells"] == 0
+    if kind == "one_block":
+        assert info["sides_mirror"] == 6
+    if kind == "corner_refined":
+        assert info["sides_fine"] > 0 and info["sides_coarse"] > 0
+    rng = np.random.default_rng(2)
+    x = part.centers
+    n = x.shape[0]
+    u = (np.sin(2 * x[:, 0]) * np.cos(3 * x[:, 1]) + 0.3 * x[:, 2] + 0.1 * rng.uniform(-1, 1, n)).astype(f32_)
+    C = np.stack([np.ones(n, f32_), f32_(0.5) + f32_(0.1) * rng.uniform(-1, 1, n).astype(f32_), f32_(-0.25) * np.ones(n, f32_)],
+                 axis=1)
+    du, dC = ibamd.hip(u), ibamd.hip(C)
+    gen = ibamd.to_host(ibamd.residual_advection(dpart, du, dC, flags=ibamd.IBH_FORCE_GENERAL))
+    strip = ibamd.to_host(ibamd.residual_advection(dpart, du, dC))
+    _lib.call("ibh_set_tuning", b"quad_variant", 512)
+    try:
+        cellk = ibamd.to_host(ibamd.residual_advection(dpart, du, dC))
+    finally:
+        _lib.call("ibh_set_tuning", b"quad_variant", 0)
+    assert rel_inf(strip, gen) <= 1e-5 and rel_inf(cellk, gen) <= 1e-5 and rel_inf(strip, cellk) <= 2e-6
+    P = np.stack([f32_(1e5) * (1 + f32_(0.05) * rng.uniform(-1, 1, n)), f32_(288.15) * (1 + f32_(0.05) * rng.uniform(-1, 1, n)),
+                  f32_(100.0) * (1 + f32_(0.1) * rng.uniform(-1, 1, n)), f32_(60.0) * (1 + f32_(0.1) * rng.uniform(-1, 1, n)),
+                  f32_(-40.0) * (1 + f32_(0.1) * rng.uniform(-1, 1, n))], axis=1).astype(f32_)
+    one = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P)))
+    egen = ibamd.to_host(ibamd.residual_euler_hll(dpart, ibamd.hip(P), flags=ibamd.IBH_FORCE_GENERAL))
+    for v in range(5):
+        assert rel_inf(one[:, v], egen[:, v]) <= 1e-5, v
+    g3 = ibamd.cell_gradient(dpart, du)
+    for d in (1, 2, 3):
+        assert rel_inf(ibamd.to_host(g3[d - 1]), ibamd.to_host(ibamd.cell_gradient(dpart, du, d))) <= 5e-6
