@@ -185,6 +185,13 @@ def test_3d_single_kernel_sweeps_at_bench_size():
     for got in (strip, cellk, two):
         assert rel_inf(got, exp) <= 1e-5
     assert rel_inf(strip, cellk) <= 2e-6 and rel_inf(strip, two) <= 2e-6
+    # per cell (as in the 2-D test above): error relative to the local scale |ref| + |u| / h
+    e64, s64 = exp.astype(np.float64), strip.astype(np.float64)
+    rel = np.abs(s64 - e64) / (np.abs(e64) + np.abs(u.astype(np.float64)) / part.spacing.min(axis=1).astype(np.float64))
+    pct = {f"p{q}": float(np.percentile(rel, q)) for q in (50, 99, 99.9)}
+    pct["max"] = float(rel.max())
+    print("\nper-cell relative error of the 3-D strip sweep (1.67 M cells):", pct)
+    assert pct["p99.9"] <= 2e-6 and pct["max"] <= 5e-5
     const = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(np.full(n, 3.25, dtype=f32)), dC))
     assert np.array_equal(const, np.zeros(n, dtype=f32))            # constant field: exactly zero
     r4 = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(f32(4.0) * u), dC))
