@@ -169,6 +169,11 @@ def main():
                     help="N > 1: exchange on a second stream beside the interior blocks, boundary blocks after it. "
                          "Off by default: inside a HIP graph the cross-stream fork/join costs ~15 us per step "
                          "(scripts/mixed_ab.py), far more than the ~3 us it hides on partitions of this size")
+    ap.add_argument("--fused-step", action="store_true",
+                    help="N > 1: exchange + image-only sweep as ONE launch (XgmiHalo.fused_step: exchange workgroups "
+                         "beside the interior quads, boundary waves wait for the unpacked skirt), used where it "
+                         "reproduces the two-launch step bit for bit.  Opt-in: rehearsed for correctness with all "
+                         "ranks on one GPU, where its timing means nothing; not yet timed on separate GPUs")
     ap.add_argument("--no-overlap", action="store_true", help="(default since the measurement above; kept for old command lines)")
     ap.add_argument("--halo", default="auto", choices=["auto", "rccl", "xgmi"],
                     help="N > 1 skirt exchange: rccl = grouped send/recv (eager launches); xgmi = direct peer writes "
@@ -294,6 +299,7 @@ def main():
     hx = None
     comm_stream = None
     halo_kind = None
+    fused_step = False
     if world > 1:
         from ibamd.halo import (HaloExchange, HaloPlan, XgmiHalo, euler_sweep_overlapped, sweep_overlapped,
                                 verify_exchangers)
@@ -320,6 +326,29 @@ def main():
         overlap = (args.overlap and not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
                    and (not euler or image_only))
         comm_stream = torch.cuda.Stream() if overlap else None
+        # exchange + image-only quad sweep as ONE launch (XgmiHalo.fused_step: the exchange workgroups run beside the
+        # interior quads), taken when it reproduces exchange-then-sweep bit for bit on every rank
+        if (args.fused_step and halo_kind == "xgmi-direct" and image_only and not euler and comm_stream is None
+                and flags == ibamd.IBH_IMAGE_ONLY):
+            ok_f = 0
+            try:
+                ref_f = torch.zeros_like(ud)
+                hx.exchange(u)
+                ibamd.residual_advection(dpart, u, C, out=ref_f, flags=flags)
+                got_f = torch.zeros_like(ud)
+                torch.cuda.synchronize()
+                dist.barrier()
+                hx.fused_step(dpart, u, C, got_f)
+                torch.cuda.synchronize()
+                ok_f = int(bool(torch.equal(got_f, ref_f)))
+            except Exception as e:  # noqa: BLE001 -- partitions the fused kernel does not cover
+                if rank == 0:
+                    print(f"[bench] fused exchange + sweep step unavailable ({e})", file=sys.stderr)
+            tf = torch.tensor([ok_f], dtype=torch.int32, device=u.device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tf, op=dist.ReduceOp.MIN)
+            fused_step = bool(tf.item()) and hx.healthy()
+            if fused_step:
+                halo_kind = "xgmi-direct, fused with the sweep (one launch per step)"
 
     def sweep(extra=0):
         if euler:
@@ -359,6 +388,8 @@ def main():
             sweep()
         elif hx is None:
             sweep()
+        elif fused_step:
+            hx.fused_step(dpart, u, C, ud)
         elif comm_stream is not None and euler:
             euler_sweep_overlapped(hx, dpart, P, Rres, comm_stream, flags=flags)
         elif comm_stream is not None:
@@ -376,7 +407,7 @@ def main():
     # The sweep is ~10 us of GPU work: a Python/ctypes launch per step would be host-bound, so on one GPU
     # the step loop is captured into HIP graphs of `graph_batch` sweeps each (every sweep still runs in full).
     # (N > 1: only with the xgmi exchange, which is kernels only; RCCL calls are launched eagerly.)
-    graphable = (world == 1 or halo_kind == "xgmi-direct") and not (config4 or config5)   # (closures launch eagerly)
+    graphable = (world == 1 or (halo_kind or "").startswith("xgmi-direct")) and not (config4 or config5)   # (closures launch eagerly)
     batch = args.graph_batch if (graphable and args.graph_batch > 0) else 0
     graph = None
     side = torch.cuda.Stream()
@@ -424,7 +455,7 @@ def main():
     dt = dts[len(dts) // 2]
     halo_timeouts = None
     if world > 1:
-        if halo_kind == "xgmi-direct":
+        if (halo_kind or "").startswith("xgmi-direct"):
             # a wait kernel that hit its spin bound unpacked stale skirt values: the figure would be for a wrong
             # residual.  Checked after the timed region (collective); such a run does not publish a number.
             halo_timeouts = 0 if hx.healthy() else 1

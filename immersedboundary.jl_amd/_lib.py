@@ -103,6 +103,8 @@ _SIGS = {
     "ibh_halo_pull": [c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, C.c_uint32],
     "ibh_halo_exchange": [c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp,
                           c_vp, C.c_uint32],
+    "ibh_step_advection_xgmi": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                c_vp, c_vp, c_vp, C.c_uint32, c_vp],
     "ibh_axpy_clamped": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_axpy": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_sumsq": [c_i64, c_vp, c_vp],

@@ -487,6 +487,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 #include "ibh_quad2d.h"
 #include "ibh_quad2d_euler.h"
 #include "ibh_strip3d.h"
+#include "ibh_halo_dev.h"
 #include "ibh_block3d.h"
 
 namespace {
@@ -634,6 +635,76 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
         __builtin_amdgcn_s_waitcnt(0);
         dbg_stamp(slot, 1, __builtin_amdgcn_s_memrealtime());
         dbg_stamp(slot, 3, (unsigned long long)isq);
+    }
+}
+
+// One step of a rank of a multi-GPU run in ONE launch: the xGMI halo exchange of u (ibh_halo_dev.h) and the image-only
+// quad sweep.  Grid = [E exchange workgroups | interior quads | interior single blocks | boundary quads | boundary
+// single blocks]: the exchange workgroups push this rank's skirt rows to the peers, wait for the peers' rows and unpack
+// them while the interior waves -- which read no skirt cell -- already compute; a boundary wave first waits (bounded
+// spin) until every exchange workgroup of ITS launch has unpacked.  fstate (device, zeroed once): [0] tickets of the
+// boundary workgroups (launch index = ticket / boundary workgroups per launch: the grid of an exchanger never
+// changes), [1] exchange workgroups done.  A time-out sets bit 1 of state[2] (XgmiHalo.healthy()).
+template <bool DT>
+__global__ __launch_bounds__(64 * WPB) void k_step_quad(float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
+                                                        float* __restrict__ ud, const QuadDesc2* __restrict__ qd,
+                                                        const int32_t* __restrict__ qtab, int32_t nq_int, int32_t nq,
+                                                        const BlockDesc2* __restrict__ blocks,
+                                                        const int32_t* __restrict__ htab,
+                                                        const int32_t* __restrict__ etab,
+                                                        const int32_t* __restrict__ dtab,
+                                                        const int32_t* __restrict__ singles, int32_t ns_int, int32_t ns,
+                                                        const int32_t* __restrict__ send_all,
+                                                        const int32_t* __restrict__ recv_all,
+                                                        const float* __restrict__ src0, const float* __restrict__ src1,
+                                                        XchgArgs A, uint32_t* __restrict__ state, uint32_t max_spins,
+                                                        int32_t E, unsigned long long* __restrict__ fstate) {
+    __shared__ __attribute__((aligned(16))) float lds[QUAD_WG_LDS];
+    const int32_t b0 = (int32_t)blockIdx.x;
+    if (b0 < E) {
+        halo_exchange_wg(u, 1, 0, send_all, recv_all, src0, src1, A, state, max_spins, b0, E);
+        __threadfence();  // the unpacked skirt rows before the count
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&fstate[1], 1ull);
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t nwg_qi = (nq_int + WPB - 1) / WPB, nwg_si = (ns_int + WPB - 1) / WPB;
+    const int32_t nwg_qb = (nq - nq_int + WPB - 1) / WPB, nwg_sb = (ns - ns_int + WPB - 1) / WPB;
+    int32_t b = b0 - E;
+    const bool boundary = b >= nwg_qi + nwg_si;
+    if (boundary) {
+        __shared__ unsigned long long want;
+        if (threadIdx.x == 0) {
+            const unsigned long long t = atomicAdd(&fstate[0], 1ull);
+            want = (t / (unsigned long long)(nwg_qb + nwg_sb) + 1ull) * (unsigned long long)E;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const unsigned long long w = want;
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&fstate[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < w) {
+                if (++spins >= max_spins) {  // bounded: every wave reaches the exit
+                    atomicOr(&state[2], 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __threadfence();  // acquire: the loads below see the unpacked rows
+        b -= nwg_qi + nwg_si;
+    }
+    // [quads | single blocks] of this phase
+    const int32_t nwq = boundary ? nwg_qb : nwg_qi, q0 = boundary ? nq_int : 0, q1 = boundary ? nq : nq_int;
+    const int32_t nws = boundary ? nwg_sb : nwg_si, s0 = boundary ? ns_int : 0, s1 = boundary ? ns : ns_int;
+    if (b < nwq) {
+        const int32_t q = __builtin_amdgcn_readfirstlane(q0 + xcd_remap(b, nwq) * WPB + wave);
+        if (q < q1) quad2::sweep_quad<false, 127>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane);
+    } else {
+        const int32_t first = __builtin_amdgcn_readfirstlane(s0 + xcd_remap(b - nwq, nws) * WPB + wave);
+        if (first < s1)
+            blk2::sweep_adv<DT>(blocks, htab, etab, dtab, singles, first, WPB, 1, u, C, ldc, ud,
+                                lds + wave * BLK2_SWEEP_LDS, lane);
     }
 }
 
@@ -1148,6 +1219,61 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
             hipLaunchKernelGGL((k_passB_adv<3, true>), gB, blk, 0, ibh_stream, v, u, C, ldc, p->G, ud, p->blocks2,
                                p->htab, p->nblk, 0, cellsB, nB, flat_of(p, cellsB), nullptr);
     }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+// One step of a rank in one launch: xGMI halo exchange of u + image-only quad sweep (k_step_quad).  Needs a partition
+// whose image blocks are all eligible and carry quads (the ranks of the benchmark meshes); otherwise the caller runs
+// ibh_halo_exchange and ibh_residual_advection(IBH_IMAGE_ONLY) one after the other (same result).
+int ibh_step_advection_xgmi(ibh_part* p, float* u, const float* C, int64_t ldc, float* ud, const int32_t* send_all,
+                            int n_send_peers, const int32_t* send_seg, float* const* dst0, float* const* dst1,
+                            uint32_t* const* send_flags, const int32_t* recv_all, const float* src0, const float* src1,
+                            int n_recv_peers, const int32_t* recv_seg, const uint32_t* const* recv_flags,
+                            uint32_t* state, uint32_t max_spins, unsigned long long* fstate) {
+    IBH_REQUIRE(p && u && C && ud && state && fstate, "ibh_step_advection_xgmi: null argument");
+    IBH_REQUIRE(p->nd == 2 && p->bs == 8 && p->nblk > 0 && p->img_all_fz && !p->fuse_all && p->nq[1] > 0 && ibh_quad,
+                "ibh_step_advection_xgmi: needs a 2-D partition with skirt fragments whose image blocks are all eligible "
+                "for the quad sweep");
+    IBH_REQUIRE(n_send_peers >= 0 && n_send_peers <= IBH_MAX_PEERS && n_recv_peers >= 0 && n_recv_peers <= IBH_MAX_PEERS &&
+                    n_send_peers + n_recv_peers > 0,
+                "ibh_step_advection_xgmi: 1 to 16 peers");
+    XchgArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ns = n_send_peers;
+    A.nr = n_recv_peers;
+    if (n_send_peers) {
+        IBH_REQUIRE(send_all && send_seg && dst0 && dst1 && send_flags, "ibh_step_advection_xgmi: null send argument");
+        for (int q = 0; q < n_send_peers; ++q) {
+            A.dst[0][q] = dst0[q];
+            A.dst[1][q] = dst1[q];
+            A.sflag[q] = send_flags[q];
+            A.sseg[q] = send_seg[q];
+        }
+        A.sseg[n_send_peers] = send_seg[n_send_peers];
+    }
+    if (n_recv_peers) {
+        IBH_REQUIRE(recv_all && src0 && src1 && recv_seg && recv_flags, "ibh_step_advection_xgmi: null receive argument");
+        for (int q = 0; q < n_recv_peers; ++q) {
+            A.rflag[q] = recv_flags[q];
+            A.rseg[q] = recv_seg[q];
+        }
+        A.rseg[n_recv_peers] = recv_seg[n_recv_peers];
+    }
+    const int32_t big = std::max(A.ns ? A.sseg[A.ns] : 0, A.nr ? A.rseg[A.nr] : 0);
+    int E = (big + 255) / 256;
+    E = E < 1 ? 1 : E > 64 ? 64 : E;
+    const int32_t nq = p->nq[1], nqi = p->nq_int[1], ns = p->nqs[1], nsi = p->nqs_int[1];
+    const int32_t nwg = (nqi + WPB - 1) / WPB + (nsi + WPB - 1) / WPB + (nq - nqi + WPB - 1) / WPB + (ns - nsi + WPB - 1) / WPB;
+    static_assert(WPB == 4, "the exchange workgroups of k_step_quad are 256 threads");
+    if (p->n_dt > 0)
+        hipLaunchKernelGGL(k_step_quad<true>, dim3(E + nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->qd[1],
+                           p->qtab[1], nqi, nq, p->blocks2, p->htab, p->etab, p->dtab, p->qsingles[1], nsi, ns, send_all,
+                           recv_all, src0, src1, A, state, max_spins, E, fstate);
+    else
+        hipLaunchKernelGGL(k_step_quad<false>, dim3(E + nwg), dim3(64 * WPB), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
+                           p->qd[1], p->qtab[1], nqi, nq, p->blocks2, p->htab, p->etab, p->dtab, p->qsingles[1], nsi, ns,
+                           send_all, recv_all, src0, src1, A, state, max_spins, E, fstate);
     IBH_LAUNCH_CHECK();
     return 0;
 }

@@ -341,6 +341,29 @@ class XgmiHalo:
         self.finish(self.start(field))
         return field
 
+    def fused_step(self, dpart, u, C, ud):
+        """Exchange of the scalar field ``u`` + the image-only quad sweep ``ud = residual_advection(u, C)`` in ONE launch
+        (``ibh_step_advection_xgmi``): the exchange workgroups run beside the interior quads, boundary waves wait for the
+        unpacked skirt rows.  Raises ``IbhError`` on partitions the fused kernel does not cover (callers fall back to
+        ``exchange`` + ``residual_advection(IBH_IMAGE_ONLY)``: same result)."""
+        B, Cc = self.B, self.C
+        if self.nv != 1:
+            raise ValueError("fused_step exchanges a scalar field (XgmiHalo(nv=1))")
+        f, _, _ = B._field_inplace(u, what="halo field")
+        Cf, nvc, ldc = B._field(C, dpart.nc)
+        o, _, _ = B._field_inplace(ud, dpart.nc, "out")
+        if getattr(self, "_fstate", None) is None:
+            self._fstate = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.step += 1
+        B._stream()
+        B.call("ibh_step_advection_xgmi", dpart.handle, B._ptr(f), B._ptr(Cf), ldc, B._ptr(o), B._ptr(self.send_all),
+               len(self.peers_send), Cc.cast(self._sseg, B.c_vp), Cc.cast(self._dst[0], B.c_vp),
+               Cc.cast(self._dst[1], B.c_vp), Cc.cast(self._sflags, B.c_vp), B._ptr(self.recv_all),
+               B.c_vp(self._recv.value), B.c_vp(self._recv.value + 4 * self.n_recv_f), len(self.peers_recv),
+               Cc.cast(self._rseg, B.c_vp), Cc.cast(self._rflags, B.c_vp), B.c_vp(self.state.data_ptr()),
+               self.max_spins, B.c_vp(self._fstate.data_ptr()))
+        return ud
+
     def healthy(self):
         """False if any wait kernel hit its spin bound (collective: every rank gets the same answer)."""
         ok = torch.tensor([1 if int(self.state[2].item()) == 0 else 0], dtype=torch.int32,

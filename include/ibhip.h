@@ -309,6 +309,17 @@ int ibh_halo_exchange(float* f, int nv, int64_t ld, const int32_t* send_all, int
                       float* const* dst0, float* const* dst1, uint32_t* const* send_flags, const int32_t* recv_all,
                       const float* src0, const float* src1, int n_recv_peers, const int32_t* recv_seg,
                       const uint32_t* const* recv_flags, uint32_t* state, uint32_t max_spins);
+/* One step of a rank in ONE launch: ibh_halo_exchange of the scalar field u + the image-only quad sweep of
+ * ibh_residual_advection(u, C) -> ud (test/advection.jl:67-83 on the rank's image cells).  The exchange workgroups run
+ * beside the interior quads; a boundary wave waits (bounded by max_spins, time-out sets status bit 1) until the skirt rows
+ * of ITS launch are unpacked: the overlap of exchange and interior compute that north_star asks for, without a second
+ * stream.  fstate: 2 device uint64, zeroed once per exchanger.  Fails (no launch) on partitions whose image blocks are
+ * not all eligible for the quad sweep; the caller then runs the two entry points one after the other. */
+int ibh_step_advection_xgmi(ibh_part*, float* u, const float* C, int64_t ldc, float* ud, const int32_t* send_all,
+                            int n_send_peers, const int32_t* send_seg, float* const* dst0, float* const* dst1,
+                            uint32_t* const* send_flags, const int32_t* recv_all, const float* src0, const float* src1,
+                            int n_recv_peers, const int32_t* recv_seg, const uint32_t* const* recv_flags,
+                            uint32_t* state, uint32_t max_spins, unsigned long long* fstate);
 
 /* ---- small device-resident vector ops for the FAS loop (solver.jl:79-88) ---------- */
 /* q += clamp(omega,0,1) * r ; omega scalar */

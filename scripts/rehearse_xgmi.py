@@ -56,4 +56,60 @@ if rank == 0:
     print("graph-captured overlapped sweeps with xGMI exchange match:", bool(t.item()), flush=True)
 assert t.item() == 1
 xg1.close()
+
+# ---- the fused step (exchange + image-only quad sweep in ONE launch) on partitions of the RAE2822 mesh: against
+# exchange-then-sweep, eagerly and inside a HIP graph, the skirt poisoned before every step
+import bench
+msh2 = bench.build_mesh("rae2822_37k")
+n2 = len(msh2)
+mps2 = -(-(-(-n2 // world)) // 64) * 64
+dom2 = ibamd.Domain(msh2, max_partition_size=mps2, boundaries=False, only=[rank + 1])
+part2 = dom2.partitions[rank + 1]
+plan2 = HaloPlan(dom2, rank + 1)
+dp2 = ibamd.to_backend(part2, ibamd.hip)
+assert dp2.info["image_blocks_all_eligible"] and dp2.info["image_quads"] > 0
+# the field every rank holds after an exchange: a function of the cell centres
+xc = part2.centers.astype(np.float64)
+uh = (np.sin(2 * np.pi * xc[:, 0]) * np.cos(2 * np.pi * xc[:, 1]) + 0.1 * np.sin(37.0 * xc[:, 0] + 11.0 * xc[:, 1])).astype(np.float32)
+Ch = np.stack([np.ones(uh.size, np.float32), (0.5 + 0.2 * np.cos(5.0 * xc[:, 0])).astype(np.float32)], axis=1)
+u_true2, C2 = ibamd.hip(uh), ibamd.hip(Ch)
+skirt2 = np.ones(dp2.nc, bool); skirt2[part2.image_in_domain] = False
+sk2 = torch.from_numpy(skirt2).cuda()
+img2 = torch.from_numpy(part2.image_in_domain).long().cuda()
+xg2 = XgmiHalo(plan2, dom2, "cuda", nv=1)
+ref2 = torch.full((dp2.nc,), float("nan"), device="cuda")
+u2 = u_true2.clone(); u2[sk2] = float("nan")
+xg2.exchange(u2)
+assert bool(torch.equal(u2, u_true2)), "synthetic field is not a function of the cell centres"
+ibamd.residual_advection(dp2, u2, C2, out=ref2, flags=ibamd.IBH_IMAGE_ONLY)
+ok2 = True
+for _ in range(3):                                   # eager
+    u2[sk2] = float("nan")
+    out2 = torch.full((dp2.nc,), float("nan"), device="cuda")
+    torch.cuda.synchronize(); dist.barrier()
+    xg2.fused_step(dp2, u2, C2, out2)
+    torch.cuda.synchronize()
+    ok2 = ok2 and bool(torch.equal(out2[img2], ref2[img2])) and bool(torch.equal(u2, u_true2))
+side2 = torch.cuda.Stream()
+with torch.cuda.stream(side2):                        # captured: 4 steps per graph, 3 replays
+    out3 = torch.full((dp2.nc,), float("nan"), device="cuda")
+    xg2.fused_step(dp2, u2, C2, out3)
+    torch.cuda.synchronize(); dist.barrier()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=side2):
+        for _ in range(4):
+            xg2.fused_step(dp2, u2, C2, out3)
+    for _ in range(3):
+        u2[sk2] = float("nan")
+        out3.fill_(float("nan"))
+        torch.cuda.synchronize(); dist.barrier()
+        g2.replay()
+        torch.cuda.synchronize()
+        ok2 = ok2 and bool(torch.equal(out3[img2], ref2[img2])) and bool(torch.equal(u2, u_true2))
+ok2 = ok2 and xg2.healthy()
+t2 = torch.tensor([int(ok2)]); dist.all_reduce(t2, op=dist.ReduceOp.MIN)
+if rank == 0:
+    print("fused exchange + sweep step matches exchange-then-sweep:", bool(t2.item()), flush=True)
+assert t2.item() == 1
+xg2.close()
 dist.destroy_process_group()

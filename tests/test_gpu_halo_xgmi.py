@@ -23,3 +23,4 @@ def test_xgmi_halo_two_ranks_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "xgmi == reference exchange: True" in r.stdout
     assert "graph-captured overlapped sweeps with xGMI exchange match: True" in r.stdout
+    assert "fused exchange + sweep step matches exchange-then-sweep: True" in r.stdout
