@@ -477,10 +477,15 @@ def cell_gradient(part, u, dim=None):
     if dim is None:
         # the tuple form: all dimensions in one sweep per field (ibh_cell_gradient_nd)
         u, nv, ld = _field(u, part.nc)
-        nd = part.nd
-        buf = colmajor_empty(part.nc, nd * nv)
+        nd, nc = part.nd, part.nc
         _stream()
-        call("ibh_cell_gradient_nd", part.handle, _ptr(u), nv, ld, _ptr(buf), part.nc, None, 0)
+        if nv == 1:
+            # gradients + sensor back to back: the kernel writes them in place (no copy out of a workspace)
+            buf = colmajor_empty(nc, nd + 1)
+            call("ibh_cell_gradient_nd", part.handle, _ptr(u), 1, ld, _ptr(buf), nc, c_vp(buf.data_ptr() + 4 * nd * nc), nc)
+        else:
+            buf = colmajor_empty(nc, nd * nv)
+            call("ibh_cell_gradient_nd", part.handle, _ptr(u), nv, ld, _ptr(buf), nc, None, 0)
         return tuple(buf[:, d * nv] if u.ndim == 1 else buf[:, d * nv:(d + 1) * nv] for d in range(nd))
     u, nv, ld = _field(u, part.nc)
     out = _like(u, part.nc)

@@ -1299,6 +1299,15 @@ int ibh_cell_gradient_nd(ibh_part* p, const float* u, int nv, int64_t ldu, float
         if (sensor) return ibh_jst_sensor(p, 0, u, nv, ldu, sensor, lds);
         return 0;
     }
+    if (nv == 1 && ldo == p->nc && sensor == out + (size_t)nd * ldo && lds == ldo) {
+        // one field, gradients and sensor back to back: pass A writes them in place (the output IS its workspace for the
+        // duration of the call: no copy, and the partition's own workspace is not even allocated)
+        float* const own = p->G;
+        p->G = out;
+        const int rc1 = ibh_residual_advection(p, u, u, p->nc, out, IBH_PASS_A_ONLY | IBH_NO_FUSE);
+        p->G = own;
+        return rc1;
+    }
     int rc = ensure_G(p);
     if (rc) return rc;
     for (int v = 0; v < nv; ++v) {

@@ -165,7 +165,8 @@ int ibh_cell_gradient(const ibh_part*, int dim, const float* u, int nv, int64_t 
 /* cell_gradient(part, u): the tuple form, src/ImmersedBoundary.jl:980-988 -- all dimensions in one sweep per field:
  * out (nc, nd*nv), gradient of field v along dimension d in column d*nv + v; sensor (nc, nv) or NULL: JST_sensor(part, u)
  * (:1077-1097, dim = 0) of every field for free.  Block-structured partitions: pass A of the two-kernel sweeps (tuned
- * arithmetic, inside 5e-6 norm-wise of ibh_cell_gradient / ibh_jst_sensor); others: those kernels, one dimension at a time. */
+ * arithmetic, inside 5e-6 norm-wise of ibh_cell_gradient / ibh_jst_sensor); others: those kernels, one dimension at a time.
+ * With nv = 1, ldo = lds = nc and sensor = out + nd * nc (one (nc, nd + 1) buffer) the sweep writes in place: no copy. */
 int ibh_cell_gradient_nd(ibh_part*, const float* u, int nv, int64_t ldu, float* out, int64_t ldo, float* sensor,
                          int64_t lds);
 int ibh_face_distance(const ibh_part*, int dim, float* out);     /* :995  */
