@@ -271,8 +271,6 @@ def main():
     ud = torch.zeros(dpart.nc, dtype=torch.float32, device=u.device)
     euler = args.residual == "euler"
     if euler:
-        if world > 1 and msh.ndims == 3:
-            raise SystemExit("3-D workloads: one GPU only (secondary measurement)")
         rng = np.random.default_rng(12345)
         n = part.centers.shape[0]
         nvp = msh.ndims + 2
@@ -514,8 +512,6 @@ def main():
     reps = 50
     cells_launch = dpart.nc
     is3d = msh.ndims == 3
-    if is3d and world > 1:
-        raise SystemExit("3-D workloads: one GPU only (secondary measurement)")
     # single-kernel sweep: every block eligible, no face-list cells (2-D scalar sweep on one partition)
     inf = dpart.info
     base_flags = flags & ~ibamd.IBH_IMAGE_ONLY
