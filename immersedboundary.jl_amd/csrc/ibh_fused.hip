@@ -487,6 +487,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 #include "ibh_quad2d.h"
 #include "ibh_quad2d_euler.h"
 #include "ibh_strip3d.h"
+#include "ibh_strip3d_euler.h"
 #include "ibh_halo_dev.h"
 #include "ibh_block3d.h"
 
@@ -847,6 +848,23 @@ __global__ __launch_bounds__(64 * WPB3S) __attribute__((amdgpu_waves_per_eu(WAVE
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3S + wave);
     if (blk < n) strip3::sweep_strip(blocks, htab, ftab, rtab, r4tab, blk, u, C, ldc, ud, lds + wave * S3_LDS, lane);
+}
+
+// Column form of the 3-D Euler sweep (strip3e::sweep_euler_cols): one wavefront per block
+#ifndef WPB3E
+#define WPB3E 2
+#endif
+template <int WAVES>
+__global__ __launch_bounds__(64 * WPB3E) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_sweep3_euler_cols(
+    const float* __restrict__ P, uint32_t ldp, float* __restrict__ R, uint32_t ldr, float Rgas, float gamma,
+    const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab, const int32_t* __restrict__ ftab,
+    const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg) {
+    __shared__ __attribute__((aligned(16))) float lds[WPB3E * S3E_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3E + wave);
+    if (blk < n)
+        strip3e::sweep_euler_cols(blocks, htab, ftab, rtab, r4tab, blk, P, ldp, R, ldr, blk3::Gas3{Rgas, gamma},
+                                  lds + wave * S3E_LDS, lane);
 }
 
 // wave-per-block form of the 3-D scalar pass A (blk3::passA_wave): 4 blocks per 256-thread workgroup
@@ -1367,6 +1385,16 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
         !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY | IBH_IMAGE_ONLY |
                    IBH_PHASE_INTERIOR | IBH_PHASE_BOUNDARY))) {
         // 3-D, every block qualifies for the single-kernel sweep: one launch, nothing through the workspace
+        if (ibh_quad_variant != 512) {
+            const int32_t nwg = (p->nblk + WPB3E - 1) / WPB3E;
+#define S3E_LAUNCH(W)                                                                                                \
+    hipLaunchKernelGGL(k_sweep3_euler_cols<W>, dim3(nwg), dim3(64 * WPB3E), 0, ibh_stream, P, (uint32_t)ldp, R,       \
+                       (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks3, p->htab3, p->ftab3, p->rtab3, p->r4tab3,    \
+                       p->nblk, nwg)
+            if (ibh_quad_variant == 513) S3E_LAUNCH(3);
+            else S3E_LAUNCH(2);
+#undef S3E_LAUNCH
+        } else  // A/B: thread-per-cell form
         hipLaunchKernelGGL(k_sweep3_euler, dim3(p->nblk), dim3(512), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,
                            fluid->R, fluid->gamma, p->blocks3, p->htab3, p->ftab3, p->rtab3, p->r4tab3, p->nblk);
         IBH_LAUNCH_CHECK();

@@ -150,10 +150,12 @@ __device__ __forceinline__ float slot_eval(const float* pl, const float* pA, flo
     }
     const float dde = hde - h;
     const float x = (1.0f - qs) * din - 0.5f * dde;
-    const float ea0 = lds_read(pl + la) - h, ea1 = lds_read(pl + ha) - h;
-    const float eb0 = lds_read(pl + lb) - h, eb1 = lds_read(pl + hb) - h;
-    const float A0 = lds_read(pA + ib), A1 = lds_read(pA + n + ib), B0 = lds_read(pA + 2 * n + ia),
-                B1 = lds_read(pA + 3 * n + ia);
+    // eight LDS reads every lane performs, in flight together (ONE asm statement: the compiler may neither sink one of
+    // them into a divergent branch of the selects below nor wait for them one by one)
+    float pa0 = pl[la], pa1 = pl[ha], pb0 = pl[lb], pb1 = pl[hb];
+    float A0 = pA[ib], A1 = pA[n + ib], B0 = pA[2 * n + ia], B1 = pA[3 * n + ia];
+    asm volatile("" : "+v"(pa0), "+v"(pa1), "+v"(pb0), "+v"(pb1), "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1));
+    const float ea0 = pa0 - h, ea1 = pa1 - h, eb0 = pb0 - h, eb1 = pb1 - h;
     const float aa0 = ra0 ? A0 : fabsf(ea0), aa1 = ra1 ? A1 : fabsf(ea1);
     const float ab0 = rb0 ? B0 : fabsf(eb0), ab1 = rb1 ? B1 : fabsf(eb1);
     float dh = jst_max3(din + dde, ain + fabsf(dde), rn, ea0 + ea1, aa0 + aa1, ra, eb0 + eb1, ab0 + ab1, rb);
