@@ -850,11 +850,13 @@ __global__ __launch_bounds__(64 * WPB3S) __attribute__((amdgpu_waves_per_eu(WAVE
     if (blk < n) strip3::sweep_strip(blocks, htab, ftab, rtab, r4tab, blk, u, C, ldc, ud, lds + wave * S3_LDS, lane);
 }
 
-// Column form of the 3-D Euler sweep (strip3e::sweep_euler_cols): one wavefront per block
+// Column form of the 3-D Euler sweep (strip3e::sweep_euler_cols): one wavefront per block.  (A persistent form -- a
+// chain of blocks per wave, the first loads of the next block in flight during the z fluxes of the one in hand -- was
+// measured slower: 143 against 107 us at 4.56 M cells; the 26 registers of the prefetch and the second descriptor spill.)
 #ifndef WPB3E
 #define WPB3E 2
 #endif
-template <int WAVES>
+template <int WAVES, bool STAMP = false>
 __global__ __launch_bounds__(64 * WPB3E) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_sweep3_euler_cols(
     const float* __restrict__ P, uint32_t ldp, float* __restrict__ R, uint32_t ldr, float Rgas, float gamma,
     const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab, const int32_t* __restrict__ ftab,
@@ -862,9 +864,10 @@ __global__ __launch_bounds__(64 * WPB3E) __attribute__((amdgpu_waves_per_eu(WAVE
     __shared__ __attribute__((aligned(16))) float lds[WPB3E * S3E_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3E + wave);
-    if (blk < n)
-        strip3e::sweep_euler_cols(blocks, htab, ftab, rtab, r4tab, blk, P, ldp, R, ldr, blk3::Gas3{Rgas, gamma},
-                                  lds + wave * S3E_LDS, lane);
+    if (blk >= n) return;
+    strip3e::sweep_euler_cols<STAMP>(blocks, htab, ftab, rtab, r4tab, blk, P, ldp, R, ldr, blk3::Gas3{Rgas, gamma},
+                                     lds + wave * S3E_LDS, lane,
+                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)blk * 8 : nullptr);
 }
 
 // wave-per-block form of the 3-D scalar pass A (blk3::passA_wave): 4 blocks per 256-thread workgroup
@@ -1387,12 +1390,13 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
         // 3-D, every block qualifies for the single-kernel sweep: one launch, nothing through the workspace
         if (ibh_quad_variant != 512) {
             const int32_t nwg = (p->nblk + WPB3E - 1) / WPB3E;
-#define S3E_LAUNCH(W)                                                                                                \
-    hipLaunchKernelGGL(k_sweep3_euler_cols<W>, dim3(nwg), dim3(64 * WPB3E), 0, ibh_stream, P, (uint32_t)ldp, R,       \
+#define S3E_LAUNCH(W, ST)                                                                                            \
+    hipLaunchKernelGGL((k_sweep3_euler_cols<W, ST>), dim3(nwg), dim3(64 * WPB3E), 0, ibh_stream, P, (uint32_t)ldp, R, \
                        (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks3, p->htab3, p->ftab3, p->rtab3, p->r4tab3,    \
                        p->nblk, nwg)
-            if (ibh_quad_variant == 513) S3E_LAUNCH(3);
-            else S3E_LAUNCH(2);
+            if (ibh_quad_variant == 513) S3E_LAUNCH(3, false);
+            else if (ibh_quad_variant == 4) S3E_LAUNCH(2, true);  // wave time stamps (scripts/wave_timeline_3d.py)
+            else S3E_LAUNCH(2, false);
 #undef S3E_LAUNCH
         } else  // A/B: thread-per-cell form
         hipLaunchKernelGGL(k_sweep3_euler, dim3(p->nblk), dim3(512), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,

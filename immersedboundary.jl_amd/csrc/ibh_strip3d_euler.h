@@ -269,8 +269,8 @@ __device__ __forceinline__ void side_mean_p(const BlockDesc3& bb, const int32_t*
 // of the directions done before: max over directions of n_i / d_i = N / Dn with N = max(N d, n Dn), Dn = Dn d.
 template <int D, bool FIRST>
 __device__ __forceinline__ void sensor_pass(const BlockDesc3& bb, const int32_t* __restrict__ ftab,
-                                            const float* __restrict__ P, int lane, uint32_t hid0, uint32_t hid1, float hp0,
-                                            float hp1, Col& p, Col& N, Col& Dn) {
+                                            const float* __restrict__ P, int lane, float hp0, float hp1, Col& p, Col& N,
+                                            Col& Dn) {
     constexpr int S0 = 2 * D, S1 = 2 * D + 1;
     const float rh = bb.rh[D];
     float hm0, ha0, hm1, ha1;
@@ -447,14 +447,13 @@ constexpr int rstride() {
 
 // ---- flux pass along D: the lane's column with its two halo ends; R -= (F_high - F_low) / h for its 8 cells.
 // MODE 0: first pass (R = ...), 1: R += ..., 2: last pass (R + ... goes to global memory: z-columns, coalesced dwords).
-// The halo registers of this pass were loaded by the caller; those of the next pass (sides N0, N1) are requested here,
-// before the flux loop.
-template <int D, int MODE, int N0>
+// The halo registers of this pass were loaded by the caller; `prefetch` requests what comes next, before the flux loop.
+template <int D, int MODE, class Prefetch>
 __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const LaneGeo& LG, const int32_t* __restrict__ ftab,
                                           const int32_t* __restrict__ r4tab, const float* __restrict__ P, uint32_t ldp,
                                           float* lds, int lane, const Gas3& gas, Col* Pc, Col& Dc, const Slot* slots,
-                                          const int32_t* rids, const HaloRegs& h0, const HaloRegs& h1, HaloRegs& n0,
-                                          HaloRegs& n1, float* __restrict__ Rr, uint32_t ldr) {
+                                          const int32_t* rids, const HaloRegs& h0, const HaloRegs& h1, Prefetch&& prefetch,
+                                          float* __restrict__ Rr, uint32_t ldr) {
     constexpr int S0 = 2 * D, S1 = 2 * D + 1;
     const float rh = bb.rh[D];
     const float qlo = bb.q[S0], qhi = bb.q[S1];
@@ -509,13 +508,10 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const LaneGeo& L
         side_eval<S1>(bb, LG, ftab, r4tab, P, ldp, lds, lane, slots[S1], h1.hu, h1.hd, rids[S1], h1.rv, Pb, Sb, Dc.e[3].y,
                       gas, Sh1, Dh1, Ff1);
     }
-    // ---- the halo registers of the next pass
-    if constexpr (N0 >= 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        halo_load<N0>(bb, P, ldp, slots[N0], rids[N0], n0);
-        halo_load<N0 + 1>(bb, P, ldp, slots[N0 + 1], rids[N0 + 1], n1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    // ---- loads of what comes next (the halo registers of the next pass)
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch();
+    __builtin_amdgcn_sched_barrier(0);
     // column ends: mean halo values for the slopes of cells 0 / 7, the halo cells themselves for the faces
     Dc.e[0].x = Dh0;
     Dc.e[4].y = Dh1;
@@ -596,21 +592,72 @@ __device__ __forceinline__ void load_zcol(const float* __restrict__ p, Col& c) {
     }
 }
 
+// the first loads of a block, those of the sensor: halo cell ids, rim ids, the pressure as z-columns, the halo pressures
+struct Pre {
+    Slot slots[6];
+    int32_t rids[6];
+    Col p;
+    float hp[6];
+};
+__device__ __forceinline__ void load_pre(const BlockDesc3& bn, const int32_t* __restrict__ htab,
+                                         const int32_t* __restrict__ rtab, const float* __restrict__ P, int32_t blk,
+                                         int lane, Pre& q) {
+    // halo cell ids first: where a side is FINE (a table load) the compiler waits for every load in flight before it
+    // uses the ids
+    q.slots[0] = slot_of<0>(bn, htab, blk, lane);
+    q.slots[1] = slot_of<1>(bn, htab, blk, lane);
+    q.slots[2] = slot_of<2>(bn, htab, blk, lane);
+    q.slots[3] = slot_of<3>(bn, htab, blk, lane);
+    q.slots[4] = slot_of<4>(bn, htab, blk, lane);
+    q.slots[5] = slot_of<5>(bn, htab, blk, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) q.rids[s] = rtab[(size_t)blk * 384 + s * 64 + lane];
+    load_zcol(P + (uint32_t)bn.base + lane, q.p);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) q.hp[s] = ldg(P, q.slots[s].hid);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// One block.
+// STAMP: phase time stamps of the wave (100 MHz ticks) for scripts/wave_timeline_3d.py: 0 start, 1 first loads landed,
+// 2 sensor done, 3 x fluxes, 4 transposed, 5 y fluxes, 6 transposed, 7 end
+template <bool STAMP = false>
 __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
                                                  const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
                                                  const int32_t* __restrict__ r4tab, int32_t blk,
                                                  const float* __restrict__ P, uint32_t ldp, float* __restrict__ Rr,
-                                                 uint32_t ldr, Gas3 gas, float* lds, int lane) {
-    // ---- every load that does not depend on another one, up front: rim ids, descriptor, the pressure as z-columns
-    // (sensor), the five primitives as x-columns (two float4 per field), the halo registers of the x sides
-    int32_t rids[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) rids[s] = rtab[(size_t)blk * 384 + s * 64 + lane];
+                                                 uint32_t ldr, Gas3 gas, float* lds, int lane,
+                                                 unsigned long long* stamps = nullptr) {
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (k == 1 || k == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (stamps && lane == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    stamp(0);
     const BlockDesc3 bb = blocks[blk];
     const int ta = lane & 7, tb = lane >> 3;
     float* buf = lds + S3E_BUF;
-    Col p;
-    load_zcol(P + (uint32_t)bb.base + lane, p);
+    // ---- every load that does not depend on another one, up front, in the order of their use: those of the sensor, then
+    // the loads of the x fluxes:
+    Pre pre;
+    load_pre(bb, htab, rtab, P, blk, lane, pre);
+    // ---- the halo registers of the x sides, the five primitives
+    // as x-columns (two float4 per field)
+    Slot slots[6];
+    int32_t rids[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        slots[s] = pre.slots[s];
+        rids[s] = pre.rids[s];
+    }
+    HaloRegs hA0, hA1, hB0, hB1;
+    halo_load_values<0>(P, ldp, slots[0], hA0);
+    halo_load_values<1>(P, ldp, slots[1], hA1);
+    __builtin_amdgcn_sched_barrier(0);
     Col Pc[5];
     {
         const uint32_t a0 = (uint32_t)bb.base + 8u * (uint32_t)lane;
@@ -622,36 +669,24 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
             Pc[v].e[0].y = hi.x; Pc[v].e[1].y = hi.y; Pc[v].e[2].y = hi.z; Pc[v].e[3].y = hi.w;
         }
     }
-    Slot slots[6];
-    slots[0] = slot_of<0>(bb, htab, blk, lane);
-    slots[1] = slot_of<1>(bb, htab, blk, lane);
-    slots[2] = slot_of<2>(bb, htab, blk, lane);
-    slots[3] = slot_of<3>(bb, htab, blk, lane);
-    slots[4] = slot_of<4>(bb, htab, blk, lane);
-    slots[5] = slot_of<5>(bb, htab, blk, lane);
-    float hp[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) hp[s] = ldg(P, slots[s].hid);
-    HaloRegs hA0, hA1, hB0, hB1;
-    halo_load_values<0>(P, ldp, slots[0], hA0);
-    halo_load_values<1>(P, ldp, slots[1], hA1);
     __builtin_amdgcn_sched_barrier(0);
     hA0.rv = ldg(P, (uint32_t)(rids[0] >= 0 ? rids[0] : bb.base));  // (the only loads here that depend on another one)
     hA1.rv = ldg(P, (uint32_t)(rids[1] >= 0 ? rids[1] : bb.base));
     __builtin_amdgcn_sched_barrier(0);
+    stamp(1);
     // ---- pressure sensor of the block's cells: z, y, x
     Col Dc;
     {
-        Col N, Dn;
-        sensor_pass<2, true>(bb, ftab, P, lane, slots[4].hid, slots[5].hid, hp[4], hp[5], p, N, Dn);
+        Col p = pre.p, N, Dn;
+        sensor_pass<2, true>(bb, ftab, P, lane, pre.hp[4], pre.hp[5], p, N, Dn);
         transpose<2, 1>(buf, ta, tb, p);
         transpose<2, 1>(buf, ta, tb, N);
         transpose<2, 1>(buf, ta, tb, Dn);
-        sensor_pass<1, false>(bb, ftab, P, lane, slots[2].hid, slots[3].hid, hp[2], hp[3], p, N, Dn);
+        sensor_pass<1, false>(bb, ftab, P, lane, pre.hp[2], pre.hp[3], p, N, Dn);
         transpose<1, 0>(buf, ta, tb, p);
         transpose<1, 0>(buf, ta, tb, N);
         transpose<1, 0>(buf, ta, tb, Dn);
-        sensor_pass<0, false>(bb, ftab, P, lane, slots[0].hid, slots[1].hid, hp[0], hp[1], p, N, Dn);
+        sensor_pass<0, false>(bb, ftab, P, lane, pre.hp[0], pre.hp[1], p, N, Dn);
 #pragma unroll
         for (int j = 1; j < 4; ++j)
             Dc.e[j] = v2f{fmaxf(N.e[j].x * __builtin_amdgcn_rcpf(Dn.e[j].x), 1e-7f),
@@ -659,17 +694,29 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
         Dc.e[4].x = fmaxf(N.e[4].x * __builtin_amdgcn_rcpf(Dn.e[4].x), 1e-7f);
         Dc.e[0].y = fmaxf(N.e[0].y * __builtin_amdgcn_rcpf(Dn.e[0].y), 1e-7f);
     }
+    stamp(2);
     // ---- fluxes: x, y, z
     const LaneGeo LG = lane_geo(lane);
-    flux_pass<0, 0, 2>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hA0, hA1, hB0, hB1, Rr, ldr);
+    flux_pass<0, 0>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hA0, hA1, [&]() {
+        halo_load<2>(bb, P, ldp, slots[2], rids[2], hB0);
+        halo_load<3>(bb, P, ldp, slots[3], rids[3], hB1);
+    }, Rr, ldr);
+    stamp(3);
 #pragma unroll
     for (int v = 0; v < 5; ++v) transpose<0, 1>(buf, ta, tb, Pc[v]);
     transpose<0, 1>(buf, ta, tb, Dc);
-    flux_pass<1, 1, 4>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hB0, hB1, hA0, hA1, Rr, ldr);
+    stamp(4);
+    flux_pass<1, 1>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hB0, hB1, [&]() {
+        halo_load<4>(bb, P, ldp, slots[4], rids[4], hA0);
+        halo_load<5>(bb, P, ldp, slots[5], rids[5], hA1);
+    }, Rr, ldr);
+    stamp(5);
 #pragma unroll
     for (int v = 0; v < 5; ++v) transpose<1, 2>(buf, ta, tb, Pc[v]);
     transpose<1, 2>(buf, ta, tb, Dc);
-    flux_pass<2, 2, -1>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hA0, hA1, hB0, hB1, Rr, ldr);
+    stamp(6);
+    flux_pass<2, 2>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hA0, hA1, []() {}, Rr, ldr);
+    stamp(7);
 }
 
 #pragma clang fp contract(off)

@@ -1,5 +1,6 @@
 """A/B of the 3-D Euler sweep forms on one workload (run on the GPU box): python scripts/probe_3d_euler.py [workload]
-column form (strip3e::sweep_euler_cols) at 2 / 3 waves per SIMD, thread-per-cell single kernel, two-kernel form."""
+column form (strip3e::sweep_euler_cols) as persistent waves / one block per wave, thread-per-cell single kernel,
+two-kernel form."""
 import json
 import os
 import sys
