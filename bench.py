@@ -98,37 +98,8 @@ def synthetic_fields(centers, seed=12345):
     return u.astype(np.float32), C
 
 
-def cpu_baseline(part, u, C, budget_s=10.0):
-    """The oracle timed on this host: the C restatement (oracle/csrc/residual.c) in both of its forms -- one array
-    pass per reference broadcast like the Julia code ("faithful"), and cell-fused -- each at its best OpenMP thread
-    count from a short scan (the box may give this job fewer CPUs than it shows).  The reported value is the faster."""
-    from oracle import residual_c as rc
-    cp = rc.CPart(part)
-
-    def rate(fused, threads, reps):
-        cp.residual_advection(u, C, fused=fused, threads=threads)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            cp.residual_advection(u, C, fused=fused)
-        return reps / (time.perf_counter() - t0)
-    best = {}
-    for fused in (False, True):
-        cands = [(rate(fused, t, 3), t) for t in sorted({1, 8, 16, 32, 64, rc.max_threads()}) if t <= rc.max_threads()]
-        best[fused] = max(cands)
-    fused = best[True][0] > best[False][0]
-    threads = best[fused][1]
-    cp.residual_advection(u, C, fused=fused, threads=threads)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        cp.residual_advection(u, C, fused=fused)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 2000:
-            break
-    mc = u.shape[0] / 1e6
-    other = best[not fused]
-    # what the job may really use: CPUs in the affinity mask and the cgroup CPU quota (a box can show 256 cores and
-    # give this job about one: then one thread wins the scan above)
+def cpu_limits():
+    """CPUs this job may really use: affinity mask and cgroup CPU quota (a box can show 256 cores and give less)."""
     quota = None
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
@@ -143,9 +114,46 @@ def cpu_baseline(part, u, C, budget_s=10.0):
             break
         except (OSError, ValueError, IndexError):
             continue
+    aff = len(os.sched_getaffinity(0))
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return aff, quota, usable
+
+
+def cpu_baseline(part, u, C, budget_s=10.0):
+    """The oracle timed on this host: the C restatement (oracle/csrc/residual.c) in both of its forms -- one array
+    pass per reference broadcast like the Julia code ("faithful"), and cell-fused -- each at its best OpenMP thread
+    count.  The thread counts scanned go up to min(affinity mask, cgroup quota) and are set explicitly
+    (ibo_set_threads): OMP_NUM_THREADS of the box does not cap the scan.  The reported value is the faster."""
+    from oracle import residual_c as rc
+    cp = rc.CPart(part)
+    aff, quota, usable = cpu_limits()
+
+    def rate(fused, threads, reps):
+        cp.residual_advection(u, C, fused=fused, threads=threads)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cp.residual_advection(u, C, fused=fused)
+        return reps / (time.perf_counter() - t0)
+    scan = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, usable) if t <= usable})
+    best = {}
+    for fused in (False, True):
+        best[fused] = max((rate(fused, t, 3), t) for t in scan)
+    fused = best[True][0] > best[False][0]
+    threads = best[fused][1]
+    cp.residual_advection(u, C, fused=fused, threads=threads)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cp.residual_advection(u, C, fused=fused)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 2000:
+            break
+    mc = u.shape[0] / 1e6
+    other = best[not fused]
     return dict(value=mc * n / dt, n=n, secs=dt, threads=threads, form="cell-fused" if fused else "faithful",
                 other_form="faithful" if fused else "cell-fused", other_value=mc * other[0], other_threads=other[1],
-                one_thread=mc * rate(False, 1, 2), affinity=len(os.sched_getaffinity(0)), cgroup_cpus=quota)
+                one_thread=mc * rate(False, 1, 2), affinity=aff, cgroup_cpus=quota, scanned=scan,
+                omp_num_threads_env=os.environ.get("OMP_NUM_THREADS"))
 
 
 def main():
@@ -244,10 +252,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=120)   # a rank that dies in set-up must not hold the others for 10 min
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
 
     msh = build_mesh(args.workload)
     ncells = len(msh)
@@ -326,8 +336,13 @@ def main():
         comm_stream = torch.cuda.Stream() if overlap else None
         # exchange + image-only quad sweep as ONE launch (XgmiHalo.fused_step: the exchange workgroups run beside the
         # interior quads), taken when it reproduces exchange-then-sweep bit for bit on every rank
-        if (args.fused_step and halo_kind == "xgmi-direct" and image_only and not euler and comm_stream is None
-                and flags == ibamd.IBH_IMAGE_ONLY):
+        # Every rank must take the same branch (the trial holds collectives): the rank-local predicate is all-reduced.
+        red0 = u.device if args.backend == "nccl" else "cpu"
+        elig = int(bool(args.fused_step and halo_kind == "xgmi-direct" and image_only and not euler
+                        and comm_stream is None and flags == ibamd.IBH_IMAGE_ONLY))
+        te = torch.tensor([elig], dtype=torch.int32, device=red0)
+        dist.all_reduce(te, op=dist.ReduceOp.MIN)
+        if args.fused_step and int(te.item()):
             ok_f = 0
             try:
                 ref_f = torch.zeros_like(ud)
@@ -335,18 +350,36 @@ def main():
                 ibamd.residual_advection(dpart, u, C, out=ref_f, flags=flags)
                 got_f = torch.zeros_like(ud)
                 torch.cuda.synchronize()
-                dist.barrier()
-                hx.fused_step(dpart, u, C, got_f)
-                torch.cuda.synchronize()
-                ok_f = int(bool(torch.equal(got_f, ref_f)))
-            except Exception as e:  # noqa: BLE001 -- partitions the fused kernel does not cover
-                if rank == 0:
-                    print(f"[bench] fused exchange + sweep step unavailable ({e})", file=sys.stderr)
-            tf = torch.tensor([ok_f], dtype=torch.int32, device=u.device if args.backend == "nccl" else "cpu")
+                ok_f = 1
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: reference step of the fused trial failed ({e})", file=sys.stderr)
+            # a rank that cannot launch the fused kernel would leave its peers' sequence numbers one step ahead: the
+            # decision to launch is collective too
+            tf = torch.tensor([ok_f and int(hx.can_fuse(dpart))], dtype=torch.int32, device=red0)
             dist.all_reduce(tf, op=dist.ReduceOp.MIN)
-            fused_step = bool(tf.item()) and hx.healthy()
+            ok_f = 0
+            if int(tf.item()):
+                try:
+                    hx.fused_step(dpart, u, C, got_f)
+                    torch.cuda.synchronize()
+                    ok_f = int(bool(torch.equal(got_f, ref_f)))
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: fused exchange + sweep step failed ({e})", file=sys.stderr)
+            tf = torch.tensor([ok_f and int(hx.healthy())], dtype=torch.int32, device=red0)
+            dist.all_reduce(tf, op=dist.ReduceOp.MIN)
+            fused_step = bool(tf.item())
             if fused_step:
                 halo_kind = "xgmi-direct, fused with the sweep (one launch per step)"
+            elif not hx.healthy() or not int(tf.item()):
+                # the exchanger's sequence numbers may be out of step after a failed trial: do not keep it
+                if args.halo == "xgmi":
+                    raise SystemExit("fused exchange + sweep trial failed on a rank; rerun without --fused-step")
+                if rank == 0:
+                    print("[bench] fused-step trial failed on a rank: closing the xgmi exchanger, using the "
+                          "reference exchange", file=sys.stderr)
+                hx.close()
+                hx = HaloExchange(plan, u.device)
+                halo_kind = "rccl" if args.backend == "nccl" else "gloo-staged"
 
     def sweep(extra=0):
         if euler:
@@ -437,13 +470,18 @@ def main():
     run(args.warmup)
     # EXACTLY `steps` sweeps between barrier + synchronize on both sides, max over ranks -- and that block `repeats`
     # times: a block is a fraction of a millisecond, its wall time moves with launch jitter; the median is reported
-    dts = []
+    dts, gts = [], []
+    ev_stream = side if graph is not None else torch.cuda.current_stream()
     for _ in range(max(1, args.repeats)):
         barrier()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        g0.record(ev_stream)
         run(args.steps)
+        g1.record(ev_stream)
         barrier()
         dts.append(time.perf_counter() - t0)
+        gts.append(g0.elapsed_time(g1) * 1e-3)   # GPU side of the same block (events on the launch stream)
     if world > 1:
         red_dev = u.device if args.backend == "nccl" else "cpu"
         tmax = torch.tensor(dts, dtype=torch.float64, device=red_dev)
@@ -451,6 +489,8 @@ def main():
         dts = [float(x) for x in tmax.tolist()]
     dts.sort()
     dt = dts[len(dts) // 2]
+    gts.sort()
+    gpu_dt = gts[len(gts) // 2]
     halo_timeouts = None
     if world > 1:
         if (halo_kind or "").startswith("xgmi-direct"):
@@ -601,6 +641,7 @@ def main():
                                                               "3D sphere" if is3d else "2D RAE2822"),
         "value": round(value, 2), "unit": "Mcells*iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "repeats": len(dts), "ms_per_step": round(ms_per_step, 5),
+        "gpu_ms_per_step": round(gpu_dt / args.steps * 1e3, 5),
         "ms_per_step_min_max": [round(dts[0] / args.steps * 1e3, 5), round(dts[-1] / args.steps * 1e3, 5)],
         "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -661,10 +702,12 @@ def main():
         cb = cpu_baseline(part, u_h, C_h)
         out["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "Mcells*iters/s", "cores": cb["threads"],
                                "kind": "port", "host_cores": os.cpu_count(), "affinity_cpus": cb["affinity"],
-                               "cgroup_cpu_quota": cb["cgroup_cpus"],
+                               "cgroup_cpu_quota": cb["cgroup_cpus"], "threads_scanned": cb["scanned"],
                                "sample": f"{cb['n']} sweeps of the same {u_h.shape[0]}-cell partition in {cb['secs']:.1f} s: "
                                          f"C restatement of the Julia closure (oracle/csrc/residual.c), {cb['form']} form, "
-                                         f"OpenMP on {cb['threads']} threads of a {os.cpu_count()}-core host (best of a scan); "
+                                         f"OpenMP on {cb['threads']} threads of a {os.cpu_count()}-core host "
+                                         f"({'best of the thread counts ' + str(cb['scanned']) if len(cb['scanned']) > 1 else 'the only thread count this job is allowed'}; "
+                                         f"OMP_NUM_THREADS={cb['omp_num_threads_env']}); "
                                          f"{cb['other_form']} form {cb['other_value']:.1f} on {cb['other_threads']} threads, "
                                          f"faithful form on 1 thread {cb['one_thread']:.1f} Mcells*iters/s"}
     if rank == 0:

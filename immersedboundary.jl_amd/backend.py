@@ -136,6 +136,10 @@ def _hipaware(fn):
             if isinstance(x, tuple):
                 return tuple(un(v) for v in x)
             return x
+        # an operator that writes into a HipArray (out=...): pending broadcasts that read it are evaluated first, so
+        # that they see the old values like Julia's eager broadcast would
+        if kwargs and isinstance(kwargs.get("out"), HipArray):
+            kwargs["out"]._flush_readers()
         a = [un(x) for x in args]
         k = {key: un(v) for key, v in kwargs.items()} if kwargs else kwargs
         out = fn(*a, **k)
@@ -628,17 +632,20 @@ def impose_bc(f, dom, bname, *args, conv_to_backend=None, conv_from_backend=None
     if (conv_to_backend is None) != (conv_from_backend is None):
         raise AssertionError("Backend converters must be provided at the same time")
     from .hiparray import HipArray
+
+    def on_device(a):
+        return isinstance(a, HipArray) or (isinstance(a, torch.Tensor) and a.is_cuda)
+    host_args = None
+    if not all(on_device(a) for a in args):
+        if conv_to_backend is None:
+            raise TypeError("impose_bc needs device arrays or conv_to_backend/conv_from_backend (no CPU path)")
+        host_args = args
+        args = tuple(a if on_device(a) else conv_to_backend(a) for a in args)   # (the converter may return HipArrays)
     wrapped = any(isinstance(a, HipArray) for a in args)
     for a in args:
         if isinstance(a, HipArray):
             a._flush_readers()   # the arrays are written in place: pending broadcasts that read them go first
     args = tuple(a.t if isinstance(a, HipArray) else a for a in args)
-    host_args = None
-    if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
-        if conv_to_backend is None:
-            raise TypeError("impose_bc needs device arrays or conv_to_backend/conv_from_backend (no CPU path)")
-        host_args = args
-        args = tuple(conv_to_backend(a) for a in args)
     fields = [_field_inplace(a, what="impose_bc argument") for a in args]  # updated in place (:1241-1245)
     for ipart in dom.boundaries[bname]:
         bdry = to_backend(dom.boundaries[bname][ipart])
@@ -661,4 +668,5 @@ def impose_bc(f, dom, bname, *args, conv_to_backend=None, conv_from_backend=None
                 call("ibh_bc_blend", bdry.handle, _ptr(a), nv, ld, _ptr(ia), bdry.ng, c_vp(None), 0, _hptr(const))
     if host_args is not None:
         for h, (a, _, _) in zip(host_args, fields):
-            h[...] = conv_from_backend(a)
+            if not on_device(h):
+                h[...] = conv_from_backend(a)

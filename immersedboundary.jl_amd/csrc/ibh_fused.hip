@@ -683,9 +683,12 @@ __global__ __launch_bounds__(64 * WPB) void k_step_quad(float* __restrict__ u, c
         __syncthreads();
         if (lane == 0) {
             const unsigned long long w = want;
-            uint32_t spins = 0;
+            // bounded like the exchange wait, but strictly longer (4 x the spins at half the sleep): a peer that is late
+            // yet inside the exchange bound must not make these waves give up first and compute on stale skirt rows
+            unsigned long long spins = 0;
+            const unsigned long long bound = 4ull * (unsigned long long)max_spins;
             while (__hip_atomic_load(&fstate[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < w) {
-                if (++spins >= max_spins) {  // bounded: every wave reaches the exit
+                if (++spins >= bound) {  // every wave reaches the exit
                     atomicOr(&state[2], 2u);
                     break;
                 }

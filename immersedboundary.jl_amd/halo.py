@@ -341,6 +341,15 @@ class XgmiHalo:
         self.finish(self.start(field))
         return field
 
+    def can_fuse(self, dpart):
+        """Whether ``fused_step`` covers this partition (what ``ibh_step_advection_xgmi`` requires: a 2-D partition with
+        skirt fragments whose image blocks are all eligible for the quad sweep, a scalar exchanger with peers) -- a
+        rank-local predicate: callers that run collectively all-reduce it before any rank launches."""
+        info = dpart.info
+        return bool(self.nv == 1 and dpart.nd == 2 and info.get("image_blocks_all_eligible")
+                    and info.get("image_quads", 0) > 0 and info.get("fusable_blocks") != info.get("full_blocks")
+                    and (self.peers_send or self.peers_recv))
+
     def fused_step(self, dpart, u, C, ud):
         """Exchange of the scalar field ``u`` + the image-only quad sweep ``ud = residual_advection(u, C)`` in ONE launch
         (``ibh_step_advection_xgmi``): the exchange workgroups run beside the interior quads, boundary waves wait for the
@@ -352,8 +361,12 @@ class XgmiHalo:
         f, _, _ = B._field_inplace(u, what="halo field")
         Cf, nvc, ldc = B._field(C, dpart.nc)
         o, _, _ = B._field_inplace(ud, dpart.nc, "out")
-        if getattr(self, "_fstate", None) is None:
-            self._fstate = torch.zeros(2, dtype=torch.int64, device=self.device)
+        # the ticket arithmetic of the kernel assumes ONE grid per state word pair: one pair per partition
+        if getattr(self, "_fstates", None) is None:
+            self._fstates = {}
+        if id(dpart) not in self._fstates:
+            self._fstates[id(dpart)] = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._fstate = self._fstates[id(dpart)]
         self.step += 1
         B._stream()
         B.call("ibh_step_advection_xgmi", dpart.handle, B._ptr(f), B._ptr(Cf), ldc, B._ptr(o), B._ptr(self.send_all),

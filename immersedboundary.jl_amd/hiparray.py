@@ -138,6 +138,25 @@ class HipArray:
             return None
         return depth
 
+    def _reads_other_shape(self, out):
+        """True if an array this pending expression reads overlaps the tensor ``out`` without being the same elements
+        in the same layout (elementwise evaluation in place is then not safe)."""
+        lo, hi = out.data_ptr(), out.data_ptr() + out.numel() * out.element_size()
+        seen, stack = set(), [self]
+        while stack:
+            x = stack.pop()
+            if id(x) in seen:
+                continue
+            seen.add(id(x))
+            if x._t is None:
+                stack.extend(y for y in x._expr[1:] if isinstance(y, HipArray))
+                continue
+            t = x._t
+            a, b = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+            if a < hi and lo < b and not (a == lo and t.shape == out.shape and t.stride() == out.stride()):
+                return True
+        return False
+
     def _evaluate_into(self, out):
         """Value of the pending expression into the tensor ``out`` (may alias an operand: the kernel is elementwise)."""
         B = _B()
@@ -242,7 +261,14 @@ class HipArray:
             for d in readers:
                 if d._t is None:
                     d.t  # noqa: B018
-            node._evaluate_into(out._t)
+            if node._reads_other_shape(out._t):
+                # a leaf aliases out's memory with another shape (`P ./= P[:, 1]`): threads of other columns would race
+                # with the write; Julia's broadcast_unalias copies in that case -- so does this
+                tmp = torch.empty_like(out._t)
+                node._evaluate_into(tmp)
+                out._t.copy_(tmp)
+            else:
+                node._evaluate_into(out._t)
             node._t, node._expr = out._t, None
             out._deps.clear()
             return out

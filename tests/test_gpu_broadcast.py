@@ -143,3 +143,37 @@ def test_fused_broadcast_equals_node_by_node():
     ref1 = (A + B) * Cc / f32(2) + np.abs(Cc) * (A - B) / f32(2)
     assert np.array_equal(fused[0], ref1.astype(f32))
     assert np.array_equal(fused[5], A + f32(1.0))
+
+
+def test_impose_bc_host_arrays_through_the_hiparray_converter(adv_domains):
+    """impose_bc!(f, dom, name, host_u; conv_to_backend = HipArray, conv_from_backend) -- the reference's calling
+    convention with host arrays (ImmersedBoundary.jl:1206-1212): converted first, the closure sees HipArrays, the host
+    array is updated; against the oracle."""
+    dp, do = adv_domains
+    X = dp.global_centers()
+    uo = seeded_field(X, kind="step")
+    ug = uo.copy()
+    od.impose_bc(lambda b, ui: f32(1.0), do, "upper", uo)
+    od.impose_bc(lambda b, ui: ui * f32(0.5) + f32(0.25), do, "outlet", uo)
+    seen = []
+
+    def half(b, ui):
+        seen.append(type(ui))
+        return ui * 0.5 + 0.25
+    ibamd.impose_bc(lambda b, ui: 1.0, dp, "upper", ug, **KW)
+    ibamd.impose_bc(half, dp, "outlet", ug, **KW)
+    assert seen and all(t is ibamd.HipArray for t in seen)
+    assert rel_inf(ug, uo) <= 1e-6
+
+
+def test_in_place_broadcast_that_reads_a_column_of_its_destination():
+    """`P ./= P[:, 1]` (an operand aliases the destination with another shape: Julia's broadcast_unalias copies) and a
+    pending expression whose operand an operator overwrites through out=..."""
+    rng = np.random.default_rng(3)
+    A = rng.uniform(0.5, 2, (5000, 3)).astype(f32)
+    P = ibamd.HipArray(A.copy())
+    P /= P.col(1)
+    assert np.allclose(P.to_host(), A / A[:, :1], rtol=1e-6)
+    Q = ibamd.HipArray(A.copy())
+    Q *= Q.col(3)
+    assert np.array_equal(Q.to_host(), A * A[:, 2:3])
