@@ -226,14 +226,14 @@ class DevicePartition:
         self.domain = torch.from_numpy(dom).to(dev)
         self.image = torch.from_numpy(np.ascontiguousarray(part.image, dtype=np.int32)).to(dev)
         self.image_in_domain = torch.from_numpy(iid).to(dev)
-        info = (C.c_int64 * 16)()
-        call("ibh_partition_info", h, info, 16)
+        info = (C.c_int64 * 24)()
+        call("ibh_partition_info", h, info, 24)
         self.info = dict(full_blocks=info[0], irregular_cells=info[1], sides_same=info[2], sides_mirror=info[3],
                          sides_coarse=info[4], sides_fine=info[5], sides_general=info[6], interior_blocks=info[7],
                          fusable_blocks=info[8], workspace_blocks=info[9],
                          image_blocks_all_eligible=bool(info[10]), image_blocks=info[11],
                          quads=info[12] if self.nd == 2 else 0, quad_singles=info[13], image_quads=info[14],
-                         image_quad_singles=info[15],
+                         image_quad_singles=info[15], row_sweep=bool(info[16]),
                          # 3-D single-kernel sweeps: rim neighbours of halo cells that are four finer cells
                          rim4_rows=info[12] if self.nd == 3 else 0)
 

@@ -37,7 +37,7 @@ struct Host2D {
     std::vector<int32_t> irr, htab, etab, dtab, img, fz, ng, nf;
     std::vector<char> fus, needg;
     int32_t nph[2] = {0, 0};
-    int32_t n_img_int = 0, img_all_fz = 0, fuse_all = 0, n_fz_int = 0, n_ng_int = 0, n_nf_int = 0;
+    int32_t n_img_int = 0, img_all_fz = 0, fuse_all = 0, rows_ok = 0, n_fz_int = 0, n_ng_int = 0, n_nf_int = 0;
     int64_t info[12] = {0};
     QuadSet2 quads[2];  // 0: all blocks (fuse_all partitions), 1: image blocks (img_all_fz partitions)
 };
@@ -78,6 +78,31 @@ static void analyze2_host(const HostPartView& v, int32_t n_image, const int32_t*
         }
     H.info[9] = H.fuse_all ? 0 : (int64_t)H.ng.size();
     if (H.fuse_all) ibh_build_quads2(H.blocks, H.htab, H.etab, H.fus, H.nph[1], H.quads[0], nc);
+    // Row sweep (ibh_rows2d.h): its halo cell ids are arithmetic on the neighbour block bases.  Taken only where that
+    // arithmetic -- restated here -- reproduces the halo table (which was read off the registered faces) for every slot
+    // of every block, every neighbour block is complete, and no block takes its deeper cells from a table.
+    if (H.fuse_all && H.dtab.empty()) {
+        bool ok = true;
+        for (int32_t b = 0; b < nb && ok; ++b) {
+            const BlockDesc2& B = H.blocks[b];
+            for (int s = 0; s < 4 && ok; ++s) {
+                const int d = s >> 1, sd = d == 0 ? 1 : 8, st = d == 0 ? 8 : 1;
+                const bool low = (s & 1) == 0;
+                const int opp = low ? 7 * sd : 0, own = low ? 0 : 7 * sd;
+                const int ty = B.type[s];
+                if (ty == SIDE_GENERAL) { ok = false; break; }
+                if (ty != SIDE_MIRROR && (B.nb[s][0] < 0 || (ty == SIDE_FINE && B.nb[s][1] < 0))) { ok = false; break; }
+                for (int t = 0; t < 8 && ok; ++t)
+                    for (int k = 0; k < 2; ++k) {
+                        const int tt = ty == SIDE_COARSE ? (t >> 1) + 4 * B.sub[s] : ty == SIDE_FINE ? 2 * (t & 3) + k : t;
+                        const int32_t nbb = (ty == SIDE_FINE && (t >> 2)) ? B.nb[s][1] : B.nb[s][0];
+                        const int32_t id = ty == SIDE_MIRROR ? B.base + own + t * st : nbb + opp + tt * st;
+                        if (id != H.htab[(size_t)b * 64 + (s * 8 + t) * 2 + k]) { ok = false; break; }
+                    }
+            }
+        }
+        H.rows_ok = ok;
+    }
     if (H.img_all_fz && !H.fuse_all) ibh_build_quads2(H.blocks, H.htab, H.etab, is_imgblk, H.nph[1], H.quads[1], nc);
 }
 
@@ -211,6 +236,8 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         if ((rc = ibh_upload(&p->dtab, H.dtab.data(), H.dtab.size()))) return rc;
         p->n_dt = (int32_t)(H.dtab.size() / 64);
         p->fuse_all = H.fuse_all;
+        p->rows_ok = H.rows_ok;
+        p->info[16] = H.rows_ok;
         p->n_img = (int32_t)H.img.size();
         p->n_img_int = H.n_img_int;
         p->img_all_fz = H.img_all_fz;
@@ -393,7 +420,7 @@ int ibh_partition_destroy(ibh_part* p) {
 
 int ibh_partition_info(const ibh_part* p, int64_t* info, int n) {
     IBH_REQUIRE(p && info, "ibh_partition_info: null argument");
-    for (int i = 0; i < n && i < 16; ++i) info[i] = p->info[i];
+    for (int i = 0; i < n && i < 24; ++i) info[i] = p->info[i];
     return 0;
 }
 

@@ -101,6 +101,7 @@ struct ibh_part {
     int32_t* img_list = nullptr; // image blocks, ascending, the first n_img_int of them < nB1
     int32_t n_img = 0, n_img_int = 0, img_all_fz = 0;
     int32_t fuse_all = 0;        // 1: every block is eligible for the single-kernel sweep and there are no face-list cells
+    int32_t rows_ok = 0;         // 1: fuse_all and the arithmetic halo ids of the row sweep (ibh_rows2d.h) reproduce the halo table
     // quad sweeps (ibh_quad2d.h): set 0 = all blocks (used when fuse_all), set 1 = image blocks (used when img_all_fz)
     QuadDesc2* qd[2] = {nullptr, nullptr};
     int32_t* qtab[2] = {nullptr, nullptr};
@@ -124,7 +125,7 @@ struct ibh_part {
     // rec[(q*5 + 1 + k)*n_irr + t] = the cell across its k-th face (accumulator order).  One coalesced read
     // replaces the offsets -> face ids -> owner/neighbour chain of the CSR walk.
     int32_t* irr_rec = nullptr;
-    int64_t info[16] = {0};
+    int64_t info[24] = {0};
     // workspace for per-cell gradients + sensor (pass A output)
     float* G = nullptr;
     size_t G_bytes = 0;

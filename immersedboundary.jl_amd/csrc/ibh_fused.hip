@@ -486,6 +486,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 #include "ibh_sweep2d.h"
 #include "ibh_quad2d.h"
 #include "ibh_quad2d_euler.h"
+#include "ibh_rows2d.h"
 #include "ibh_strip3d.h"
 #include "ibh_strip3d_euler.h"
 #include "ibh_halo_dev.h"
@@ -637,6 +638,21 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
         dbg_stamp(slot, 1, __builtin_amdgcn_s_memrealtime());
         dbg_stamp(slot, 3, (unsigned long long)isq);
     }
+}
+
+// Row / column sweep (rows2::sweep_rows): one wavefront per EIGHT blocks, every complete block of a one-partition mesh
+#ifndef WPBR
+#define WPBR 4
+#endif
+__global__ __launch_bounds__(64 * WPBR) void k_sweep_rows(const float* __restrict__ u, const float* __restrict__ C,
+                                                          uint32_t ldc, float* __restrict__ ud,
+                                                          const BlockDesc2* __restrict__ blocks,
+                                                          const int32_t* __restrict__ etab, int32_t b0, int32_t n,
+                                                          int32_t nwg) {
+    __shared__ __attribute__((aligned(16))) float lds[WPBR * ROWS_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t first = __builtin_amdgcn_readfirstlane((xcd_remap(blockIdx.x, nwg) * WPBR + wave) * 8);
+    if (first < n) rows2::sweep_rows(blocks + b0, etab + (size_t)b0 * 16, first, n, u, C, ldc, ud, lds + wave * ROWS_LDS, lane);
 }
 
 // One step of a rank of a multi-GPU run in ONE launch: the xGMI halo exchange of u (ibh_halo_dev.h) and the image-only
@@ -983,6 +999,9 @@ const int ibh_3d_wave = getenv("IBH_3D_WAVE") ? atoi(getenv("IBH_3D_WAVE")) : 1;
 const int ibh_sweep_iters = getenv("IBH_SWEEP_ITERS") ? atoi(getenv("IBH_SWEEP_ITERS")) : 0;
 // IBH_QUAD=0: per-block single kernel everywhere (A/B runs)
 const int ibh_quad = getenv("IBH_QUAD") ? atoi(getenv("IBH_QUAD")) : 1;
+// row / column sweep (ibh_rows2d.h) where the partition qualifies: OFF by default -- measured slower than the quad sweep
+// (8.4 against 6.1 us at 0.87 M cells, 21.7 against 17.0 at 3.47 M: profiles/r3_final/probe_rows.json)
+int ibh_rows = getenv("IBH_ROWS") ? atoi(getenv("IBH_ROWS")) : 0;
 // ibh_set_tuning(key, v): "quad_variant" 4 = wave time stamps (scripts/wave_timeline.py); "quad_parts" 1 / 2 = only the
 // quads / only the single blocks of a quad sweep (measurement); "quad_singles_first" = grid order
 int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_first = 0, ibh_quad_singles_iters = 1;
@@ -1037,6 +1056,7 @@ int ibh_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "quad_parts")) ibh_quad_parts = value;
     else if (!strcmp(key, "quad_singles_first")) ibh_quad_singles_first = value;
     else if (!strcmp(key, "quad_singles_iters")) ibh_quad_singles_iters = value;
+    else if (!strcmp(key, "rows")) ibh_rows = value;
     else return ibh_fail(-1, "ibh_set_tuning: unknown key", __FILE__, __LINE__);
     return 0;
 }
@@ -1152,7 +1172,13 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
         IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
         const int32_t b0 = ph2 ? p->nB1 : 0, b1 = ph1 ? p->nB1 : p->nblk;
-        if (quads_ok(0)) launch_quads(0, ph1, ph2);
+        if (p->rows_ok && ibh_rows && !(flags & IBH_NO_QUAD) && ibh_quad_variant == 0) {
+            // row / column sweep: eight blocks per wavefront, arithmetic halo ids (`quad_variant` != 0: the quad forms)
+            const int32_t nw = (b1 - b0 + 7) / 8, nwg = (nw + WPBR - 1) / WPBR;
+            if (nwg > 0)
+                hipLaunchKernelGGL(k_sweep_rows, dim3(nwg), dim3(64 * WPBR), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
+                                   p->blocks2, p->etab, b0, b1 - b0, nwg);
+        } else if (quads_ok(0)) launch_quads(0, ph1, ph2);
         else launch_sweep(nullptr, b0, b1 - b0);
         IBH_LAUNCH_CHECK();
         return 0;

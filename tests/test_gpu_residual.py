@@ -321,3 +321,37 @@ def test_quad_sweep(adv_mesh, rae_mesh_small, case, kind):
     ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud2, flags=ibamd.IBH_PHASE_INTERIOR)
     ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud2, flags=ibamd.IBH_PHASE_BOUNDARY)
     assert np.array_equal(ibamd.to_host(ud2), got)
+
+
+@pytest.mark.parametrize("case", ["advection", "rae"])
+@pytest.mark.parametrize("kind", ["smooth", "step"])
+def test_row_sweep(adv_mesh, rae_mesh_small, case, kind):
+    """Row / column sweep (one wavefront per eight blocks, a lane per row then per column, arithmetic halo ids:
+    csrc/ibh_rows2d.h; opt-in) on one-partition domains: against the oracle and against the quad sweep."""
+    import torch
+    from conftest import ADV_FAMILIES, RAE_FAMILIES
+    from ibamd import _lib
+    from oracle import residual_c as rc
+    msh, fam = (adv_mesh, ADV_FAMILIES) if case == "advection" else (rae_mesh_small, RAE_FAMILIES)
+    dom = ibamd.Domain(msh, hypercube_families=fam, max_partition_size=10 ** 9)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    assert dpart.info["row_sweep"]   # the library checked its id arithmetic against the halo table of every block
+    u = seeded_field(part.centers, kind=kind)
+    C = np.stack([np.ones_like(u), f32(0.5) + seeded_field(part.centers, seed=3) * f32(0.1)], axis=1)
+    exp = rc.CPart(part).residual_advection(u, C)
+    quad = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C)))
+    ud = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.call("ibh_set_tuning", b"rows", 1)
+    try:
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud)
+        got = ibamd.to_host(ud)
+        ud2 = torch.full((u.shape[0],), float("nan"), dtype=torch.float32, device="cuda")
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud2, flags=ibamd.IBH_PHASE_INTERIOR)
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=ud2, flags=ibamd.IBH_PHASE_BOUNDARY)
+    finally:
+        _lib.call("ibh_set_tuning", b"rows", 0)
+    assert not np.isnan(got).any()
+    assert rel_inf(got, exp) <= TOL
+    assert rel_inf(got, quad) <= 2e-6
+    assert np.array_equal(ibamd.to_host(ud2), got)
