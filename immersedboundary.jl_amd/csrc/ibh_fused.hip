@@ -489,6 +489,7 @@ __device__ __forceinline__ void passB_adv_block2(const BlockDesc2* __restrict__ 
 #include "ibh_rows2d.h"
 #include "ibh_strip3d.h"
 #include "ibh_strip3d_euler.h"
+#include "ibh_cols3d.h"
 #include "ibh_halo_dev.h"
 #include "ibh_block3d.h"
 
@@ -869,6 +870,21 @@ __global__ __launch_bounds__(64 * WPB3S) __attribute__((amdgpu_waves_per_eu(WAVE
     if (blk < n) strip3::sweep_strip(blocks, htab, ftab, rtab, r4tab, blk, u, C, ldc, ud, lds + wave * S3_LDS, lane);
 }
 
+// Column form of the 3-D scalar sweep (cols3::sweep_cols): one wavefront per block
+#ifndef WPB3C
+#define WPB3C 2
+#endif
+template <int WAVES>
+__global__ __launch_bounds__(64 * WPB3C) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_sweep3_cols(
+    const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc, float* __restrict__ ud,
+    const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab, const int32_t* __restrict__ ftab,
+    const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg) {
+    __shared__ __attribute__((aligned(16))) float lds[WPB3C * C3_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3C + wave);
+    if (blk < n) cols3::sweep_cols(blocks, htab, ftab, rtab, r4tab, blk, u, C, ldc, ud, lds + wave * C3_LDS, lane);
+}
+
 // Column form of the 3-D Euler sweep (strip3e::sweep_euler_cols): one wavefront per block.  (A persistent form -- a
 // chain of blocks per wave, the first loads of the next block in flight during the z fluxes of the one in hand -- was
 // measured slower: 143 against 107 us at 4.56 M cells; the 26 registers of the prefetch and the second descriptor spill.)
@@ -1076,9 +1092,17 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
 #define S3_LAUNCH(W)                                                                                                  \
     hipLaunchKernelGGL(k_sweep3_strip<W>, dim3(nwg), dim3(64 * WPB3S), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->blocks3, \
                        p->htab3, p->ftab3, p->rtab3, p->r4tab3, p->nblk, nwg)
+#define C3_LAUNCH(W)                                                                                                  \
+    hipLaunchKernelGGL(k_sweep3_cols<W>, dim3(nwg), dim3(64 * WPB3C), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->blocks3, \
+                       p->htab3, p->ftab3, p->rtab3, p->r4tab3, p->nblk, nwg)
+                static_assert(WPB3C == WPB3S, "one grid for both forms");
                 if (ibh_quad_variant == 515) S3_LAUNCH(2);
                 else if (ibh_quad_variant == 514) S3_LAUNCH(4);
-                else S3_LAUNCH(3);
+                else if (ibh_quad_variant == 518) S3_LAUNCH(3);   // A/B: the strip form (round 2)
+                else if (ibh_quad_variant == 519) C3_LAUNCH(4);   // (7 registers spilled: 46 against 41 us at 4.56 M cells)
+                else if (ibh_quad_variant == 520) C3_LAUNCH(5);
+                else C3_LAUNCH(3);
+#undef C3_LAUNCH
 #undef S3_LAUNCH
             } else  // A/B: thread-per-cell form
             hipLaunchKernelGGL(k_sweep3_adv, dim3(p->nblk), dim3(512), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->blocks3,

@@ -1,0 +1,45 @@
+# Profile set of round 3 (run from the repo root on the GPU box):  bash scripts/collect_profiles_r3.sh <name> [quick]
+# Per workload: the bench line, a rocprofv3 kernel trace (kernel_stats_<tag>.csv) and PMC passes in separate runs
+# (pmc_summary_<tag>.json: FETCH_SIZE, WRITE_SIZE, SQ groups).  Writes gpurun_out/<name>/...; copy what is to be kept into
+# profiles/<name>/.  Every step appends to progress.log.
+export TMPDIR=/tmp
+N=${1:-r3}; O=$PWD/gpurun_out/$N; mkdir -p $O
+say() { echo "$(date +%T) $*" | tee -a $O/progress.log; }
+GROUPS_PMC=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+            "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM GRBM_GUI_ACTIVE")
+profile_one() {   # tag, bench args...
+  local tag=$1; shift
+  local B="python3 bench.py --no-cpu-baseline $*"
+  say "bench $tag"; $B > $O/bench_$tag.json 2>>$O/bench.err
+  say "kernel trace $tag"
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -o kt -- $B --repeats 3 > $O/kt_$tag.log 2>&1 || say "kernel trace failed: $tag"
+  cp $(find $O/kt_$tag -name '*kernel_stats.csv' | head -1) $O/kernel_stats_$tag.csv 2>/dev/null
+  mkdir -p $O/p_$tag
+  for c in "${GROUPS_PMC[@]}"; do
+    local t=$(echo $c | tr ' ' '_' | cut -c1-60)
+    say "pmc $tag $c"
+    timeout -k 10 600 rocprofv3 --pmc $c --output-format csv -d $O/p_$tag/pmc_$t -o pmc -- $B --repeats 3 > $O/p_$tag/pmc_$t.log 2>&1 || say "pass failed: $tag $c"
+  done
+  python3 scripts/summarize_pmc.py $O/p_$tag > $O/pmc_summary_$tag.json
+  rm -rf $O/kt_$tag $O/p_$tag $O/kt_$tag.log
+}
+say "headline with the cpu baseline"; python3 bench.py > $O/bench.json 2>$O/bench.err
+profile_one headline
+profile_one euler2d --residual euler
+profile_one 3d_4.6M --workload sphere3d_4.6M --steps 100 --warmup 10
+profile_one 3d_euler_4.6M --workload sphere3d_4.6M --residual euler --steps 50 --warmup 5
+profile_one 3.47M --workload rae2822_3.47M
+if [ "$2" != "quick" ]; then
+  say 28M; python3 bench.py --no-cpu-baseline --workload rae2822_28M --steps 50 --warmup 5 --repeats 5 > $O/bench_28M.json 2>>$O/bench.err
+  say "3d euler 33M"; bash scripts/with_heartbeat.sh $O/progress.log python3 bench.py --no-cpu-baseline --workload sphere3d_33M --residual euler --steps 20 --warmup 3 --repeats 5 > $O/bench_3d_euler_33M.json 2>>$O/bench.err
+  say "3d 33M"; bash scripts/with_heartbeat.sh $O/progress.log python3 bench.py --no-cpu-baseline --workload sphere3d_33M --steps 50 --warmup 5 --repeats 5 > $O/bench_3d_33M.json 2>>$O/bench.err
+  say config4; python3 bench.py --no-cpu-baseline --workload sphere3d_8M --residual euler --step config4 --steps 20 --warmup 3 --repeats 5 > $O/bench_config4_8M.json 2>>$O/bench.err
+  say "config5 33M"; bash scripts/with_heartbeat.sh $O/progress.log python3 bench.py --no-cpu-baseline --workload sphere3d_33M --residual euler --step config5 --steps 3 --warmup 1 --repeats 2 > $O/bench_config5_33M.json 2>>$O/bench.err
+fi
+say probes
+python3 scripts/probe_3d_euler.py sphere3d_1.6M > $O/probe_3d_euler_1.6M.json 2>>$O/bench.err
+python3 scripts/probe_3d_euler.py sphere3d_4.6M > $O/probe_3d_euler_4.6M.json 2>>$O/bench.err
+python3 scripts/probe_3d.py > $O/probe_3d_4.6M.json 2>>$O/bench.err
+python3 scripts/wave_timeline_3d.py > $O/wave_timeline_3d_euler_4.6M.json 2>>$O/bench.err
+python3 scripts/probe_rows.py > $O/probe_rows_0.87M.json 2>>$O/bench.err
+say done

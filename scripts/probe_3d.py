@@ -1,4 +1,5 @@
-"""A/B of the 3-D scalar sweep forms on one workload (run on the GPU box): python scripts/probe_3d.py [workload]"""
+"""A/B of the 3-D scalar sweep forms on one workload (run on the GPU box): python scripts/probe_3d.py [workload]
+column form (cols3::sweep_cols), strip form (strip3::sweep_strip), thread-per-cell single kernel, two-kernel form."""
 import json
 import os
 import sys
@@ -47,7 +48,8 @@ def timed(fn, n=20, reps=15):
 out = {"workload": name, "cells": int(dpart.nc), "blocks": int(dpart.info["full_blocks"]),
        "single_kernel_blocks": int(dpart.info["fusable_blocks"])}
 ref = None
-for key, var in (("strip_3_waves_per_simd_us", 0), ("strip_2_waves_per_simd_us", 515), ("strip_4_waves_per_simd_us", 514),
+for key, var in (("strip_3_waves_per_simd_us", 518), ("cols_3_waves_per_simd_us", 0), ("cols_4_waves_per_simd_us", 519),
+                 ("cols_5_waves_per_simd_us", 520), ("strip_2_waves_per_simd_us", 515), ("strip_4_waves_per_simd_us", 514),
                  ("thread_per_cell_us", 512)):
     _lib.call("ibh_set_tuning", b"quad_variant", var)
     out[key] = round(timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud)), 3)
