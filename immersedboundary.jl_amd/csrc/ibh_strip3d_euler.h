@@ -196,6 +196,9 @@ __device__ __forceinline__ void euler_flux(const T* Pa, const T* Pb, const T* Sa
     const T cL = wL * uL - c, cR = c - wR * uR;
 #pragma unroll
     for (int v = 0; v < 5; ++v) F[v] = QL[v] * cL + QR[v] * cR;
+    // (the form (QL - QR) cL + QR (cL + cR), exact in the difference of the states, was measured: the same error against
+    // the Float64 combine of the reference -- 9.6e-6 of max |R| on tests/test_config5.py either way -- at five more
+    // instructions per face: the error is the Float32 rounding of the fluxes themselves)
     const T mL = wL * pL, mR = wR * pR;
     F[2 + DN] += mL - mR;
     F[1] += mL * uL - mR * uR;

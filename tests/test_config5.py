@@ -21,6 +21,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 f32 = np.float32
 pytestmark = pytest.mark.gpu
 NU = f32(1.5e-5)
+RES_TOL = 1e-5   # north-star tolerance; measured on the fine level 3.1e-6 (p) .. 9.6e-6 (w momentum): the tuned sweep
+                 # evaluates the HLL fluxes in Float32, the reference promotes their combine to Float64 (cfd.jl:504-507);
+                 # the coarse levels (face-list kernels, literal arithmetic) reproduce the oracle bit for bit
 
 
 def _oracle_acc(acc):
@@ -90,8 +93,9 @@ def test_config5_fas_vcycle_with_turbulence_scalar():
     for l in range(3):
         ro, _ = o_f(l, Ql_o)
         rg, _ = g_f(l, Ql_g)
-        for v in range(6):
-            assert rel_inf(ibamd.to_host(rg)[:, v], ro[:, v]) <= 2e-5, (l, v)
+        errs = {v: float(rel_inf(ibamd.to_host(rg)[:, v], ro[:, v])) for v in range(6)}
+        print(f"config-5 residual, level {l}: rel_inf per variable", errs)
+        assert max(errs.values()) <= RES_TOL, (l, errs)
         if l < 2:
             Ql_o = ocoar[l](Ql_o)
             Ql_g = ibamd.to_backend(coar[l])(Ql_g)
@@ -103,6 +107,7 @@ def test_config5_fas_vcycle_with_turbulence_scalar():
     ratio_g = ibamd.FAS(g_f, Qg, coarseners=coar, prolongators=prol, n_iter=3, rtol=1e-6)
     got = ibamd.to_host(Qg)
     assert not np.array_equal(Qo, Q0) and np.isfinite(got).all()
-    for v in range(6):
-        assert rel_inf(got[:, v], Qo[:, v]) <= 2e-5, v
+    errs = {v: float(rel_inf(got[:, v], Qo[:, v])) for v in range(6)}
+    print("config-5 V-cycle: rel_inf per variable", errs)
+    assert max(errs.values()) <= 1e-5, errs
     assert abs(ratio_g - float(ratio_o)) <= 1e-3 * max(1.0, float(ratio_o))

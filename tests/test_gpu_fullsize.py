@@ -143,20 +143,20 @@ def test_full_size_per_cell_error_percentiles(full, capsys):
     part, dpart, u, C = full
     exp = rc.CPart(part).residual_advection(u, C).astype(np.float64)
     got = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C))).astype(np.float64)
-    h = part.spacing.min(axis=1).astype(np.float64)
-    local = np.abs(exp) + np.abs(u.astype(np.float64)) / h
-    rel = np.abs(got - exp) / local
+    from conftest import stencil_scale
+    rel = np.abs(got - exp) / stencil_scale(part, u, exp)
     pct = {f"p{p}": float(np.percentile(rel, p)) for p in (50, 90, 99, 99.9)}
     pct["max"] = float(rel.max())
     pct["norm_wise"] = float(np.abs(got - exp).max() / np.abs(exp).max())
     with capsys.disabled():
         print("\nper-cell relative error of the tuned sweep (0.87 M cells):", json.dumps(pct))
-    assert pct["p99.9"] <= 2e-6 and pct["max"] <= 2e-5 and pct["norm_wise"] <= 1e-5
+    # (measured: max 5.9e-7, p99.9 3.4e-7; the same bound as the 3-D sweeps below)
+    assert pct["p99.9"] <= 1e-6 and pct["max"] <= 2e-6 and pct["norm_wise"] <= 1e-5
 
 
 def test_3d_single_kernel_sweeps_at_bench_size():
     """The 3-D workloads of bench.py at full size (sphere-in-box octree, 1 667 072 cells, every kind of block side): the
-    single-kernel sweeps -- strip form (scalar), workgroup form (Euler) -- against the C restatement on the whole mesh,
+    single-kernel sweeps -- column forms (scalar and Euler: one wavefront per block) -- against the C restatement on the whole mesh,
     against the thread-per-cell and the two-kernel forms, and the size-independent properties of the closure."""
     import bench
     from ibamd import _lib
@@ -186,12 +186,15 @@ def test_3d_single_kernel_sweeps_at_bench_size():
         assert rel_inf(got, exp) <= 1e-5
     assert rel_inf(strip, cellk) <= 2e-6 and rel_inf(strip, two) <= 2e-6
     # per cell (as in the 2-D test above): error relative to the local scale |ref| + |u| / h
+    from conftest import stencil_scale
     e64, s64 = exp.astype(np.float64), strip.astype(np.float64)
-    rel = np.abs(s64 - e64) / (np.abs(e64) + np.abs(u.astype(np.float64)) / part.spacing.min(axis=1).astype(np.float64))
+    rel = np.abs(s64 - e64) / stencil_scale(part, u, e64)
     pct = {f"p{q}": float(np.percentile(rel, q)) for q in (50, 99, 99.9)}
     pct["max"] = float(rel.max())
-    print("\nper-cell relative error of the 3-D strip sweep (1.67 M cells):", pct)
-    assert pct["p99.9"] <= 2e-6 and pct["max"] <= 5e-5
+    print("\nper-cell relative error of the 3-D column sweep (1.67 M cells):", pct)
+    # (measured: max 7.7e-7, p99.9 3.7e-7.  Round 2 divided by |ref| + |u| / h of the cell alone and needed 5e-5: its worst
+    # cells are zero crossings of u, not sensor effects -- conftest.stencil_scale)
+    assert pct["p99.9"] <= 1e-6 and pct["max"] <= 2e-6
     const = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(np.full(n, 3.25, dtype=f32)), dC))
     assert np.array_equal(const, np.zeros(n, dtype=f32))            # constant field: exactly zero
     r4 = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(f32(4.0) * u), dC))
