@@ -499,6 +499,7 @@ class Mesh:
             ref_regions.append((dfields[name], hs[name] * bs))
         if verbose:
             print("Refining region tree...", file=sys.stderr)
+        self.ref_regions, self.growth_ratio = ref_regions, growth_ratio   # (kept: what refine_octree was called with)
         ows = refine_octree(ref_regions, self.origin, self.widths, growth_ratio)
         self.block_origins = np.stack([t[0] for t in ows], axis=1)
         self.block_widths = np.stack([t[1] for t in ows], axis=1)

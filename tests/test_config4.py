@@ -98,7 +98,11 @@ def test_config4_bc_sweep_point_implicit(sphere_case):
     h = 1e-2
     D_n = opi.hutchinson_trick(f_np, X0, samp, h=f32(h))
     D_g = pi.hutchinson_trick(f_dev, ibamd.hip(X0), 2, h=h, samples=dsamp).cpu().numpy()
-    assert np.abs(D_g - D_n).max() <= 1e-2 * np.abs(D_n).max()         # Float32 finite differences on both sides
+    # Float32 finite differences on both sides, h = 1e-2 on a +-1 sample: for the pressure column that perturbation is ONE
+    # ulp of 1e5 (0.0078), so a Jacobian-vector product carries ~1e-2 of rounding noise whatever computes it.  The
+    # kernels behind these products are compared tightly on exact pointwise systems (tests/test_point_implicit.py:
+    # block inversion 2e-4 of the block scale, block apply 1e-5); here the comparison can only show that both sides see the same operator.
+    assert np.abs(D_g - D_n).max() <= 1e-2 * np.abs(D_n).max()
     lin_n, b_n, invD_n = opi.linearize(f_np, X0, samp, h=f32(h))
     lin, b, prec = pi.linearize(f_dev, ibamd.hip(X0), 2, h=h, samples=dsamp)
     for v in range(5):
