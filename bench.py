@@ -331,18 +331,19 @@ def main():
                 if rank == 0:
                     print(f"[bench] xgmi halo exchange unavailable ({e}); using {halo_kind}", file=sys.stderr)
         # (the Euler sweep has overlap phases only where the image blocks all take the single kernel)
-        overlap = (args.overlap and not args.no_overlap and not args.general and dpart.info["interior_blocks"] > 0
-                   and (not euler or image_only))
+        auto_forms = args.halo == "auto" and not (args.overlap or args.fused_step or args.no_overlap)
+        can_overlap = (not args.general and dpart.info["interior_blocks"] > 0 and (not euler or image_only))
+        overlap = args.overlap and not args.no_overlap and can_overlap
         comm_stream = torch.cuda.Stream() if overlap else None
         # exchange + image-only quad sweep as ONE launch (XgmiHalo.fused_step: the exchange workgroups run beside the
         # interior quads), taken when it reproduces exchange-then-sweep bit for bit on every rank
         # Every rank must take the same branch (the trial holds collectives): the rank-local predicate is all-reduced.
         red0 = u.device if args.backend == "nccl" else "cpu"
-        elig = int(bool(args.fused_step and halo_kind == "xgmi-direct" and image_only and not euler
+        elig = int(bool((args.fused_step or auto_forms) and halo_kind == "xgmi-direct" and image_only and not euler
                         and comm_stream is None and flags == ibamd.IBH_IMAGE_ONLY))
         te = torch.tensor([elig], dtype=torch.int32, device=red0)
         dist.all_reduce(te, op=dist.ReduceOp.MIN)
-        if args.fused_step and int(te.item()):
+        if int(te.item()):
             ok_f = 0
             try:
                 ref_f = torch.zeros_like(ud)
@@ -357,20 +358,23 @@ def main():
             # decision to launch is collective too
             tf = torch.tensor([ok_f and int(hx.can_fuse(dpart))], dtype=torch.int32, device=red0)
             dist.all_reduce(tf, op=dist.ReduceOp.MIN)
+            launched = bool(int(tf.item()))
             ok_f = 0
-            if int(tf.item()):
+            if launched:
                 try:
                     hx.fused_step(dpart, u, C, got_f)
                     torch.cuda.synchronize()
                     ok_f = int(bool(torch.equal(got_f, ref_f)))
                 except Exception as e:  # noqa: BLE001
                     print(f"[bench] rank {rank}: fused exchange + sweep step failed ({e})", file=sys.stderr)
+            elif rank == 0:
+                print("[bench] fused exchange + sweep step: not available on every rank's partition", file=sys.stderr)
             tf = torch.tensor([ok_f and int(hx.healthy())], dtype=torch.int32, device=red0)
             dist.all_reduce(tf, op=dist.ReduceOp.MIN)
             fused_step = bool(tf.item())
             if fused_step:
                 halo_kind = "xgmi-direct, fused with the sweep (one launch per step)"
-            elif not hx.healthy() or not int(tf.item()):
+            elif launched:
                 # the exchanger's sequence numbers may be out of step after a failed trial: do not keep it
                 if args.halo == "xgmi":
                     raise SystemExit("fused exchange + sweep trial failed on a rank; rerun without --fused-step")
@@ -409,6 +413,8 @@ def main():
         def f5(level, Q):
             return euler_wray_agarwal_residual(levels5[level], Q), 2e-7
 
+    step_form = {"fused": fused_step, "overlap": comm_stream is not None}
+
     def step():
         if config5:
             Q5.copy_(Q5_0)
@@ -419,11 +425,11 @@ def main():
             sweep()
         elif hx is None:
             sweep()
-        elif fused_step:
+        elif step_form["fused"]:
             hx.fused_step(dpart, u, C, ud)
-        elif comm_stream is not None and euler:
+        elif step_form["overlap"] and euler:
             euler_sweep_overlapped(hx, dpart, P, Rres, comm_stream, flags=flags)
-        elif comm_stream is not None:
+        elif step_form["overlap"]:
             sweep_overlapped(hx, dpart, u, C, ud, comm_stream, flags=flags)
         else:
             hx.exchange(P if euler else u)
@@ -434,6 +440,79 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # --halo auto on real peers: the step forms that are available here -- exchange-then-sweep, the fused launch (if its
+    # trial reproduced exchange-then-sweep bit for bit on every rank), the overlapped phases (if they do) -- are timed for
+    # 50 steps each and the fastest is taken; every decision is collective (all-reduced), the three times are reported.
+    auto_step_us = None
+    if world > 1 and auto_forms and not (config4 or config5):
+        red0 = u.device if args.backend == "nccl" else "cpu"
+
+        def agree(flag):
+            t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=red0)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        base_kind = "xgmi-direct" if (halo_kind or "").startswith("xgmi-direct") else halo_kind
+        forms = [("exchange-then-sweep", False, False)]
+        if fused_step:
+            forms.append(("fused", True, False))
+        if agree(can_overlap):
+            ok_o = False
+            try:   # the overlapped phases must reproduce exchange-then-sweep bit for bit before they are timed
+                comm_stream = torch.cuda.Stream()
+                ref_o = (Rres if euler else ud).clone()
+                step_form.update(fused=False, overlap=False)
+                step()
+                torch.cuda.synchronize()
+                ref_o.copy_(Rres if euler else ud)
+                step_form.update(overlap=True)
+                step()
+                torch.cuda.synchronize()
+                ok_o = bool(torch.equal(ref_o, Rres if euler else ud))
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: overlapped step failed ({e})", file=sys.stderr)
+            if agree(ok_o):
+                forms.append(("overlap", False, True))
+        can_graph = (halo_kind or "").startswith("xgmi-direct")
+        auto_step_us = {}
+        for name, fz, ov in forms:
+            step_form.update(fused=fz, overlap=ov)
+            nrep, gsz = 5, 10
+            torch.cuda.synchronize()
+            dist.barrier()
+            sg = torch.cuda.Stream()
+            g = None
+            with torch.cuda.stream(sg):
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                if can_graph:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=sg):
+                        for _ in range(gsz):
+                            step()
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(nrep):
+                    if g is not None:
+                        g.replay()
+                    else:
+                        for _ in range(gsz):
+                            step()
+                torch.cuda.synchronize()
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red0)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            auto_step_us[name] = round(float(tt.item()) / (nrep * gsz) * 1e6, 3)
+            del g
+        best = min(auto_step_us, key=auto_step_us.get)     # (identical on every rank: the times were all-reduced)
+        fused_step = best == "fused"
+        step_form.update(fused=fused_step, overlap=best == "overlap")
+        if best != "overlap":
+            comm_stream = None
+        halo_kind = base_kind if best == "exchange-then-sweep" else (
+            "xgmi-direct, fused with the sweep (one launch per step)" if fused_step else (base_kind or "") + ", overlapped phases")
 
     # The sweep is ~10 us of GPU work: a Python/ctypes launch per step would be host-bound, so on one GPU
     # the step loop is captured into HIP graphs of `graph_batch` sweeps each (every sweep still runs in full).
@@ -657,7 +736,8 @@ def main():
                             if mixed else "block-fast-path, two kernels"),
                    "launch": f"hip-graph x{batch}" if batch else "eager",
                    "halo": None if hx is None else {"backend": args.backend, "exchange": halo_kind,
-                                                    "overlap": comm_stream is not None, "timeouts": halo_timeouts,
+                                                    "overlap": bool(step_form["overlap"]), "timeouts": halo_timeouts,
+                                                    "auto_step_us": auto_step_us,
                                                     "send_cells": hx.plan.n_send, "recv_cells": hx.plan.n_recv,
                                                     "peers": len(hx.plan.peers),
                                                     "interior_blocks": dpart.info["interior_blocks"]},

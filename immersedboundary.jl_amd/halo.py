@@ -239,60 +239,94 @@ class XgmiHalo:
         self.B, self.C, self.dist, self.group = B, C, dist, group
         self.plan, self.nv, self.max_spins = plan, nv, int(max_spins)
         self.device = torch.device(device)
-        B._dev()
-        world = dist.get_world_size(group)
-        me = plan.pid - 1
+        self.world = dist.get_world_size(group)
+        self.me = plan.pid - 1
         self.peers_recv, self.peers_send = sorted(plan.recv), sorted(plan.send)
+        self._recv = self._flags = None
+        self._opened = []
+        # Set-up is collective: EVERY step that can fail on one rank alone (no device, allocation, IPC export / import,
+        # device tables) runs under `_agree`, which gathers the outcome of all ranks -- either every rank gets an
+        # exchanger or all of them raise the same error here; nobody is left waiting in a collective of a later step.
+        self._agree(self._setup_device, "device set-up")
         # The double-buffer argument (class docstring) needs every peer I write to to be a peer I wait on: only then
         # am I at most one step ahead of it.  Skirt dependencies are symmetric for face-connected partitions; a
         # one-sided plan (e.g. donor-extended lists) is rejected here, collectively, instead of racing silently.
-        sym = torch.tensor([1 if self.peers_recv == self.peers_send else 0], dtype=torch.int32,
-                           device=self.device if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(sym, op=dist.ReduceOp.MIN, group=group)
-        if not bool(sym.item()):
+        sym = self._agree(lambda: self.peers_recv == self.peers_send, "peer lists", gather=True)
+        if not all(sym):
             raise ValueError("XgmiHalo needs symmetric peers (every send peer is also a receive peer) on every rank")
         self.recv_off, o = {}, 0
         for q in self.peers_recv:
             self.recv_off[q] = o
             o += nv * int(plan.recv[q].size)
         self.n_recv_f = o
-        # Set-up is collective: every step that can fail locally is followed by an agreement point, so that
-        # either all ranks get an exchanger or all of them raise (nobody is left waiting in a collective).
-        self._recv = B.c_vp()
-        self._flags = B.c_vp()
-        self._opened = []
-        mine, err = None, None
-        try:
-            B.call("ibh_ipc_alloc", C.byref(self._recv), 2 * max(o, 1) * 4, 1)
-            B.call("ibh_ipc_alloc", C.byref(self._flags), world * 4, 1)
-            hr, hf = (C.c_ubyte * 64)(), (C.c_ubyte * 64)()
-            B.call("ibh_ipc_export", self._recv, C.cast(hr, B.c_vp))
-            B.call("ibh_ipc_export", self._flags, C.cast(hf, B.c_vp))
-            mine = dict(recv=bytes(hr), flags=bytes(hf), off={int(q): int(v) for q, v in self.recv_off.items()},
-                        n=int(o))
-        except Exception as e:  # noqa: BLE001
-            err = repr(e)
-        every = [None] * world
-        dist.all_gather_object(every, (mine, err), group=group)
-        if any(x[1] for x in every):
-            raise RuntimeError("XgmiHalo: allocation/export failed on a rank: " + "; ".join(str(x[1]) for x in every if x[1]))
+        every = self._agree(self._ipc_alloc_export, "allocation / IPC export", gather=True)
         self.remote = {}       # q -> (recv base address, floats per parity, my offset, flag slot address)
-        err = None
+        self._agree(lambda: self._ipc_import(every), "mapping a peer buffer")
+        self._agree(self._device_tables, "device tables")
+        self.step = 0
+        dist.barrier(group=group)
+
+    def _agree(self, fn, what, gather=False):
+        """Run ``fn`` on this rank, then gather (value, error) of every rank: raise on ALL ranks if any failed.  Returns
+        this rank's value, or the list of every rank's value (``gather``)."""
+        val, err = None, None
         try:
-            for q in self.peers_send:
-                info = every[q - 1][0]
-                pr, pf = B.c_vp(), B.c_vp()
-                B.call("ibh_ipc_import", C.cast(C.create_string_buffer(info["recv"], 64), B.c_vp), C.byref(pr))
-                self._opened.append(pr)
-                B.call("ibh_ipc_import", C.cast(C.create_string_buffer(info["flags"], 64), B.c_vp), C.byref(pf))
-                self._opened.append(pf)
-                self.remote[q] = (pr.value, info["n"], info["off"][plan.pid], pf.value + 4 * me)
-        except Exception as e:  # noqa: BLE001
-            err = repr(e)
-        errs = [None] * world
-        dist.all_gather_object(errs, err, group=group)
-        if any(errs):
-            raise RuntimeError("XgmiHalo: mapping a peer buffer failed: " + "; ".join(str(x) for x in errs if x))
+            val = fn()
+        except Exception as e:  # noqa: BLE001 -- any local failure must become everybody's failure
+            err = f"rank {self.me}: {e!r}"
+        every = [None] * self.world
+        self.dist.all_gather_object(every, (val if gather else None, err), group=self.group)
+        errs = [x[1] for x in every if x[1]]
+        if errs:
+            self._release_local()
+            raise RuntimeError(f"XgmiHalo: {what} failed on a rank: " + "; ".join(errs))
+        return [x[0] for x in every] if gather else val
+
+    def _release_local(self):
+        """Free what this rank has allocated or mapped so far (no collective inside)."""
+        for p in self._opened:
+            try:
+                self.B.call("ibh_ipc_close", p)
+            except Exception:  # noqa: BLE001
+                pass
+        self._opened = []
+        for name in ("_recv", "_flags"):
+            p = getattr(self, name, None)
+            if p is not None and getattr(p, "value", None):
+                try:
+                    self.B.call("ibh_ipc_free", p)
+                except Exception:  # noqa: BLE001
+                    pass
+            setattr(self, name, None)
+
+    # ---- the steps of the set-up that touch the device (overridden by the CPU tests of the agreement logic)
+    def _setup_device(self):
+        self.B._dev()
+
+    def _ipc_alloc_export(self):
+        B, C = self.B, self.C
+        self._recv, self._flags = B.c_vp(), B.c_vp()
+        B.call("ibh_ipc_alloc", C.byref(self._recv), 2 * max(self.n_recv_f, 1) * 4, 1)
+        B.call("ibh_ipc_alloc", C.byref(self._flags), self.world * 4, 1)
+        hr, hf = (C.c_ubyte * 64)(), (C.c_ubyte * 64)()
+        B.call("ibh_ipc_export", self._recv, C.cast(hr, B.c_vp))
+        B.call("ibh_ipc_export", self._flags, C.cast(hf, B.c_vp))
+        return dict(recv=bytes(hr), flags=bytes(hf), off={int(q): int(v) for q, v in self.recv_off.items()},
+                    n=int(self.n_recv_f))
+
+    def _ipc_import(self, every):
+        B, C = self.B, self.C
+        for q in self.peers_send:
+            info = every[q - 1]
+            pr, pf = B.c_vp(), B.c_vp()
+            B.call("ibh_ipc_import", C.cast(C.create_string_buffer(info["recv"], 64), B.c_vp), C.byref(pr))
+            self._opened.append(pr)
+            B.call("ibh_ipc_import", C.cast(C.create_string_buffer(info["flags"], 64), B.c_vp), C.byref(pf))
+            self._opened.append(pf)
+            self.remote[q] = (pr.value, info["n"], info["off"][self.plan.pid], pf.value + 4 * self.me)
+
+    def _device_tables(self):
+        C, plan = self.C, self.plan
         self.send_idx = {q: torch.from_numpy(plan.send[q]).to(self.device) for q in self.peers_send}
         self.recv_idx = {q: torch.from_numpy(plan.recv[q]).to(self.device) for q in self.peers_recv}
         self.recv_all = torch.cat([self.recv_idx[q] for q in self.peers_recv]) if self.peers_recv else None
@@ -312,9 +346,8 @@ class XgmiHalo:
                                                         for q in self.peers_send]))
         self._sflags = (C.c_void_p * max(ns, 1))(*[self.remote[q][3] for q in self.peers_send])
         self._rflags = (C.c_void_p * max(nr, 1))(*[self._flags.value + 4 * (q - 1) for q in self.peers_recv])
-        self.step = 0
-        torch.cuda.synchronize()
-        dist.barrier(group=group)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
 
     def start(self, field):
         """The whole exchange, one launch (``ibh_halo_exchange``); ``finish`` has nothing left to do."""
@@ -346,9 +379,9 @@ class XgmiHalo:
         skirt fragments whose image blocks are all eligible for the quad sweep, a scalar exchanger with peers) -- a
         rank-local predicate: callers that run collectively all-reduce it before any rank launches."""
         info = dpart.info
+        has_fragments = info.get("irregular_cells", 0) > 0 or info.get("fusable_blocks") != info.get("full_blocks")
         return bool(self.nv == 1 and dpart.nd == 2 and info.get("image_blocks_all_eligible")
-                    and info.get("image_quads", 0) > 0 and info.get("fusable_blocks") != info.get("full_blocks")
-                    and (self.peers_send or self.peers_recv))
+                    and info.get("image_quads", 0) > 0 and has_fragments and (self.peers_send or self.peers_recv))
 
     def fused_step(self, dpart, u, C, ud):
         """Exchange of the scalar field ``u`` + the image-only quad sweep ``ud = residual_advection(u, C)`` in ONE launch
@@ -389,31 +422,39 @@ class XgmiHalo:
         self.state[2] = 0
 
     def close(self):
-        torch.cuda.synchronize()
+        """Collective: peers unmap before anybody frees."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
         self.dist.barrier(group=self.group)
         for p in self._opened:
             self.B.call("ibh_ipc_close", p)
         self._opened = []
         self.dist.barrier(group=self.group)
-        self.B.call("ibh_ipc_free", self._recv)
-        self.B.call("ibh_ipc_free", self._flags)
+        self._release_local()
 
 
 def verify_exchangers(a, b, nc, nv, rounds=3):
-    """Run both exchangers on the same random fields; True iff every rank got identical skirt values."""
+    """Run both exchangers on the same random fields; True iff every rank got identical skirt values.  Collective: a rank
+    on which an exchange raises still takes part in the all-reduce (everybody then gets False)."""
     import torch.distributed as dist
     dev = a.device
     ok = True
-    for r in range(rounds):
-        g = torch.Generator(device="cpu").manual_seed(1234 + 17 * r + a.plan.pid)
-        base = torch.rand((nv, nc), generator=g) if nv > 1 else torch.rand(nc, generator=g)
-        fa, fb = base.to(dev).clone(), base.to(dev).clone()
-        if nv > 1:
-            fa, fb = fa.T, fb.T  # (nc, nv) column-major views
-        a.exchange(fa)
-        b.exchange(fb)
-        torch.cuda.synchronize()
-        ok = ok and bool(torch.equal(fa, fb))
+    try:
+        for r in range(rounds):
+            g = torch.Generator(device="cpu").manual_seed(1234 + 17 * r + a.plan.pid)
+            base = torch.rand((nv, nc), generator=g) if nv > 1 else torch.rand(nc, generator=g)
+            fa, fb = base.to(dev).clone(), base.to(dev).clone()
+            if nv > 1:
+                fa, fb = fa.T, fb.T  # (nc, nv) column-major views
+            a.exchange(fa)
+            b.exchange(fb)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(fa, fb))
+    except Exception as e:  # noqa: BLE001
+        import sys
+        print(f"[halo] rank {a.plan.pid - 1}: exchanger verification raised {e!r}", file=sys.stderr)
+        ok = False
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend(a.group) == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=a.group)
     return bool(t.item())
