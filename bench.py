@@ -189,7 +189,7 @@ def main():
                          "reproduces the rccl exchange bit for bit at start-up, else rccl")
     ap.add_argument("--graph-batch", type=int, default=20,
                     help="sweeps captured per HIP graph (launch-bound loop; 0 = eager launches)")
-    ap.add_argument("--step", default="sweep", choices=["sweep", "config4", "config5"],
+    ap.add_argument("--step", default="sweep", choices=["sweep", "march", "config4", "config5"],
                     help="config4 (3-D workloads, --residual euler): a step = impose_bc! with FlowBC closures on the "
                          "immersed sphere and the far field (ghost-layer interpolation) + the Euler residual sweep; one "
                          "point-implicit linearise + relaxation is timed beside it; config5: a step = one FAS! V-cycle "
@@ -266,13 +266,17 @@ def main():
     mps = -(-mps // npb) * npb  # block-aligned partitions
     config4 = args.step == "config4"
     config5 = args.step == "config5"
+    march = args.step == "march"
+    if march and (msh.ndims != 2 or args.residual != "advection" or world != 1):
+        raise SystemExit("--step march: the explicit step of test/advection.jl on a 2-D workload, one GPU")
     if (config4 or config5) and (msh.ndims != 3 or args.residual != "euler" or world != 1):
         raise SystemExit("--step config4 / config5 need a sphere3d workload, --residual euler and one GPU")
     if config5:
         msh.distance_fields = {}  # the V-cycle line builds no ghost cells (config4 does)
     fam4 = [("farfield", [(d, s_) for d in (1, 2, 3) for s_ in (False, True)])]
-    dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=config4, only=[rank + 1],
-                       hypercube_families=fam4 if config4 else ())
+    fam2 = [("farfield", [(1, False), (1, True), (2, False), (2, True)])]
+    dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=config4 or march, only=[rank + 1],
+                       hypercube_families=fam4 if config4 else fam2 if march else ())
     part = dom.partitions[rank + 1]
     n_image = int(part.image.size)
     u_h, C_h = synthetic_fields(part.centers)
@@ -415,7 +419,22 @@ def main():
 
     step_form = {"fused": fused_step, "overlap": comm_stream is not None}
 
+    if march:
+        # march! of test/advection.jl:61-89, device resident: dt by a device reduction (every 10 steps here: C is constant),
+        # sweep + u .+= ud .* dt in one launch, the impose_bc! calls as one BC set (wall: value 0, far field: copy(u))
+        bcs_m = ibamd.BCSet(dom, [(name, "copy" if name == "farfield" else 0.0) for name in dom.boundaries], ipart=rank + 1)
+        dt_m = ibamd.timestep_advection(dpart, C, scale=0.75)
+        um = [u.clone(), torch.empty_like(u)]
+        mstate = {"k": 0}
+
     def step():
+        if march:
+            k = mstate["k"]
+            if k % 10 == 0:
+                ibamd.timestep_advection(dpart, C, scale=0.75, out=dt_m)
+            ibamd.step_advection(dpart, um[k & 1], C, dt_m, bcs_m, out=um[(k + 1) & 1])
+            mstate["k"] = k + 1
+            return
         if config5:
             Q5.copy_(Q5_0)
             ibamd.FAS(f5, Q5, coarseners=coar5, prolongators=prol5, n_iter=2, rtol=1e-9)
@@ -769,6 +788,13 @@ def main():
                                                     "what": "pseudo-time step (P - P0)/dt - R(P), Hutchinson block "
                                                             "estimate with 1 sample per variable (6 sweeps), one two-"
                                                             "direction relaxation (2 sweeps)"}}
+    if march:
+        out["metric"] = "Mcells*steps/s, explicit march (device dt + sweep and update in one launch + BC set), 2D RAE2822"
+        out["config"]["step"] = {"ghost_cells": int(bcs_m.n_ghost), "bc_set_levels": int(bcs_m.n_levels),
+                                 "dt_reduction_every": 10, "finite": bool(torch.isfinite(um[0]).all().item()),
+                                 "what": "test/advection.jl:61-89 without the host in the loop: ibh_timestep_advection every "
+                                         "10 steps, ibh_step_advection (k_sweep_quad storing u + dt ud, then the BC set) "
+                                         "ping-pong between two arrays; boundaries: wall = 0, far field = copy(u)"}
     if config5:
         out["metric"] = ("Mcells*V-cycles/s, config-5 step (FAS! V-cycle, 3 levels x 2 smoothing iterations, Euler HLL + "
                          "Wray-Agarwal scalar residual), 3D sphere")

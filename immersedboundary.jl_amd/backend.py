@@ -580,6 +580,94 @@ def residual_advection(part, u, C_, out=None, flags=0):
     return ud
 
 
+# ---------------------------------------------------------------------------
+# an explicit solver step, device resident (test/advection.jl:30-89)
+# ---------------------------------------------------------------------------
+class BCSet:
+    """An ordered list of ``impose_bc!`` calls (ImmersedBoundary.jl:1197-1247) whose closures the library knows --
+    ``(name, value)``: ``do bdry, u; value end``; ``(name, "copy")``: ``do bdry, u; copy(u) end`` (the three calls of
+    test/advection.jl:30-46) -- on the one partition ``ipart`` of ``dom`` whose local cell order is the global one.
+    ``apply(u)`` has the semantics of the sequential calls; boundaries that do not read each other's ghost cells share
+    their two launches (``n_levels`` pairs in all)."""
+
+    def __init__(self, dom, specs, ipart=1):
+        part = dom.partitions[ipart]
+        if not np.array_equal(part.domain, np.arange(part.domain.size)):
+            raise ValueError("BCSet: the partition's local cell order must be the global one (a one-partition domain)")
+        self._bcs = []
+        modes, values = [], []
+        for name, spec in specs:
+            self._bcs.append(to_backend(dom.boundaries[name][ipart]))
+            modes.append(1 if isinstance(spec, str) and spec == "copy" else 0)
+            values.append(0.0 if modes[-1] else float(spec))
+        n = len(self._bcs)
+        arr = (c_vp * n)(*[bd.handle for bd in self._bcs])
+        m = np.asarray(modes, dtype=np.int32)
+        v = np.asarray(values, dtype=np.float32)
+        h = c_vp()
+        _dev()
+        call("ibh_bcset_create", C.byref(h), n, arr, _hptr(m), _hptr(v))
+        self.handle = h
+        ng, nl = C.c_int32(0), C.c_int32(0)
+        call("ibh_bcset_info", h, C.byref(ng), C.byref(nl))
+        self.n_ghost, self.n_levels = int(ng.value), int(nl.value)
+
+    def apply(self, u):
+        """The boundary conditions on the device field ``u`` (in place)."""
+        from .hiparray import HipArray
+        if isinstance(u, HipArray):
+            u._flush_readers()
+            u = u.t
+        f, nv, _ = _field_inplace(u, what="BCSet field")
+        if nv != 1:
+            raise ValueError("BCSet applies to a scalar field")
+        _stream()
+        call("ibh_bcset_apply", self.handle, _ptr(f))
+        return u
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().ibh_bcset_destroy(self.handle)
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def timestep_advection(part, C_, scale=1.0, out=None):
+    """``scale * 0.5 / maximum(max.(unsigned_green_gauss(part, at_faces(part, C[:, d], d), d) ...))`` (test/advection.jl:
+    52-59, :65) as a one-element device tensor: the step loop never reads it back."""
+    part = _part(part)
+    C_, nvc, ldc = _field(C_, part.nc)
+    if nvc != part.nd:
+        raise ValueError("C must be (nc, nd)")
+    dt = out if out is not None else torch.empty(1, dtype=torch.float32, device=C_.device)
+    _stream()
+    call("ibh_timestep_advection", part.handle, _ptr(C_), ldc, C.c_float(scale), _ptr(dt))
+    return dt
+
+
+def step_advection(part, u, C_, dt, bcs=None, out=None):
+    """One ``march!`` of test/advection.jl:61-89 without the host: ``out = u + dt * R(u)`` (sweep and update in one launch
+    where the quad sweep applies), then the boundary conditions ``bcs`` (a ``BCSet``) on ``out``.  ``dt``: one-element
+    device tensor (``timestep_advection``).  ``u`` and ``out`` must be different arrays (ping-pong)."""
+    part = _part(part)
+    u, nv, _ = _field(u, part.nc)
+    if nv != 1:
+        raise ValueError("u must be a scalar field")
+    C_, nvc, ldc = _field(C_, part.nc)
+    if nvc != part.nd:
+        raise ValueError("C must be (nc, nd)")
+    if out is None:
+        out = torch.empty(part.nc, dtype=torch.float32, device=u.device)
+    o, nvo, _ = _field_inplace(out, part.nc, "out")
+    if nvo != 1 or o.data_ptr() == u.data_ptr():
+        raise ValueError("out must be a scalar field other than u")
+    _stream()
+    call("ibh_step_advection", part.handle, _ptr(u), _ptr(o), _ptr(C_), ldc, _ptr(dt),
+         bcs.handle if bcs is not None else c_vp(None))
+    return out
+
+
 @_hipaware
 def residual_euler_hll(part, P, fluid_R=283.0, fluid_gamma=1.4, out=None, flags=0, fluid=None):
     """Fused Euler residual R2: JST(p) + cell_gradient + MUSCL(high_order) + HLL + green_gauss."""

@@ -398,6 +398,7 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->etab);
     hipFree(p->dtab);
     hipFree(p->img_list);
+    hipFree(p->march_tmp);
     for (int k = 0; k < 2; ++k) {
         hipFree(p->qd[k]);
         hipFree(p->qtab[k]);
@@ -478,6 +479,23 @@ int ibh_bc_create(ibh_bc** out, int32_t ng, const int32_t* ghost_indices, const 
     if ((rc = ibh_upload(&b->image_domain, idm.data(), idm.size()))) return rc;
     if ((rc = ibh_upload(&b->eta, eta.data(), eta.size()))) return rc;
     if ((rc = acc_fill(&b->interp, ng, nid, interp_off, interp_idx, interp_w, index_base))) return rc;
+    // host copies (ibh_bcset_create)
+    b->h_ghost = g;
+    b->h_eta = eta;
+    if (ng > 0 && interp_off && interp_idx) {
+        const int32_t ob = interp_off[0];
+        b->h_off.resize((size_t)ng + 1);
+        for (int32_t i = 0; i <= ng; ++i) b->h_off[i] = interp_off[i] - ob;
+        const size_t nnz = (size_t)b->h_off[ng];
+        b->h_donor.resize(nnz);
+        b->h_w.resize(nnz);
+        for (size_t k = 0; k < nnz; ++k) {
+            const int32_t j = interp_idx[k] - index_base;
+            IBH_REQUIRE(j >= 0 && j < nid, "ibh_bc_create: stencil index out of range");
+            b->h_donor[k] = idm[j];
+            b->h_w[k] = interp_w ? interp_w[k] : 1.0f;
+        }
+    }
     *out = b;
     return 0;
 }

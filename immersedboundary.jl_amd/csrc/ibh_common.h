@@ -128,6 +128,8 @@ struct ibh_part {
     int64_t info[24] = {0};
     // workspace for per-cell gradients + sensor (pass A output)
     float* G = nullptr;
+    float* march_tmp = nullptr;  // scratch of ibh_timestep_advection: [max nf | nd x nc] floats + one word
+    size_t march_tmp_n = 0;
     size_t G_bytes = 0;
 };
 
@@ -142,6 +144,22 @@ struct ibh_bc {
     int32_t *ghost = nullptr, *image_domain = nullptr;
     float* eta = nullptr;
     ibh_acc interp;
+    // host copies for ibh_bcset_create (which boundaries may share a launch): ghost cells, eta, and the interpolation
+    // stencils with the donor CELLS resolved (image_domain[idx])
+    std::vector<int32_t> h_ghost, h_off, h_donor;
+    std::vector<float> h_eta, h_w;
+};
+
+// An ordered list of ghost-cell boundary conditions with closures the library knows (mode 0: a constant value, mode 1:
+// copy(u): the closures of test/advection.jl:30-46), concatenated on the device (ibh_march.hip)
+#define IBH_MAX_BC 8
+struct ibh_bcset {
+    int nbc = 0, nlev = 0;
+    int32_t ng = 0;                 // ghost cells of all boundaries, ordered by level
+    int32_t seg[IBH_MAX_BC + 1] = {0};  // ghost ranges of the levels
+    int32_t *ghost = nullptr, *off = nullptr, *donor = nullptr, *bidx = nullptr;
+    float *eta = nullptr, *w = nullptr, *gval = nullptr, *value = nullptr;
+    int32_t* mode = nullptr;
 };
 
 // thread-local state

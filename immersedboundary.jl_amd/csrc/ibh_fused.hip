@@ -600,7 +600,7 @@ __device__ __forceinline__ void dbg_stamp(int32_t slot, int k, unsigned long lon
     if (ibh_dbg_buf && threadIdx.x % 64 == 0) ibh_dbg_buf[(size_t)slot * 8 + k] = v;
 }
 
-template <bool DT, bool STAMP, int GM = 127>
+template <bool DT, bool STAMP, int GM = 127, bool STEP = false>
 __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict__ u, const float* __restrict__ C,
                                                          uint32_t ldc, float* __restrict__ ud,
                                                          const QuadDesc2* __restrict__ qd,
@@ -610,8 +610,11 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
                                                          const int32_t* __restrict__ etab,
                                                          const int32_t* __restrict__ dtab,
                                                          const int32_t* __restrict__ singles, int32_t ns, int32_t nwgs,
-                                                         int32_t singles_first, int32_t siters) {
+                                                         int32_t singles_first, int32_t siters,
+                                                         const float* __restrict__ dtp = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[QUAD_WG_LDS];
+    float dt = 0.0f;
+    if constexpr (STEP) dt = *dtp;  // (scalar load: the time step lives on the device, ibh_timestep_advection)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t slot = blockIdx.x * WPB + wave;
     if constexpr (STAMP) {
@@ -623,15 +626,15 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
     if (isq) {
         const int32_t q = __builtin_amdgcn_readfirstlane(xcd_remap(wgq, nwgq) * WPB + wave);
         if (q < nq)
-            quad2::sweep_quad<STAMP, GM>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane,
-                                         STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr);
+            quad2::sweep_quad<STAMP, GM, STEP>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane,
+                                               STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr, dt);
     } else {
         const int32_t wgs = singles_first ? (int32_t)blockIdx.x : (int32_t)blockIdx.x - nwgq;
         const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(wgs, nwgs) * (WPB * siters) + wave);
         if (first < ns) {
             const int32_t nb = __builtin_amdgcn_readfirstlane(min(siters, (ns - first + WPB - 1) / WPB));
-            blk2::sweep_adv<DT>(blocks, htab, etab, dtab, singles, first, WPB, nb, u, C, ldc, ud,
-                                lds + wave * BLK2_SWEEP_LDS, lane);
+            blk2::sweep_adv<DT, STEP>(blocks, htab, etab, dtab, singles, first, WPB, nb, u, C, ldc, ud,
+                                      lds + wave * BLK2_SWEEP_LDS, lane, dt);
         }
     }
     if constexpr (STAMP) {
@@ -1300,6 +1303,27 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
 // One step of a rank in one launch: xGMI halo exchange of u + image-only quad sweep (k_step_quad).  Needs a partition
 // whose image blocks are all eligible and carry quads (the ranks of the benchmark meshes); otherwise the caller runs
 // ibh_halo_exchange and ibh_residual_advection(IBH_IMAGE_ONLY) one after the other (same result).
+int ibh_step_advection(ibh_part* p, const float* u, float* u_out, const float* C, int64_t ldc, const float* dt_dev,
+                       const ibh_bcset* bcs) {
+    IBH_REQUIRE(p && u && u_out && C && dt_dev && u != u_out, "ibh_step_advection: null or aliased argument");
+    if (p->nc == 0) return 0;
+    int rc = 0;
+    if (p->nd == 2 && p->bs == 8 && p->nblk > 0 && p->fuse_all && ibh_quad && p->nq[0] > 0 && p->n_dt == 0) {
+        // sweep and update in one launch: the quad sweep stores u + dt * residual (its cells of u are in registers)
+        const int32_t nq = p->nq[0], ns = p->nqs[0];
+        const int32_t nwgq = (nq + WPB - 1) / WPB, nwgs = (ns + WPB - 1) / WPB;
+        hipLaunchKernelGGL((k_sweep_quad<false, false, 127, true>), dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C,
+                           (uint32_t)ldc, u_out, p->qd[0], p->qtab[0], nq, nwgq, p->blocks2, p->htab, p->etab, p->dtab,
+                           p->qsingles[0], ns, nwgs, ibh_quad_singles_first, 1, dt_dev);
+        IBH_LAUNCH_CHECK();
+    } else {
+        if ((rc = ibh_residual_advection(p, u, C, ldc, u_out, 0))) return rc;
+        if ((rc = ibh_update_dev(p->nc, dt_dev, u, u_out, u_out))) return rc;
+    }
+    if (bcs) rc = ibh_bcset_apply(bcs, u_out);
+    return rc;
+}
+
 int ibh_step_advection_xgmi(ibh_part* p, float* u, const float* C, int64_t ldc, float* ud, const int32_t* send_all,
                             int n_send_peers, const int32_t* send_seg, float* const* dst0, float* const* dst1,
                             uint32_t* const* send_flags, const int32_t* recv_all, const float* src0, const float* src1,

@@ -1,0 +1,210 @@
+// libibhip: the pieces of an explicit solver step around the residual sweep, device resident (test/advection.jl:30-89):
+//   * ibh_bcset_*: an ordered list of ghost-cell boundary conditions whose closures the library knows (a constant value,
+//     copy(u): advection.jl:30-46) applied to a field with the semantics of the sequential impose_bc! calls
+//     (ImmersedBoundary.jl:1197-1247: every ghost cell of a boundary is interpolated BEFORE any of them is written; a later
+//     boundary sees the earlier ones): boundaries that do not read each other's ghost cells form a level, a level is two
+//     launches (interpolate + closure + blend into a side buffer, scatter) whatever the number of boundaries;
+//   * ibh_timestep_advection: dt = scale * 0.5 / max over cells and dimensions of unsigned_green_gauss(at_faces(C_d, d), d)
+//     (advection.jl:52-59) left in device memory -- no host read-back in the step loop.
+// The step itself (sweep + u += dt ud in one launch) is ibh_step_advection in ibh_fused.hip.
+// Arithmetic: the operator kernels' (ibh_ops.hip): -ffp-contract=off, the reference's evaluation order.
+#include <algorithm>
+#include <vector>
+
+#include "ibh_common.h"
+
+#define MARCH_BLOCK 256
+
+namespace {
+
+// interpolated value of ghost g of the set: sum over its stencil in the order of k_accumulate (ibh_ops.hip)
+__device__ __forceinline__ float bc_interp1(const int32_t* __restrict__ off, const int32_t* __restrict__ donor,
+                                            const float* __restrict__ w, const float* __restrict__ a, int32_t g) {
+    const int32_t b = off[g], e = off[g + 1];
+    float s = 0.0f;
+    for (int32_t k = b; k < e; ++k) {
+        const float t = a[donor[k]] * w[k];
+        s = (k == b) ? t : s + t;
+    }
+    return s;
+}
+
+// ghosts g0 .. g1 of the set: interpolate from the field, closure, blend (k_bc_blend) -- into `gval`, NOT into the field:
+// every ghost cell of these boundaries is interpolated from the field as it was before any of them is written
+__global__ void k_bcset_interp(int32_t g0, int32_t g1, const float* __restrict__ eta, const int32_t* __restrict__ off,
+                               const int32_t* __restrict__ donor, const float* __restrict__ w,
+                               const int32_t* __restrict__ bidx, const int32_t* __restrict__ mode,
+                               const float* __restrict__ value, const float* __restrict__ a, float* __restrict__ gval) {
+    for (int32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += gridDim.x * blockDim.x) {
+        const float i = bc_interp1(off, donor, w, a, g);
+        const int32_t k = bidx[g];
+        const float e = eta[g];
+        const float b = mode[k] ? i : value[k];
+        gval[g] = e * i + (1.0f - e) * b;
+    }
+}
+__global__ void k_bcset_scatter(int32_t g0, int32_t g1, const int32_t* __restrict__ ghost, const float* __restrict__ gval,
+                                float* __restrict__ a) {
+    for (int32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += gridDim.x * blockDim.x) a[ghost[g]] = gval[g];
+}
+
+// out = u + dt * r with dt in device memory (the update of advection.jl:87 for partitions without the fused step kernel)
+__global__ void k_update_dev(int64_t n, const float* __restrict__ dt, const float* __restrict__ u,
+                             const float* __restrict__ r, float* __restrict__ out) {
+    const float h = *dt;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = u[i] + r[i] * h;
+}
+
+__global__ void k_max_cells(int64_t n, int nd, const float* __restrict__ t, unsigned int* __restrict__ word) {
+    float m = 0.0f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int d = 0; d < nd; ++d) m = fmaxf(m, t[i + (int64_t)d * n]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMax(word, __float_as_uint(m));
+}
+__global__ void k_dt_from_max(const unsigned int* __restrict__ word, float scale, float* __restrict__ dt) {
+    *dt = (0.5f / __uint_as_float(*word)) * scale;  // advection.jl:53 and :65
+}
+
+}  // namespace
+
+extern "C" {
+
+int ibh_bcset_create(ibh_bcset** out, int nbc, const ibh_bc* const* bcs, const int32_t* modes, const float* values) {
+    IBH_REQUIRE(out && nbc >= 1 && nbc <= IBH_MAX_BC && bcs && modes && values, "ibh_bcset_create: bad argument");
+    for (int k = 0; k < nbc; ++k) {
+        IBH_REQUIRE(bcs[k] && (modes[k] == 0 || modes[k] == 1), "ibh_bcset_create: null boundary or bad mode");
+        IBH_REQUIRE(bcs[k]->ng == 0 || (int32_t)bcs[k]->h_off.size() == bcs[k]->ng + 1,
+                    "ibh_bcset_create: boundary without host stencils");
+    }
+    // Levels.  Sequential impose_bc! calls: boundary k is interpolated from the field as boundaries 1..k-1 left it and
+    // before any of its own ghost cells is written.  Interpolating a whole LEVEL of boundaries into a side buffer and
+    // scattering afterwards is the same thing iff no boundary of the level has a donor cell that is a ghost cell of an
+    // earlier boundary of the same level (its own ghost cells and those of later boundaries are read as they were: right)
+    // and no ghost cell belongs to two boundaries of the level.  level(k) = 1 + max level of the earlier boundaries it
+    // depends on that way.
+    std::vector<std::vector<int32_t>> gs(nbc);
+    for (int k = 0; k < nbc; ++k) {
+        gs[k] = bcs[k]->h_ghost;
+        std::sort(gs[k].begin(), gs[k].end());
+    }
+    int level[IBH_MAX_BC] = {0}, nlev = 0;
+    for (int k = 0; k < nbc; ++k) {
+        int lv = 0;
+        for (int j = 0; j < k; ++j) {
+            bool dep = false;
+            for (int32_t c : bcs[k]->h_donor)
+                if (std::binary_search(gs[j].begin(), gs[j].end(), c)) { dep = true; break; }
+            for (int32_t c : gs[k])
+                if (!dep && std::binary_search(gs[j].begin(), gs[j].end(), c)) { dep = true; break; }
+            if (dep) lv = std::max(lv, level[j] + 1);
+        }
+        level[k] = lv;
+        nlev = std::max(nlev, lv + 1);
+    }
+    ibh_bcset* s = new ibh_bcset();
+    s->nbc = nbc;
+    s->nlev = nlev;
+    std::vector<int32_t> ghost, off{0}, donor, bidx, mode(modes, modes + nbc);
+    std::vector<float> eta, w, value(values, values + nbc);
+    for (int lv = 0; lv < nlev; ++lv) {  // ghosts ordered by level, boundaries of a level in their order
+        s->seg[lv] = (int32_t)ghost.size();
+        for (int k = 0; k < nbc; ++k) {
+            if (level[k] != lv) continue;
+            const ibh_bc* b = bcs[k];
+            for (int32_t g = 0; g < b->ng; ++g) {
+                ghost.push_back(b->h_ghost[g]);
+                eta.push_back(b->h_eta[g]);
+                bidx.push_back(k);
+                for (int32_t j = b->h_off[g]; j < b->h_off[g + 1]; ++j) {
+                    donor.push_back(b->h_donor[j]);
+                    w.push_back(b->h_w[j]);
+                }
+                off.push_back((int32_t)donor.size());
+            }
+        }
+    }
+    s->seg[nlev] = s->ng = (int32_t)ghost.size();
+    int rc;
+    if ((rc = ibh_upload(&s->ghost, ghost.data(), ghost.size()))) return rc;
+    if ((rc = ibh_upload(&s->eta, eta.data(), eta.size()))) return rc;
+    if ((rc = ibh_upload(&s->off, off.data(), off.size()))) return rc;
+    if ((rc = ibh_upload(&s->donor, donor.data(), donor.size()))) return rc;
+    if ((rc = ibh_upload(&s->w, w.data(), w.size()))) return rc;
+    if ((rc = ibh_upload(&s->bidx, bidx.data(), bidx.size()))) return rc;
+    if ((rc = ibh_upload(&s->mode, mode.data(), mode.size()))) return rc;
+    if ((rc = ibh_upload(&s->value, value.data(), value.size()))) return rc;
+    IBH_HIP(hipMalloc((void**)&s->gval, sizeof(float) * std::max<size_t>(ghost.size(), 1)));
+    *out = s;
+    return 0;
+}
+
+int ibh_bcset_destroy(ibh_bcset* s) {
+    if (!s) return 0;
+    hipFree(s->ghost); hipFree(s->eta); hipFree(s->off); hipFree(s->donor); hipFree(s->w); hipFree(s->bidx);
+    hipFree(s->mode); hipFree(s->value); hipFree(s->gval);
+    delete s;
+    return 0;
+}
+
+int ibh_bcset_info(const ibh_bcset* s, int32_t* n_ghost, int32_t* n_levels) {
+    IBH_REQUIRE(s, "ibh_bcset_info: null set");
+    if (n_ghost) *n_ghost = s->ng;
+    if (n_levels) *n_levels = s->nlev;
+    return 0;
+}
+
+int ibh_bcset_apply(const ibh_bcset* s, float* a) {
+    IBH_REQUIRE(s && a, "ibh_bcset_apply: null argument");
+    for (int lv = 0; lv < s->nlev; ++lv) {
+        const int32_t g0 = s->seg[lv], g1 = s->seg[lv + 1];
+        if (g1 == g0) continue;
+        const int nwg = std::min(ibh_grid(g1 - g0, MARCH_BLOCK), 2048);
+        hipLaunchKernelGGL(k_bcset_interp, dim3(nwg), dim3(MARCH_BLOCK), 0, ibh_stream, g0, g1, s->eta, s->off, s->donor,
+                           s->w, s->bidx, s->mode, s->value, a, s->gval);
+        hipLaunchKernelGGL(k_bcset_scatter, dim3(nwg), dim3(MARCH_BLOCK), 0, ibh_stream, g0, g1, s->ghost, s->gval, a);
+    }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_update_dev(int64_t n, const float* dt_dev, const float* u, const float* r, float* out) {
+    IBH_REQUIRE(dt_dev && u && r && out, "ibh_update_dev: null argument");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_update_dev, dim3(std::min(ibh_grid(n, MARCH_BLOCK), 2048)), dim3(MARCH_BLOCK), 0, ibh_stream, n,
+                       dt_dev, u, r, out);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_timestep_advection(ibh_part* p, const float* C, int64_t ldc, float scale, float* dt_dev) {
+    IBH_REQUIRE(p && C && dt_dev && p->nd >= 1, "ibh_timestep_advection: bad argument");
+    const int nd = p->nd;
+    int32_t nfmax = 0;
+    for (int d = 0; d < nd; ++d) nfmax = std::max(nfmax, p->dim[d].nf);
+    const size_t need = (size_t)nfmax + (size_t)nd * p->nc + 1;
+    if (p->march_tmp_n < need) {
+        if (p->march_tmp) IBH_HIP(hipFree(p->march_tmp));
+        p->march_tmp = nullptr;
+        IBH_HIP(hipMalloc((void**)&p->march_tmp, sizeof(float) * need));
+        p->march_tmp_n = need;
+    }
+    float* tf = p->march_tmp;
+    float* tc = tf + nfmax;
+    unsigned int* word = (unsigned int*)(tc + (size_t)nd * p->nc);
+    IBH_HIP(hipMemsetAsync(word, 0, sizeof(unsigned int), ibh_stream));
+    for (int d = 0; d < nd; ++d) {
+        int rc = ibh_at_faces(p, d + 1, C + (size_t)d * ldc, 1, p->nc, tf, nfmax);
+        if (!rc) rc = ibh_green_gauss(p, d + 1, tf, 1, nfmax, tc + (size_t)d * p->nc, p->nc, 1);
+        if (rc) return rc;
+    }
+    const int nwg = std::min(ibh_grid(p->nc, MARCH_BLOCK), 1024);
+    hipLaunchKernelGGL(k_max_cells, dim3(nwg), dim3(MARCH_BLOCK), 0, ibh_stream, (int64_t)p->nc, nd, tc, word);
+    hipLaunchKernelGGL(k_dt_from_max, dim3(1), dim3(1), 0, ibh_stream, word, scale, dt_dev);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -294,9 +294,10 @@ __device__ __forceinline__ QuadHalo quad_load_halo_paired(const QuadLane& G, con
 }
 
 // ---- the arithmetic of one quad.  STAMP: phase time stamps of the wave (100 MHz ticks) for scripts/wave_timeline.py
-template <bool STAMP>
+// STEP: the explicit update u + dt * residual is stored instead of the residual (ibh_step_advection)
+template <bool STAMP, bool STEP = false>
 __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T, const QuadOwn& O, const QuadHalo& H,
-                                             float* __restrict__ ud, unsigned long long* stamps) {
+                                             float* __restrict__ ud, unsigned long long* stamps, float dt = 0.0f) {
     using blk2::wave_lds_sync;
     auto stamp = [&](int k) {
         if constexpr (STAMP) {
@@ -451,23 +452,23 @@ __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T
             FTf[c] = t15 ? ex[c] : FT[c];
         }
         const v4f res = -((FRf - FL) * rhx) - ((FTf - FB) * rhy);
-        *(v4f_g*)((char*)ud + ((size_t)O.a0 << 2)) = res;
+        *(v4f_g*)((char*)ud + ((size_t)O.a0 << 2)) = STEP ? U + dt * res : res;
     }
 }
 
 // ---- one quad by one wave.  (Sweeping several quads per wave with the next quad's loads in flight was measured and
 // dropped: the prefetch registers cost a wave per SIMD -- 124 VGPRs against 89 -- and the sweep lives on wave-level
 // parallelism: 6.1 us against 5.5 us at 0.87 M cells, no gain at 3.47 M.)
-template <bool STAMP, int GM = 127>
+template <bool STAMP, int GM = 127, bool STEP = false>
 __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, const int32_t* __restrict__ qtab, int32_t q,
                                            const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
                                            float* __restrict__ ud, float* lds, int lane,
-                                           unsigned long long* stamps = nullptr) {
+                                           unsigned long long* stamps = nullptr, float dt = 0.0f) {
     const QuadLane G = quad_lane(lds, lane);
     const QuadTab T = quad_load_tab(qd, qtab, q, lane);  // everything that needs the quad's index only is in flight
     const QuadOwn O = quad_load_own(G, T, u, C, ldc);
     const QuadHalo H = GM == 127 ? quad_load_halo_paired(G, T, u, C, ldc) : quad_load_halo<GM == 126 ? 127 : GM>(G, T, u, C, ldc);
-    quad_compute<STAMP>(G, T, O, H, ud, stamps);
+    quad_compute<STAMP, STEP>(G, T, O, H, ud, stamps, dt);
 }
 
 #pragma clang fp contract(off)

@@ -144,13 +144,14 @@ static_assert(offsetof(BlockDesc2, type) == 4 && offsetof(BlockDesc2, q) == 84, 
 // `nb` blocks at positions blk0, blk0 + stride, ... (block indices, or entries of `blist`) by this wave; the
 // lane-only index arithmetic is shared by all of them and the loads of the next blocks are in flight while a
 // block is computed
-template <bool DT>
+// STEP: the explicit update u + dt * residual is stored instead of the residual (ibh_step_advection)
+template <bool DT, bool STEP = false>
 __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ htab,
                                           const int32_t* __restrict__ etab, const int32_t* __restrict__ dtab,
                                           const int32_t* __restrict__ blist,
                                           int32_t blk0, int32_t stride, int32_t nb,
                                           const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
-                                          float* __restrict__ ud, float* lds, int lane) {
+                                          float* __restrict__ ud, float* lds, int lane, float dt = 0.0f) {
     float* fU = lds;
     float* fD = lds + 128;
     float* fSX = lds + 256;
@@ -289,7 +290,8 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
         const float FB = e2 ? eB : FBs;
         FR = e1 ? 0.5f * (FR + FR1) : FR;
         FT = e3 ? 0.5f * (FT + FT1) : FT;
-        stg(ud, (uint32_t)bb.base + lane, -((FR - FL) * bb.rh[0]) - ((FT - FB) * bb.rh[1]));
+        const float res = -((FR - FL) * bb.rh[0]) - ((FT - FB) * bb.rh[1]);
+        stg(ud, (uint32_t)bb.base + lane, STEP ? uc + dt * res : res);
     }
 }
 

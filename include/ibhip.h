@@ -324,6 +324,23 @@ int ibh_step_advection_xgmi(ibh_part*, float* u, const float* C, int64_t ldc, fl
 
 /* ---- small device-resident vector ops for the FAS loop (solver.jl:79-88) ---------- */
 /* q += clamp(omega,0,1) * r ; omega scalar */
+/* ---- an explicit solver step, device resident (test/advection.jl:30-89: march! = dt, closure, u .+= ud .* dt, apply_bcs!)
+ * ibh_bcset: an ordered list of impose_bc! calls (ImmersedBoundary.jl:1197-1247) whose closures the library knows --
+ *   mode 0: `do bdry, u; value end`, mode 1: `do bdry, u; copy(u) end` (advection.jl:30-46) -- applied with the semantics
+ *   of the sequential calls: boundaries that do not read each other's ghost cells form a level; a level is two launches
+ *   (interpolate + closure + blend into a side buffer, then scatter) whatever the number of boundaries.
+ * ibh_timestep_advection: dt = scale * 0.5 / maximum(max.(unsigned_green_gauss(at_faces(C_d, d), d)...)) (:52-59, :65)
+ *   written to device memory; ibh_step_advection: u_out = u + dt * R(u) in ONE launch where the quad sweep applies (else
+ *   sweep + update), then the boundary conditions on u_out.  u and u_out must not alias. */
+typedef struct ibh_bcset ibh_bcset;
+int ibh_bcset_create(ibh_bcset** out, int n_bc, const ibh_bc* const* bcs, const int32_t* modes, const float* values);
+int ibh_bcset_destroy(ibh_bcset*);
+int ibh_bcset_info(const ibh_bcset*, int32_t* n_ghost, int32_t* n_levels);
+int ibh_bcset_apply(const ibh_bcset*, float* a);
+int ibh_timestep_advection(ibh_part*, const float* C, int64_t ldc, float scale, float* dt_device);
+int ibh_update_dev(int64_t n, const float* dt_device, const float* u, const float* r, float* out);
+int ibh_step_advection(ibh_part*, const float* u, float* u_out, const float* C, int64_t ldc, const float* dt_device,
+                       const ibh_bcset* bcs /* or NULL */);
 int ibh_axpy_clamped(int64_t n, float omega, const float* r, float* q);
 /* y = a*x + y */
 int ibh_axpy(int64_t n, float a, const float* x, float* y);

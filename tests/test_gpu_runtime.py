@@ -294,3 +294,67 @@ def test_surface_and_volume_integrals(rae_domains):
     assert np.abs(vi - exact).max() <= 1e-5 * np.abs(exact).max()
     assert np.abs(vio - exact).max() <= 1e-3 * np.abs(exact).max()
     assert abs(float(ibamd.volume_integral(dp, ibamd.hip(np.ones(n, f32)))) - 2500.0) <= 0.5   # test/rae2822.jl:24-29
+
+
+def test_advection_march_through_the_fused_step(adv_mesh):
+    """``march!`` of test/advection.jl:61-89 through ``ibh_step_advection``: time step by a device reduction
+    (``ibh_timestep_advection``), sweep + ``u .+= ud .* dt`` in ONE launch, the three ``impose_bc!`` calls of :30-46 as a
+    ``BCSet`` -- no host read-back in the loop -- against the oracle's operator-by-operator march on the same one-partition
+    domain; the BC set alone against ``impose_bc``; the unfused fallback (``IBH_QUAD=0`` path: sweep, update) agrees."""
+    from conftest import ADV_FAMILIES
+    from ibamd import _lib
+    kw = dict(hypercube_families=ADV_FAMILIES, max_partition_size=10 ** 9)
+    dp, do = ibamd.Domain(adv_mesh, **kw), od.Domain(adv_mesh, **kw)
+    (part,) = dp.partitions.values()
+    (opart,) = do.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    n = len(dp)
+    u0 = seeded_field(dp.global_centers(), kind="step")
+    Ch = np.ones((n, 2), dtype=f32)
+
+    def o_closure(p, u, ud, Cl):
+        D = od.JST_sensor(p, u)
+        for dim in (1, 2):
+            Cf = od.at_faces(p, np.ascontiguousarray(Cl[:, dim - 1]), dim)
+            gu = od.cell_gradient(p, u, dim)
+            uL, uR = od.MUSCL(p, u, gu, dim, D=D, high_order=True)
+            ud -= od.green_gauss(p, (uL + uR) * Cf / f32(2) + np.abs(Cf) * (uL - uR) / f32(2), dim)
+    one = np.ones(n, f32)
+    dt_o = f32(0.5) / np.max(np.maximum(od.unsigned_green_gauss(opart, od.at_faces(opart, one, 1), 1),
+                                        od.unsigned_green_gauss(opart, od.at_faces(opart, one, 2), 2))) * f32(0.75)
+    C = ibamd.hip(Ch)
+    dt = ibamd.timestep_advection(dpart, C, scale=0.75)
+    assert abs(float(dt.item()) - float(dt_o)) <= 1e-6 * float(dt_o)
+    bcs = ibamd.BCSet(dp, [("upper", 1.0), ("lower", 0.0), ("outlet", "copy")])
+    assert bcs.n_ghost > 0
+    # the BC set alone: the three sequential impose_bc calls
+    a1, a2 = ibamd.hip(u0), ibamd.hip(u0)
+    bcs.apply(a1)
+    ibamd.impose_bc(lambda b, ui: 1.0, dp, "upper", a2)
+    ibamd.impose_bc(lambda b, ui: 0.0, dp, "lower", a2)
+    ibamd.impose_bc(lambda b, ui: ui.clone(), dp, "outlet", a2)
+    assert torch.equal(a1, a2)
+    # the march
+    uo = u0.copy()
+    ua, ub = ibamd.hip(u0), torch.empty(n, dtype=torch.float32, device="cuda")
+    for _ in range(4):
+        udo = np.zeros(n, f32)
+        do(o_closure, uo, udo, Ch)
+        uo += udo * dt_o
+        od.impose_bc(lambda b, ui: f32(1.0), do, "upper", uo)
+        od.impose_bc(lambda b, ui: f32(0.0), do, "lower", uo)
+        od.impose_bc(lambda b, ui: ui.copy(), do, "outlet", uo)
+        ibamd.timestep_advection(dpart, C, scale=0.75, out=dt)      # (advection.jl recomputes it every step)
+        ibamd.step_advection(dpart, ua, C, dt, bcs, out=ub)
+        ua, ub = ub, ua
+        assert rel_inf(ibamd.to_host(ua), uo) <= 1e-5
+    assert not np.array_equal(uo, u0)
+    # unfused form of the same step: sweep, update with the device dt, BC set
+    v = ibamd.hip(u0)
+    r = ibamd.residual_advection(dpart, v, C)
+    w = torch.empty_like(v)
+    _lib.call("ibh_update_dev", n, _lib.c_vp(dt.data_ptr()), _lib.c_vp(v.data_ptr()), _lib.c_vp(r.data_ptr()),
+              _lib.c_vp(w.data_ptr()))
+    bcs.apply(w)
+    f = ibamd.step_advection(dpart, ibamd.hip(u0), C, dt, bcs)
+    assert rel_inf(ibamd.to_host(f), ibamd.to_host(w)) <= 1e-6
