@@ -336,7 +336,9 @@ def main():
                     print(f"[bench] xgmi halo exchange unavailable ({e}); using {halo_kind}", file=sys.stderr)
         # (the Euler sweep has overlap phases only where the image blocks all take the single kernel)
         auto_forms = args.halo == "auto" and not (args.overlap or args.fused_step or args.no_overlap)
-        can_overlap = (not args.general and dpart.info["interior_blocks"] > 0 and (not euler or image_only))
+        # (3-D image-only sweeps have no overlap phases: one launch over the image blocks)
+        can_overlap = (not args.general and dpart.info["interior_blocks"] > 0 and (not euler or image_only)
+                       and not (msh.ndims == 3 and image_only))
         overlap = args.overlap and not args.no_overlap and can_overlap
         comm_stream = torch.cuda.Stream() if overlap else None
         # exchange + image-only quad sweep as ONE launch (XgmiHalo.fused_step: the exchange workgroups run beside the
@@ -681,9 +683,9 @@ def main():
     # HBM-side traffic of one launch of the dominant kernel from the committed PMC passes of this build (separate
     # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command; FETCH_SIZE x2 on gfx950,
     # calibrated against the kernel's known tile loads); null if not profiled.
-    kernel = ("k_sweep3_euler_cols" if (euler and fused3) else "k_passB3e_blk" if (euler and is3d) else ("k_sweep_quad_euler" if inf.get("image_quads" if image_only else "quads", 0) > 0 and os.environ.get("IBH_QUAD", "1") != "0"
+    kernel = ("k_sweep3_euler_cols" if (euler and (fused3 or (image_only and is3d))) else "k_passB3e_blk" if (euler and is3d) else ("k_sweep_quad_euler" if inf.get("image_quads" if image_only else "quads", 0) > 0 and os.environ.get("IBH_QUAD", "1") != "0"
                else "k_sweep_euler") if (fused_e or (image_only and euler)) else "k_passB_euler_blk" if euler else
-              "k_sweep3_cols" if fused3 else "k_passB3_adv_blk" if is3d else
+              "k_sweep3_cols" if (fused3 or (image_only and is3d)) else "k_passB3_adv_blk" if is3d else
               "k_sweep_quad" if ((fused and inf.get("quads", 0) > 0) or
                                  (image_only and not euler and inf.get("image_quads", 0) > 0)) else
               "k_sweep_adv" if (fused or mixed or (image_only and not euler)) else "k_passB_adv<2,false>")

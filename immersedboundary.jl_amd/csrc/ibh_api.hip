@@ -296,6 +296,24 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         p->n_irr = (int32_t)irr.size();
         if ((rc = ibh_upload(&p->blocks3, blocks.data(), blocks.size()))) return rc;
         if ((rc = ibh_upload(&p->htab3, htab.data(), htab.size()))) return rc;
+        if (have_img && !sw.all) {   // a partition with skirt fragments: the image blocks for the image-only sweeps
+            Image3Host im;
+            ibh_analyze_image3(v, image_in_domain, n_image, im);
+            if (im.all) {
+                if (im.r4tab.empty()) im.r4tab.assign(4, 0);
+                if (im.ftab.empty()) im.ftab.assign(4, 0);
+                if ((rc = ibh_upload(&p->iblocks3, im.blocks.data(), im.blocks.size()))) return rc;
+                if ((rc = ibh_upload(&p->ihtab3, im.htab.data(), im.htab.size()))) return rc;
+                if ((rc = ibh_upload(&p->iftab3, im.ftab.data(), im.ftab.size()))) return rc;
+                if ((rc = ibh_upload(&p->irtab3, im.rtab.data(), im.rtab.size()))) return rc;
+                if ((rc = ibh_upload(&p->ir4tab3, im.r4tab.data(), im.r4tab.size()))) return rc;
+                if ((rc = ibh_upload(&p->idtab3, im.dtab.data(), im.dtab.size()))) return rc;
+                p->n_img3 = (int32_t)im.blocks.size();
+                p->img_all3 = 1;
+            }
+        }
+        p->info[10] = p->img_all3 || sw.all;       // image blocks all eligible for the single-kernel sweeps
+        p->info[11] = p->img_all3 ? p->n_img3 : (sw.all ? (int64_t)blocks.size() : 0);
         if ((rc = ibh_upload(&p->irr_cells, irr.data(), irr.size()))) return rc;
     } else {
         p->info[0] = 0;
@@ -409,6 +427,8 @@ int ibh_partition_destroy(ibh_part* p) {
     hipFree(p->nf_list);
     hipFree(p->blocks3);
     hipFree(p->htab3);
+    hipFree(p->iblocks3); hipFree(p->ihtab3); hipFree(p->iftab3); hipFree(p->irtab3); hipFree(p->ir4tab3);
+    hipFree(p->idtab3);
     hipFree(p->ftab3);
     hipFree(p->rtab3);
     hipFree(p->r4tab3);

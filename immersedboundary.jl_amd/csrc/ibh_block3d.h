@@ -1132,7 +1132,10 @@ template <int S>
 __device__ __forceinline__ uint32_t halo_cell3s(const BlockDesc3& bb, const int32_t* __restrict__ htab, int32_t blk,
                                                 int t) {
     const int ty = bb.type[S];
-    if (ty == SIDE_FINE) return (uint32_t)htab[(size_t)blk * 384 + S * 64 + t];  // wave-uniform
+    // wave-uniform: FINE sides, and sides whose neighbour block is not complete in this partition (nb < 0: a skirt
+    // fragment, image-only sweeps) take the ids from the table
+    if (ty == SIDE_FINE || ((ty == SIDE_SAME || ty == SIDE_COARSE) && bb.nb[S] < 0))
+        return (uint32_t)htab[(size_t)blk * 384 + S * 64 + t];
     constexpr int d = S >> 1;
     constexpr bool low = (S & 1) == 0;
     constexpr int sd = d == 0 ? 1 : d == 1 ? 8 : 64;

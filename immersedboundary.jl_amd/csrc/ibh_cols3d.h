@@ -43,10 +43,10 @@ struct Halo1 {
     float hu, hd, hc, rv;
 };
 template <int S>
-__device__ __forceinline__ void halo_load(const BlockDesc3& bb, const float* __restrict__ u, const float* __restrict__ Cn,
-                                          const Slot& sl, int32_t rid, Halo1& h) {
+__device__ __forceinline__ void halo_load(const BlockDesc3& bb, int lane, const float* __restrict__ u,
+                                          const float* __restrict__ Cn, const Slot& sl, int32_t rid, Halo1& h) {
     h.hu = ldg(u, sl.hid);
-    h.hd = ldg(u, (uint32_t)((int)sl.hid + sl.dd));
+    h.hd = ldg(u, strip3e::deeper_of<S>(bb, sl, lane, 0, sl.hid));
     h.hc = ldg(Cn, sl.hid);
     h.rv = ldg(u, (uint32_t)(rid >= 0 ? rid : bb.base));
 }
@@ -175,7 +175,7 @@ __device__ __forceinline__ void side_eval(const BlockDesc3& bb, const LaneGeo& L
             if (k > 0) {
                 const uint32_t c = (uint32_t)ft[k - 1];
                 hk = ldg(u, c);
-                hdk = ldg(u, (uint32_t)((int)c + sl.dd));
+                hdk = ldg(u, strip3e::deeper_of<S>(bb, sl, lane, k, c));
                 hck = ldg(Cn, c);
             }
             const int f1 = 2 * t1 + (k & 1), f2 = 2 * t2 + (k >> 1);
@@ -276,7 +276,7 @@ __device__ __forceinline__ void sweep_cols(const BlockDesc3* __restrict__ blocks
                                            const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
                                            const int32_t* __restrict__ r4tab, int32_t blk, const float* __restrict__ u,
                                            const float* __restrict__ C, uint32_t ldc, float* __restrict__ ud, float* lds,
-                                           int lane) {
+                                           int lane, const int32_t* __restrict__ dtab = nullptr) {
     const BlockDesc3 bb = blocks[blk];
     const int ta = lane & 7, tb = lane >> 3;
     float* buf = lds + C3_BUF;
@@ -286,12 +286,12 @@ __device__ __forceinline__ void sweep_cols(const BlockDesc3* __restrict__ blocks
     // every load in flight before it uses them), then u as z-columns and the halo values of the sensor, the x sides, the
     // velocity components each in the layout of its pass
     Slot slots[6];
-    slots[0] = slot_of<0>(bb, htab, blk, lane);
-    slots[1] = slot_of<1>(bb, htab, blk, lane);
-    slots[2] = slot_of<2>(bb, htab, blk, lane);
-    slots[3] = slot_of<3>(bb, htab, blk, lane);
-    slots[4] = slot_of<4>(bb, htab, blk, lane);
-    slots[5] = slot_of<5>(bb, htab, blk, lane);
+    slots[0] = slot_of<0>(bb, htab, blk, lane, dtab);
+    slots[1] = slot_of<1>(bb, htab, blk, lane, dtab);
+    slots[2] = slot_of<2>(bb, htab, blk, lane, dtab);
+    slots[3] = slot_of<3>(bb, htab, blk, lane, dtab);
+    slots[4] = slot_of<4>(bb, htab, blk, lane, dtab);
+    slots[5] = slot_of<5>(bb, htab, blk, lane, dtab);
     __builtin_amdgcn_sched_barrier(0);
     int32_t rids[6];
 #pragma unroll
@@ -303,8 +303,8 @@ __device__ __forceinline__ void sweep_cols(const BlockDesc3* __restrict__ blocks
     hC1.hu = ldg(u, slots[5].hid);
     hB0.hu = ldg(u, slots[2].hid);
     hB1.hu = ldg(u, slots[3].hid);
-    halo_load<0>(bb, u, C, slots[0], rids[0], hA0);
-    halo_load<1>(bb, u, C, slots[1], rids[1], hA1);
+    halo_load<0>(bb, lane, u, C, slots[0], rids[0], hA0);
+    halo_load<1>(bb, lane, u, C, slots[1], rids[1], hA1);
     __builtin_amdgcn_sched_barrier(0);
     Col Cc;
     {
@@ -349,8 +349,8 @@ __device__ __forceinline__ void sweep_cols(const BlockDesc3* __restrict__ blocks
     const LaneGeo LG = lane_geo(lane);
     Col R, Cn2;
     flux_pass<0, 0>(bb, LG, ftab, r4tab, u, C, lds, lane, uc, Cc, Dc, Dx, slots, rids, hA0, hA1, [&]() {
-        halo_load<2>(bb, u, Cy, slots[2], rids[2], hB0);
-        halo_load<3>(bb, u, Cy, slots[3], rids[3], hB1);
+        halo_load<2>(bb, lane, u, Cy, slots[2], rids[2], hB0);
+        halo_load<3>(bb, lane, u, Cy, slots[3], rids[3], hB1);
     }, R, ud);
     load_ycol(Cy + (uint32_t)bb.base + (uint32_t)(ta + 64 * tb), Cn2);  // y-columns: (ta, tb) = (x, z)
     transpose<0, 1>(buf, ta, tb, uc);
@@ -361,8 +361,8 @@ __device__ __forceinline__ void sweep_cols(const BlockDesc3* __restrict__ blocks
     uc.e[0].x = hm0;
     uc.e[4].y = hm1;
     flux_pass<1, 1>(bb, LG, ftab, r4tab, u, Cy, lds, lane, uc, Cn2, Dc, col_diffs(uc), slots, rids, hB0, hB1, [&]() {
-        halo_load<4>(bb, u, Cz, slots[4], rids[4], hC0);
-        halo_load<5>(bb, u, Cz, slots[5], rids[5], hC1);
+        halo_load<4>(bb, lane, u, Cz, slots[4], rids[4], hC0);
+        halo_load<5>(bb, lane, u, Cz, slots[5], rids[5], hC1);
     }, R, ud);
     load_zcol(Cz + (uint32_t)bb.base + lane, Cc);
     transpose<1, 2>(buf, ta, tb, uc);

@@ -118,6 +118,11 @@ struct ibh_part {
     // 3-D single-kernel sweep: used when every block qualifies (sweep3 != 0)
     int32_t *rtab3 = nullptr, *r4tab3 = nullptr;
     int32_t sweep3 = 0;
+    // 3-D image-only single-kernel sweeps (IBH_IMAGE_ONLY on a partition with skirt fragments): the image blocks with
+    // their own tables incl. the deeper-cell table (img_all3 != 0: every image block qualifies)
+    BlockDesc3* iblocks3 = nullptr;
+    int32_t *ihtab3 = nullptr, *iftab3 = nullptr, *irtab3 = nullptr, *ir4tab3 = nullptr, *idtab3 = nullptr;
+    int32_t n_img3 = 0, img_all3 = 0;
     int32_t n_irr = 0;           // cells handled by the general kernels when the fast path is on
     int32_t* irr_cells = nullptr;
     // Flattened stencils of the face-list cells (built when every such cell has <= 4 faces per direction):
@@ -210,6 +215,14 @@ struct Sweep3Host {
     std::vector<int32_t> rtab;   // [nblk][6][64] rim table
     std::vector<int32_t> r4tab;  // [n][4] rim neighbours that are four finer cells
 };
+// image blocks of a partition with skirt fragments and their tables (ibh_analyze3_image.cpp)
+struct Image3Host {
+    bool all = false;            // every image block qualifies for the single-kernel sweeps
+    std::vector<BlockDesc3> blocks;
+    std::vector<int32_t> htab, ftab, rtab, r4tab;  // as htab3 / ftab3 / rtab3 / r4tab3, rows per image block
+    std::vector<int32_t> dtab;   // [nblk][6][64][4] the cell one step deeper behind halo cell k of slot t
+};
+void ibh_analyze_image3(const HostPartView& v, const int32_t* image_in_domain, int32_t n_image, Image3Host& out);
 void ibh_analyze_blocks3(const HostPartView& v, std::vector<BlockDesc3>& blocks, std::vector<int32_t>& irr_cells,
                          int64_t* info, const int32_t* image_in_domain, int32_t n_image, int32_t* n_phase1,
                          std::vector<int32_t>& htab, std::vector<int32_t>& ftab, Sweep3Host* sw);

@@ -877,15 +877,20 @@ __global__ __launch_bounds__(64 * WPB3S) __attribute__((amdgpu_waves_per_eu(WAVE
 #ifndef WPB3C
 #define WPB3C 2
 #endif
-template <int WAVES>
+// TAB: the block table is that of the IMAGE blocks of a partition with skirt fragments (ibh_analyze3_image.cpp): sides
+// towards a fragment take halo and deeper cells from tables (dtab)
+template <int WAVES, bool TAB = false>
 __global__ __launch_bounds__(64 * WPB3C) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_sweep3_cols(
     const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc, float* __restrict__ ud,
     const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab, const int32_t* __restrict__ ftab,
-    const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg) {
+    const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg,
+    const int32_t* __restrict__ dtab = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[WPB3C * C3_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3C + wave);
-    if (blk < n) cols3::sweep_cols(blocks, htab, ftab, rtab, r4tab, blk, u, C, ldc, ud, lds + wave * C3_LDS, lane);
+    if (blk < n)
+        cols3::sweep_cols(blocks, htab, ftab, rtab, r4tab, blk, u, C, ldc, ud, lds + wave * C3_LDS, lane,
+                          TAB ? dtab : nullptr);
 }
 
 // Column form of the 3-D Euler sweep (strip3e::sweep_euler_cols): one wavefront per block.  (A persistent form -- a
@@ -894,18 +899,19 @@ __global__ __launch_bounds__(64 * WPB3C) __attribute__((amdgpu_waves_per_eu(WAVE
 #ifndef WPB3E
 #define WPB3E 2
 #endif
-template <int WAVES, bool STAMP = false>
+template <int WAVES, bool STAMP = false, bool TAB = false>
 __global__ __launch_bounds__(64 * WPB3E) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_sweep3_euler_cols(
     const float* __restrict__ P, uint32_t ldp, float* __restrict__ R, uint32_t ldr, float Rgas, float gamma,
     const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab, const int32_t* __restrict__ ftab,
-    const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg) {
+    const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg,
+    const int32_t* __restrict__ dtab = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[WPB3E * S3E_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3E + wave);
     if (blk >= n) return;
     strip3e::sweep_euler_cols<STAMP>(blocks, htab, ftab, rtab, r4tab, blk, P, ldp, R, ldr, blk3::Gas3{Rgas, gamma},
                                      lds + wave * S3E_LDS, lane,
-                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)blk * 8 : nullptr);
+                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)blk * 8 : nullptr, TAB ? dtab : nullptr);
 }
 
 // wave-per-block form of the 3-D scalar pass A (blk3::passA_wave): 4 blocks per 256-thread workgroup
@@ -1087,6 +1093,16 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     if (p->nd == 3 && p->bs == 8 && p->blocks3 && p->nblk > 0 && !(flags & (IBH_FORCE_GENERAL | IBH_EXACT))) {
         const bool ph1 = (flags & IBH_PHASE_INTERIOR) != 0, ph2 = (flags & IBH_PHASE_BOUNDARY) != 0;
         IBH_REQUIRE(!(ph1 && ph2), "IBH_PHASE_INTERIOR and IBH_PHASE_BOUNDARY are exclusive");
+        if ((flags & IBH_IMAGE_ONLY) && p->img_all3 && !ph1 && !ph2 &&
+            !(flags & (IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY))) {
+            // only the image cells are wanted (a rank of a multi-GPU run) and every image block qualifies: one launch over
+            // the image blocks, no workspace, nothing for the skirt fragments
+            const int32_t nwg = (p->n_img3 + WPB3C - 1) / WPB3C;
+            hipLaunchKernelGGL((k_sweep3_cols<3, true>), dim3(nwg), dim3(64 * WPB3C), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
+                               p->iblocks3, p->ihtab3, p->iftab3, p->irtab3, p->ir4tab3, p->n_img3, nwg, p->idtab3);
+            IBH_LAUNCH_CHECK();
+            return 0;
+        }
         if (p->sweep3 && !ph1 && !ph2 &&
             !(flags & (IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY | IBH_IMAGE_ONLY))) {
             // every block qualifies for the single-kernel sweep: one launch, nothing through the workspace
@@ -1458,6 +1474,17 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
             hipLaunchKernelGGL(k_sweep_euler, dim3(nwg), dim3(64 * WPBE), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,
                                fluid->R, fluid->gamma, bl, ht, et, p->dtab, count, nwg, iters, list ? list + i0 : nullptr);
         }
+        IBH_LAUNCH_CHECK();
+        return 0;
+    }
+    if (p->nd == 3 && p->img_all3 && (flags & IBH_IMAGE_ONLY) && p->bs == 8 &&
+        !(flags & (IBH_FORCE_GENERAL | IBH_EXACT | IBH_NO_FUSE | IBH_PASS_A_ONLY | IBH_PASS_B_ONLY | IBH_PHASE_INTERIOR |
+                   IBH_PHASE_BOUNDARY))) {
+        // image blocks of a partition with skirt fragments: one launch, nothing through the workspace
+        const int32_t nwg = (p->n_img3 + WPB3E - 1) / WPB3E;
+        hipLaunchKernelGGL((k_sweep3_euler_cols<2, false, true>), dim3(nwg), dim3(64 * WPB3E), 0, ibh_stream, P,
+                           (uint32_t)ldp, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->iblocks3, p->ihtab3, p->iftab3,
+                           p->irtab3, p->ir4tab3, p->n_img3, nwg, p->idtab3);
         IBH_LAUNCH_CHECK();
         return 0;
     }

@@ -239,17 +239,28 @@ __device__ __forceinline__ float slot_sensor(const float* pl, const float* pA, f
 
 // what a lane holds of slot `lane` of one side
 struct Slot {
-    uint32_t hid;  // halo cell (the first of four on a FINE side)
-    int dd;        // offset to the cell one step deeper
+    uint32_t hid;         // halo cell (the first of four on a FINE side)
+    int dd;               // offset to the cell one step deeper ...
+    const int32_t* drow;  // ... or (image-only sweeps of a partition with skirt fragments) the deeper-cell table row of the
+                          // block, [6][64][4]; null: arithmetic everywhere
 };
 template <int S>
-__device__ __forceinline__ Slot slot_of(const BlockDesc3& bb, const int32_t* __restrict__ htab, int32_t blk, int lane) {
+__device__ __forceinline__ Slot slot_of(const BlockDesc3& bb, const int32_t* __restrict__ htab, int32_t blk, int lane,
+                                        const int32_t* __restrict__ dtab = nullptr) {
     constexpr int d = S >> 1;
     constexpr int sd = d == 0 ? 1 : d == 1 ? 8 : 64;
     Slot s;
     s.hid = halo_cell3s<S>(bb, htab, blk, lane);
     s.dd = bb.type[S] == SIDE_MIRROR ? 0 : ((S & 1) ? sd : -sd);
+    s.drow = dtab ? dtab + (size_t)blk * 1536 : nullptr;
     return s;
+}
+// the cell one step deeper behind halo cell c = k-th cell of slot `lane` of side S
+template <int S>
+__device__ __forceinline__ uint32_t deeper_of(const BlockDesc3& bb, const Slot& sl, int lane, int k, uint32_t c) {
+    if (sl.drow && bb.nb[S] < 0 && bb.type[S] != SIDE_MIRROR)  // wave-uniform
+        return (uint32_t)sl.drow[(S * 64 + lane) * 4 + k];
+    return (uint32_t)((int)c + sl.dd);
 }
 
 // mean halo pressure behind boundary cell `lane` of side S and mean |halo - boundary cell| (own-cell sensor)
@@ -392,7 +403,7 @@ __device__ __forceinline__ void side_eval(const BlockDesc3& bb, const LaneGeo& L
 #pragma unroll
             for (int v = 0; v < 5; ++v) {
                 hk[v] = ldg(P + (size_t)v * ldp, c);
-                hdk[v] = ldg(P + (size_t)v * ldp, (uint32_t)((int)c + sl.dd));
+                hdk[v] = ldg(P + (size_t)v * ldp, deeper_of<S>(bb, sl, lane, k, c));
             }
             const int f1 = 2 * t1 + (k & 1), f2 = 2 * t2 + (k >> 1);
             const float dhk = slot_sensor<false>(pl, pA, hk[0], hdk[0], Pb[0], Pb[0], Pb[0], Pb[0], f1 + 18 * (f2 + 1),
@@ -423,18 +434,20 @@ struct HaloRegs {
     float hu[5], hd[5], rv;
 };
 template <int S>
-__device__ __forceinline__ void halo_load_values(const float* __restrict__ P, uint32_t ldp, const Slot& sl, HaloRegs& h) {
+__device__ __forceinline__ void halo_load_values(const BlockDesc3& bb, int lane, const float* __restrict__ P, uint32_t ldp,
+                                                 const Slot& sl, HaloRegs& h) {
+    const uint32_t hd = deeper_of<S>(bb, sl, lane, 0, sl.hid);
 #pragma unroll
     for (int v = 0; v < 5; ++v) {
         const float* Pv = P + (size_t)v * ldp;
         h.hu[v] = ldg(Pv, sl.hid);
-        h.hd[v] = ldg(Pv, (uint32_t)((int)sl.hid + sl.dd));
+        h.hd[v] = ldg(Pv, hd);
     }
 }
 template <int S>
-__device__ __forceinline__ void halo_load(const BlockDesc3& bb, const float* __restrict__ P, uint32_t ldp, const Slot& sl,
-                                          int32_t rid, HaloRegs& h) {
-    halo_load_values<S>(P, ldp, sl, h);
+__device__ __forceinline__ void halo_load(const BlockDesc3& bb, int lane, const float* __restrict__ P, uint32_t ldp,
+                                          const Slot& sl, int32_t rid, HaloRegs& h) {
+    halo_load_values<S>(bb, lane, P, ldp, sl, h);
     h.rv = ldg(P, (uint32_t)(rid >= 0 ? rid : bb.base));
 }
 
@@ -603,16 +616,16 @@ struct Pre {
     float hp[6];
 };
 __device__ __forceinline__ void load_pre(const BlockDesc3& bn, const int32_t* __restrict__ htab,
-                                         const int32_t* __restrict__ rtab, const float* __restrict__ P, int32_t blk,
-                                         int lane, Pre& q) {
+                                         const int32_t* __restrict__ rtab, const int32_t* __restrict__ dtab,
+                                         const float* __restrict__ P, int32_t blk, int lane, Pre& q) {
     // halo cell ids first: where a side is FINE (a table load) the compiler waits for every load in flight before it
     // uses the ids
-    q.slots[0] = slot_of<0>(bn, htab, blk, lane);
-    q.slots[1] = slot_of<1>(bn, htab, blk, lane);
-    q.slots[2] = slot_of<2>(bn, htab, blk, lane);
-    q.slots[3] = slot_of<3>(bn, htab, blk, lane);
-    q.slots[4] = slot_of<4>(bn, htab, blk, lane);
-    q.slots[5] = slot_of<5>(bn, htab, blk, lane);
+    q.slots[0] = slot_of<0>(bn, htab, blk, lane, dtab);
+    q.slots[1] = slot_of<1>(bn, htab, blk, lane, dtab);
+    q.slots[2] = slot_of<2>(bn, htab, blk, lane, dtab);
+    q.slots[3] = slot_of<3>(bn, htab, blk, lane, dtab);
+    q.slots[4] = slot_of<4>(bn, htab, blk, lane, dtab);
+    q.slots[5] = slot_of<5>(bn, htab, blk, lane, dtab);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 6; ++s) q.rids[s] = rtab[(size_t)blk * 384 + s * 64 + lane];
@@ -631,7 +644,8 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
                                                  const int32_t* __restrict__ r4tab, int32_t blk,
                                                  const float* __restrict__ P, uint32_t ldp, float* __restrict__ Rr,
                                                  uint32_t ldr, Gas3 gas, float* lds, int lane,
-                                                 unsigned long long* stamps = nullptr) {
+                                                 unsigned long long* stamps = nullptr,
+                                                 const int32_t* __restrict__ dtab = nullptr) {
     auto stamp = [&](int k) {
         if constexpr (STAMP) {
             __builtin_amdgcn_sched_barrier(0);
@@ -647,7 +661,7 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
     // ---- every load that does not depend on another one, up front, in the order of their use: those of the sensor, then
     // the loads of the x fluxes:
     Pre pre;
-    load_pre(bb, htab, rtab, P, blk, lane, pre);
+    load_pre(bb, htab, rtab, dtab, P, blk, lane, pre);
     // ---- the halo registers of the x sides, the five primitives
     // as x-columns (two float4 per field)
     Slot slots[6];
@@ -658,8 +672,8 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
         rids[s] = pre.rids[s];
     }
     HaloRegs hA0, hA1, hB0, hB1;
-    halo_load_values<0>(P, ldp, slots[0], hA0);
-    halo_load_values<1>(P, ldp, slots[1], hA1);
+    halo_load_values<0>(bb, lane, P, ldp, slots[0], hA0);
+    halo_load_values<1>(bb, lane, P, ldp, slots[1], hA1);
     __builtin_amdgcn_sched_barrier(0);
     Col Pc[5];
     {
@@ -701,8 +715,8 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
     // ---- fluxes: x, y, z
     const LaneGeo LG = lane_geo(lane);
     flux_pass<0, 0>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hA0, hA1, [&]() {
-        halo_load<2>(bb, P, ldp, slots[2], rids[2], hB0);
-        halo_load<3>(bb, P, ldp, slots[3], rids[3], hB1);
+        halo_load<2>(bb, lane, P, ldp, slots[2], rids[2], hB0);
+        halo_load<3>(bb, lane, P, ldp, slots[3], rids[3], hB1);
     }, Rr, ldr);
     stamp(3);
 #pragma unroll
@@ -710,8 +724,8 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
     transpose<0, 1>(buf, ta, tb, Dc);
     stamp(4);
     flux_pass<1, 1>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hB0, hB1, [&]() {
-        halo_load<4>(bb, P, ldp, slots[4], rids[4], hA0);
-        halo_load<5>(bb, P, ldp, slots[5], rids[5], hA1);
+        halo_load<4>(bb, lane, P, ldp, slots[4], rids[4], hA0);
+        halo_load<5>(bb, lane, P, ldp, slots[5], rids[5], hA1);
     }, Rr, ldr);
     stamp(5);
 #pragma unroll

@@ -283,3 +283,58 @@ def test_3d_single_kernels_on_small_octrees(kind):
     g3 = ibamd.cell_gradient(dpart, du)
     for d in (1, 2, 3):
         assert rel_inf(ibamd.to_host(g3[d - 1]), ibamd.to_host(ibamd.cell_gradient(dpart, du, d))) <= 5e-6
+
+
+@pytest.mark.gpu
+def test_3d_image_only_sweeps_on_partitions():
+    """IBH_IMAGE_ONLY on 3-D partitions with skirt fragments (what a rank of a multi-GPU run sweeps,
+    ImmersedBoundary.jl:610-619, 842-845): every image block qualifies for the single-kernel column sweeps -- halo, deeper
+    and rim cells inside skirt fragments come from tables (csrc/ibh_analyze3_image.cpp) -- so the scalar and the Euler sweep
+    are ONE launch over the image blocks, nothing is written outside the image, and the image cells agree with the C
+    restatement of the oracle (oracle/residual_c.py) and with the two-kernel form over the whole partition."""
+    import torch
+    import bench
+    from oracle import residual_c as rc
+    msh = Mesh(f32([-4, -4, -4]), f32([8, 8, 8]), ("sphere", bench.icosphere(subdiv=2), f32(0.2)), block_size=8)
+    msh.distance_fields = {}
+    n = len(msh)
+    nparts = 4
+    mps = -(-(-(-n // nparts)) // 512) * 512
+    IO = ibamd.IBH_IMAGE_ONLY
+    rng = np.random.default_rng(7)
+    used = 0
+    for pid in (1, 3):
+        dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=False, only=[pid])
+        part = dom.partitions[pid]
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        info = dpart.info
+        img = part.image_in_domain
+        nc = part.centers.shape[0]
+        assert nc > img.size                                   # there is a skirt
+        assert info["image_blocks_all_eligible"] and info["image_blocks"] * 512 == img.size
+        assert info["fusable_blocks"] == 0                     # (the all-cells sweep of this partition is the two-kernel form)
+        used += 1
+        x = part.centers
+        u = (np.sin(2 * x[:, 0]) * np.cos(3 * x[:, 1]) + 0.3 * x[:, 2] + 0.1 * rng.uniform(-1, 1, nc)).astype(f32)
+        C = np.stack([np.ones(nc, f32), f32(0.5) + f32(0.1) * rng.uniform(-1, 1, nc).astype(f32),
+                      f32(-0.25) * np.ones(nc, f32)], axis=1)
+        cpart = rc.CPart(part)
+        exp = cpart.residual_advection(u, C)
+        out = torch.full((nc,), float("nan"), dtype=torch.float32, device="cuda")
+        ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C), out=out, flags=IO)
+        one = ibamd.to_host(out)
+        assert np.isnan(one).sum() == nc - img.size            # nothing written outside the image
+        assert rel_inf(one[img], exp[img]) <= 1e-5
+        full = ibamd.to_host(ibamd.residual_advection(dpart, ibamd.hip(u), ibamd.hip(C)))
+        assert rel_inf(one[img], full[img]) <= 2e-6
+        P = np.stack([f32(1e5) * (1 + f32(0.05) * rng.uniform(-1, 1, nc)), f32(288.15) * (1 + f32(0.05) * rng.uniform(-1, 1, nc)),
+                      f32(100.0) * (1 + f32(0.1) * rng.uniform(-1, 1, nc)), f32(60.0) * (1 + f32(0.1) * rng.uniform(-1, 1, nc)),
+                      f32(-40.0) * (1 + f32(0.1) * rng.uniform(-1, 1, nc))], axis=1).astype(f32)
+        expE = cpart.residual_euler(P)
+        outE = torch.full((5, nc), float("nan"), dtype=torch.float32, device="cuda").T
+        ibamd.residual_euler_hll(dpart, ibamd.hip(P), out=outE, flags=IO)
+        oneE = ibamd.to_host(outE)
+        assert np.isnan(oneE).sum() == 5 * (nc - img.size)
+        for v in range(5):
+            assert rel_inf(oneE[img, v], expE[img, v]) <= 1e-5, v
+    assert used == 2
