@@ -269,8 +269,8 @@ def main():
     march = args.step == "march"
     if march and (msh.ndims != 2 or args.residual != "advection" or world != 1):
         raise SystemExit("--step march: the explicit step of test/advection.jl on a 2-D workload, one GPU")
-    if (config4 or config5) and (msh.ndims != 3 or args.residual != "euler" or world != 1):
-        raise SystemExit("--step config4 / config5 need a sphere3d workload, --residual euler and one GPU")
+    if (config4 or config5) and (msh.ndims != 3 or args.residual != "euler"):
+        raise SystemExit("--step config4 / config5 need a sphere3d workload and --residual euler")
     if config5:
         msh.distance_fields = {}  # the V-cycle line builds no ghost cells (config4 does)
     fam4 = [("farfield", [(d, s_) for d in (1, 2, 3) for s_ in (False, True)])]
@@ -309,10 +309,14 @@ def main():
         flags |= ibamd.IBH_IMAGE_ONLY
 
     hx = None
+    auto_forms = False
     comm_stream = None
     halo_kind = None
     fused_step = False
-    if world > 1:
+    if world > 1 and (config4 or config5):
+        from ibamd.halo import HaloExchange, HaloPlan   # (these steps bring their own exchangers, below)
+        halo_kind = "rccl" if args.backend == "nccl" else "gloo-staged"
+    if world > 1 and not (config4 or config5):
         from ibamd.halo import (HaloExchange, HaloPlan, XgmiHalo, euler_sweep_overlapped, sweep_overlapped,
                                 verify_exchangers)
         plan = HaloPlan(dom, rank + 1)
@@ -397,15 +401,59 @@ def main():
         else:
             ibamd.residual_advection(dpart, u, C, out=ud, flags=flags | extra)
 
+    dist4 = dist5 = None
     if config4:
         from ibamd import cfd as gcfd
         far_bc = gcfd.FlowBC(gcfd.Fluid(), [1.0e5, 288.15, 100.0, 0.0, 0.0])
         wall_bc = gcfd.FlowBC(gcfd.Fluid(), [1.0e5, 288.15, 0.0], normal_flow=True)
-        for bname in dom.boundaries:                  # device-resident Boundary structs, built before the timed region
-            for b in dom.boundaries[bname].values():
+        bdom4 = dom
+        if world > 1:
+            # one partition per rank (distributed.py): the ghosts this rank owns, re-indexed to its local rows, their donor
+            # cells beyond the skirt appended to the local arrays and to the halo lists
+            from ibamd.distributed import LocalDomain, bc_donor_extras
+            extras4 = bc_donor_extras(dom)
+            bdom4 = LocalDomain(dom, rank + 1, extras4)
+            hx4 = HaloExchange(HaloPlan(dom, rank + 1, extra=extras4), u.device)
+            P4 = ibamd.colmajor_empty(bdom4.n_rows, nvp)
+            P4[:] = P[0]
+            P4[:dpart.nc] = P
+            dist4 = {"extra_rows": int(bdom4.n_rows - dpart.nc), "recv_cells": hx4.plan.n_recv}
+        for bname in bdom4.boundaries:                # device-resident Boundary structs, built before the timed region
+            for b in bdom4.boundaries[bname].values():
                 ibamd.to_backend(b, ibamd.hip)
 
-    if config5:
+    if config5 and world > 1:
+        # FAS! across ranks (distributed.RankLevels): every rank holds its partition of every level, the transfer operators
+        # restricted to its rows, a halo exchange per level; norms all-reduced over the owned cells
+        from ibamd.closures import euler_wray_agarwal_residual
+        from ibamd.distributed import RankLevels, Reductions
+        lv5 = RankLevels(msh, rank + 1, world, 2, domain_kwargs=dict(boundaries=False))
+        levels5 = [dpart] + [ibamd.to_backend(p_, ibamd.hip) for p_ in lv5.parts[1:]]
+        hx5 = [HaloExchange(pl, u.device) for pl in lv5.plans]
+        red5 = [Reductions(p_.image_in_domain, device=u.device) for p_ in lv5.parts]
+        coar5, prol5 = lv5.coarseners, lv5.prolongators
+        for a5 in list(prol5) + list(coar5):
+            ibamd.to_backend(a5)
+        Q5 = ibamd.colmajor_empty(lv5.nrows[0], nvp + 1)
+        Q5[:] = 0.0
+        Q5[:dpart.nc, :nvp] = P
+        Q5[:, nvp] = 4.5e-5
+        hx5[0].exchange(Q5)
+        Q5_0 = Q5.clone()
+        ncs5 = [int(l_.nc) for l_ in levels5]
+
+        def f5(level, Q):
+            nc_l = ncs5[level]
+            if Q.shape[0] == nc_l:
+                return euler_wray_agarwal_residual(levels5[level], Q), 2e-7
+            r = ibamd.colmajor_empty(Q.shape[0], nvp + 1)
+            r[nc_l:] = 0.0
+            r[:nc_l] = euler_wray_agarwal_residual(levels5[level], Q[:nc_l])
+            return r, 2e-7
+        dist5 = {"levels_rows": [int(n_) for n_ in lv5.nrows], "levels_cells": ncs5,
+                 "extra_rows": [int(lv5.nrows[l_] - ncs5[l_]) for l_ in range(3)],
+                 "recv_cells": [int(pl.n_recv) for pl in lv5.plans]}
+    elif config5:
         from ibamd.closures import euler_wray_agarwal_residual
         cds5, prol5, coar5 = ibamd.multigrid(dom, max_levels=2)
         levels5 = [dpart] + [ibamd.to_backend(d.partitions[1], ibamd.hip) for d in cds5]
@@ -437,9 +485,20 @@ def main():
             ibamd.step_advection(dpart, um[k & 1], C, dt_m, bcs_m, out=um[(k + 1) & 1])
             mstate["k"] = k + 1
             return
-        if config5:
+        if config5 and world > 1:
+            Q5.copy_(Q5_0)
+            ibamd.FAS(f5, Q5, coarseners=coar5, prolongators=prol5, n_iter=2, rtol=1e-9,
+                      exchange=lambda l_, Q_: hx5[l_].exchange(Q_),
+                      level_norm=lambda l_, r_: red5[l_].norm(r_[:ncs5[l_]]))
+        elif config5:
             Q5.copy_(Q5_0)
             ibamd.FAS(f5, Q5, coarseners=coar5, prolongators=prol5, n_iter=2, rtol=1e-9)
+        elif config4 and world > 1:
+            hx4.exchange(P4)                              # skirt and donor rows as the owners have them
+            ibamd.impose_bc(lambda b, ia: far_bc(ia, b.normals), bdom4, "farfield", P4)
+            ibamd.impose_bc(lambda b, ia: wall_bc(ia, b.normals), bdom4, "sphere", P4)
+            hx4.exchange(P4)                              # the ghosts the peers own, for the sweep
+            ibamd.residual_euler_hll(dpart, P4[:dpart.nc], out=Rres, flags=flags)
         elif config4:
             ibamd.impose_bc(lambda b, ia: far_bc(ia, b.normals), dom, "farfield", P)
             ibamd.impose_bc(lambda b, ia: wall_bc(ia, b.normals), dom, "sphere", P)
@@ -765,7 +824,12 @@ def main():
                    "block_analysis": dpart.info},
         "roofline": roofline,
     }
-    if config4:
+    if config4 and world > 1:
+        out["metric"] = ("Mcells*iters/s, config-4 step across ranks (exchange, impose_bc! FlowBC on the owned ghosts, "
+                         "exchange, Euler HLL residual sweep on the image blocks), 3D sphere")
+        out["config"]["step"] = dict(dist4, what="distributed.LocalDomain: local boundary chunks, donor cells beyond the "
+                                                 "skirt as extra rows; two exchanges per step")
+    if config4 and world == 1:
         from ibamd import point_implicit as pi
         P0 = P.clone()
         dtp = 1e-5
@@ -800,6 +864,8 @@ def main():
     if config5:
         out["metric"] = ("Mcells*V-cycles/s, config-5 step (FAS! V-cycle, 3 levels x 2 smoothing iterations, Euler HLL + "
                          "Wray-Agarwal scalar residual), 3D sphere")
+        if dist5 is not None:
+            out["config"]["distributed"] = dist5
         out["config"]["step"] = {"levels_cells": [int(l.nc) for l in levels5],
                                  "residual_evaluations_per_step": 9,
                                  "what": "solver.jl:39-91 over multigrid() (ImmersedBoundary.jl:1355-1407); residual = fused "

@@ -149,3 +149,122 @@ class Reductions:
         """Global minimum of a per-rank scalar (the time step of test/advection.jl:52-59)."""
         t = self.torch.tensor([float(x)], dtype=self.torch.float64)
         return float(self._allreduce(t, self.dist.ReduceOp.MIN).item())
+
+
+# ---------------------------------------------------------------------------
+# FAS! across ranks: the levels of multigrid(dom) with one partition of every level per rank
+# ---------------------------------------------------------------------------
+def _local_rows(gids, domain, extra):
+    """Local rows of global cells ``gids``: position in ``domain`` (sorted), else ``len(domain)`` + position in ``extra``."""
+    gids = np.asarray(gids, dtype=np.int64)
+    nc = domain.size
+    pos = np.minimum(np.searchsorted(domain, gids), max(nc - 1, 0))
+    in_dom = domain[pos] == gids if nc else np.zeros(gids.shape, bool)
+    if extra is None or extra.size == 0:
+        assert np.all(in_dom), "transfer donor cell outside the local domain and no extras given"
+        return pos.astype(np.int64)
+    epos = np.minimum(np.searchsorted(extra, gids), extra.size - 1)
+    assert np.all(in_dom | (extra[epos] == gids)), "transfer donor cell neither in the domain nor in the extras"
+    return np.where(in_dom, pos, nc + epos).astype(np.int64)
+
+
+def _rows_accumulator(acc_rows, n_out_local, out_rows_local, col_local, n_in_local):
+    """Local Accumulator with ``n_out_local`` rows: row ``out_rows_local[i]`` holds stencil ``i`` of ``acc_rows`` (columns
+    re-indexed by ``col_local``); every other row is empty (its output is zero)."""
+    lens = np.zeros(n_out_local, dtype=np.int64)
+    lens[out_rows_local] = np.diff(acc_rows.off)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    # out_rows_local is increasing (image cells in domain order): the stencils are already in CSR order
+    assert np.all(np.diff(out_rows_local) > 0)
+    return Accumulator(csr=(off, col_local.astype(np.int32), acc_rows.w), first_index=True, n_input=n_in_local)
+
+
+class RankLevels:
+    """What a rank holds of ``multigrid(dom)`` (ImmersedBoundary.jl:1355-1407) when every level is cut the same way
+    (partition ``pid`` of every level = the same blocks of the shared block tree, ``max_partition_size`` divided by
+    ``factor^nd`` per level): its partition of every level with a halo plan, and the transfer operators restricted to
+    the rows it owns, re-indexed to local rows --
+
+    * ``coarseners[l]``: level l -> l + 1, rows = the rank's image cells of level l + 1; the IDW donors of a coarse cell are
+      its own children, local by construction;
+    * ``prolongators[l]``: level l + 1 -> l, rows = the rank's image cells of level l; IDW donors are coarse cells around
+      the fine cell, in the coarse partition's skirt or -- rarely -- beyond it: those are appended to the coarse level's
+      local arrays as extra rows and to its halo lists (as ``bc_donor_extras`` does for ``impose_bc!``), gathered from
+      all ranks at set-up.
+
+    Same stencils and weights as the global operators (the interpolator is called on the same points with the same
+    trees), so a V-cycle over these reproduces the one-partition V-cycle on the owned cells."""
+
+    def __init__(self, msh, pid, world, max_levels, factor=2, group=None, domain_kwargs=None):
+        from scipy.spatial import cKDTree
+        from .domain import Domain, interpolator
+        from .halo import HaloPlan
+        from .mesher import Mesh
+        nd = msh.ndims
+        kw = dict(domain_kwargs or {})
+        npb = msh.block_size ** nd
+        ncells = len(msh)
+        mps = -(-(-(-ncells // world)) // npb) * npb
+        self.pid, self.world = pid, world
+        self.doms, self.parts, self.plans, self.extras, self.nrows = [], [], [], [], []
+        self.coarseners, self.prolongators = [], []
+        meshes = [msh]
+        bs = msh.block_size
+        for _ in range(max_levels):
+            bs //= factor
+            meshes.append(Mesh(msh.origin, msh.widths, block_size=bs, block_origins=msh.block_origins,
+                               block_widths=msh.block_widths, distance_fields=msh.distance_fields))
+        for l, m in enumerate(meshes):
+            dom = Domain(m, max_partition_size=mps // (factor ** nd) ** l, only=[pid], **kw)
+            assert len(dom.images) == world, "every level must be cut into one partition per rank"
+            self.doms.append(dom)
+            self.parts.append(dom.partitions[pid])
+        X = [d.global_centers() for d in self.doms]
+        trees = [cKDTree(x.astype(np.float64)) for x in X]
+        need_extra = []
+        pro_rows = []
+        for l in range(max_levels):
+            fine, coarse = self.parts[l], self.parts[l + 1]
+            flo, fhi = self.doms[l].images[pid]
+            clo, chi = self.doms[l + 1].images[pid]
+            # the rank's rows of the global operators: same points, same trees, same weights
+            co = interpolator(X[l], X[l + 1][clo:chi], trees[l], linear=False)        # coarse image rows <- fine cells
+            pr = interpolator(X[l + 1], X[l][flo:fhi], trees[l + 1], linear=False)    # fine image rows <- coarse cells
+            fdom = np.asarray(fine.domain, dtype=np.int64)
+            cdom = np.asarray(coarse.domain, dtype=np.int64)
+            self.coarseners.append((co, _local_rows(co.idx, fdom, None)))
+            donors = np.asarray(pr.idx, dtype=np.int64)
+            miss = np.unique(donors[~np.isin(donors, cdom)])
+            need_extra.append(miss)
+            pro_rows.append(pr)
+        # extras of every partition of every coarse level: gathered (a rank must know what the others need of it)
+        import torch.distributed as dist
+        tables = []
+        for l in range(max_levels + 1):
+            mine = need_extra[l - 1] if l >= 1 else np.zeros(0, dtype=np.int64)
+            if dist.is_initialized() and world > 1:
+                every = [None] * world
+                dist.all_gather_object(every, mine, group=group)
+            else:
+                every = [mine]
+            tables.append({q + 1: np.asarray(every[q], dtype=np.int64) for q in range(world)})
+        for l in range(max_levels + 1):
+            self.extras.append(tables[l])
+            self.plans.append(HaloPlan(self.doms[l], pid, extra=tables[l]))
+            self.nrows.append(int(self.parts[l].domain.size + tables[l][pid].size))
+        # local operators
+        co_local, pr_local = [], []
+        for l in range(max_levels):
+            co, cols = self.coarseners[l]
+            co_local.append(_rows_accumulator(co, self.nrows[l + 1], np.asarray(self.parts[l + 1].image_in_domain),
+                                              cols, self.nrows[l]))
+            pr = pro_rows[l]
+            cdom = np.asarray(self.parts[l + 1].domain, dtype=np.int64)
+            cols = _local_rows(pr.idx, cdom, tables[l + 1][pid])
+            pr_local.append(_rows_accumulator(pr, self.nrows[l], np.asarray(self.parts[l].image_in_domain), cols,
+                                              self.nrows[l + 1]))
+        self.coarseners, self.prolongators = co_local, pr_local
+
+    @property
+    def n_levels(self):
+        return len(self.parts)

@@ -44,7 +44,7 @@ def _update(Q, omega, r):
 
 
 def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level=0, n_iter=50,
-        rtol=1e-1, atol=1e-7, norm=None, check_every=1):
+        rtol=1e-1, atol=1e-7, norm=None, check_every=1, exchange=None, level_norm=None):
     """``FAS!(f, Q; coarseners, prolongators, perscribed_f, multigrid_level, n_iter, rtol, atol)``.
 
     ``f(level, Q) -> (r, omega)`` with device arrays; ``Q`` is updated in place.  Returns the residual-norm
@@ -53,9 +53,19 @@ def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level
     ``check_every``: the convergence test -- the one host round trip (and all-reduce) of an iteration -- is made every
     that many iterations and after the last one; 1 = the reference's loop, larger values may run up to
     ``check_every - 1`` smoothing steps past the reference's exit.
+    On a rank of a multi-GPU run (``distributed.RankLevels``: the rank's partition of every level, local transfer
+    operators): ``exchange(level, Q)`` refreshes the skirt (and donor) rows of a level's local array -- called before every
+    residual evaluation and around the coarse solve, where the prolongation reads coarse skirt rows -- and
+    ``level_norm(level, r)`` is the norm over the owned cells of all ranks (``Reductions.norm`` of that level).
     """
-    _norm = norm if norm is not None else globals()["_norm"]
+    if level_norm is not None:
+        def _norm(r, _l=multigrid_level):
+            return level_norm(_l, r)
+    else:
+        _norm = norm if norm is not None else globals()["_norm"]
     l = multigrid_level
+    xch = exchange if exchange is not None else (lambda _l, _q: None)
+    xch(l, Q)
     fQ, omega = f(l, Q)
     source = None
     if perscribed_f is not None:
@@ -66,14 +76,17 @@ def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level
     if len(coarseners) > 1:
         coars, prolong = B.to_backend(coarseners[0]), B.to_backend(prolongators[0])
         Qc = coars(Q)
+        xch(l + 1, Qc)                       # (the prolongation below reads skirt rows of Qc - Qcold)
         Qcold = Qc.clone()
         pfQc = coars(r)
         FAS(f, Qc, coarseners=coarseners[1:], prolongators=prolongators[1:], perscribed_f=pfQc,
             multigrid_level=multigrid_level + 1, n_iter=n_iter, atol=atol, rtol=rtol, norm=norm,
-            check_every=check_every)
+            check_every=check_every, exchange=exchange, level_norm=level_norm)
+        xch(l + 1, Qc)
         Q += prolong(Qc - Qcold)
     check_every = max(1, int(check_every))
     for it in range(n_iter):
+        xch(l, Q)
         r, omega = f(l, Q)
         if source is not None:
             r = r + source

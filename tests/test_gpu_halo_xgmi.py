@@ -24,3 +24,17 @@ def test_xgmi_halo_two_ranks_one_gpu():
     assert "xgmi == reference exchange: True" in r.stdout
     assert "graph-captured overlapped sweeps with xGMI exchange match: True" in r.stdout
     assert "fused exchange + sweep step matches exchange-then-sweep: True" in r.stdout
+
+
+def test_device_fas_across_two_ranks_one_gpu():
+    """`FAS!` over `multigrid(dom)` across ranks, device resident (distributed.RankLevels, solver.FAS hooks; 2 processes on
+    the one GPU, gloo group): reproduces the one-partition device V-cycle on the owned cells (scripts/rehearse_fas.py)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "rehearse_fas.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "distributed device V-cycle == one-partition device V-cycle on the owned cells: True" in r.stdout, r.stdout[-1500:]
