@@ -68,6 +68,7 @@ _SIGS = {
     "ibh_scatter_rows": [c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_copy_rows": [c_vp, c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_residual_advection": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
+    "ibh_scalar_transport": [c_vp, c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp],
     "ibh_bcset_create": [C.POINTER(c_vp), c_int, C.POINTER(c_vp), c_vp, c_vp],
     "ibh_bcset_destroy": [c_vp],
     "ibh_bcset_info": [c_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],

@@ -498,6 +498,14 @@ def cell_gradient(part, u, dim=None):
     return out
 
 
+def cell_gradient_array(part, u):
+    """``cell_gradient(part, u)`` of a scalar field as ONE ``(nc, nd)`` array (the tuple form's buffer: no copies)."""
+    g = cell_gradient(part, u)
+    base = g[0]
+    nd = len(g)
+    return torch.as_strided(base, (base.shape[0], nd), (1, base.shape[0]), base.storage_offset())
+
+
 def _dist(name, part, dim):
     part = _part(part)
     out = colmajor_empty(part.nf[dim - 1])

@@ -28,13 +28,9 @@ def euler_wray_agarwal_residual(part, Q, nu=1.5e-5, out=None):
     # cell_gradient(part, u): the tuple form, one sweep per field for all dimensions
     gu = [list(B.cell_gradient(part, vel[i])) for i in range(nd)]
     S = T.shear_rate(gu)
-    gR = torch.stack(B.cell_gradient(part, R), dim=0).T
-    gS = torch.stack(B.cell_gradient(part, S), dim=0).T
+    gR = B.cell_gradient_array(part, R)      # (nc, nd): the buffer of the tuple form, no copies
+    gS = B.cell_gradient_array(part, S)
     wa = T.Wray_Agarwal(R, S, gR, gS)
-    rt = wa["S"].clone()
-    for d in range(nd):
-        conv = B.at_faces(part, vel[d] * R, d + 1)
-        diff = B.at_faces(part, float(nu) + wa["nuR"], d + 1) * B.face_gradient(part, R, d + 1)
-        rt += B.green_gauss(part, diff - conv, d + 1)
-    r[:, nvp] = rt
+    # S + sum_d green_gauss(at_faces(nu + nuR) .* face_gradient(R) .- at_faces(u_d .* R)) in one launch, straight into r
+    r[:, nvp] = T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"])
     return r

@@ -177,6 +177,53 @@ __global__ void k_wale(int64_t n, const float* __restrict__ Delta, GradPtrs G, f
     }
 }
 
+// ---- transport of a scalar with variable diffusivity, all dimensions in one launch (thread per cell, face lists):
+//   out = S + sum_d green_gauss(at_faces(nu + nuR, d) .* face_gradient(R, d) .- at_faces(vel_d .* R, d), d)
+// the composition of closures.euler_wray_agarwal_residual (turbulence.jl:222-241 closes it) operation by operation -- same
+// expressions, same order as the operator kernels of ibh_ops.hip (-ffp-contract=off), so the result is theirs bit for bit;
+// a face's flux is evaluated by both of its cells instead of being written and read back.
+struct TransportDims {
+    DimData d[IBH_MAXD];
+    const float* h[IBH_MAXD];
+    const float* vel[IBH_MAXD];
+};
+__device__ __forceinline__ float tr_face_avg(float uo, float un, float ho, float hn) { return (uo * hn + un * ho) / (hn + ho); }
+__device__ __forceinline__ float tr_flux(const DimData& D, const float* __restrict__ h, const float* __restrict__ R,
+                                         const float* __restrict__ nuR, const float* __restrict__ vel, float nu, int32_t f) {
+    const int32_t o = D.owners[f], n = D.neighbors[f];
+    const float ho = h[o], hn = h[n];
+    const float Ro = R[o], Rn = R[n];
+    const float conv = tr_face_avg(vel[o] * Ro, vel[n] * Rn, ho, hn);       // at_faces(vel_d .* R)
+    const float nuf = tr_face_avg(nu + nuR[o], nu + nuR[n], ho, hn);        // at_faces(nu .+ nuR)
+    const float fd = (ho + hn) / 2.0f;                                      // face_distance
+    const float fg = (Rn - Ro) / fd;                                        // face_gradient(R)
+    return nuf * fg - conv;
+}
+__device__ __forceinline__ float tr_mean(const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int32_t c,
+                                         const DimData& D, const float* __restrict__ h, const float* __restrict__ R,
+                                         const float* __restrict__ nuR, const float* __restrict__ vel, float nu) {
+    const int32_t b = off[c], e = off[c + 1];
+    if (e == b) return 0.0f;
+    const float w = 1.0f / (float)(e - b);
+    float s = tr_flux(D, h, R, nuR, vel, nu, idx[b]) * w;
+    for (int32_t k = b + 1; k < e; ++k) s = s + tr_flux(D, h, R, nuR, vel, nu, idx[k]) * w;
+    return s;
+}
+template <int ND>
+__global__ void k_scalar_transport(int32_t nc, TransportDims T, const float* __restrict__ R, const float* __restrict__ nuR,
+                                   float nu, const float* __restrict__ S, float* __restrict__ out) {
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        float rt = S[c];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const float ar = tr_mean(T.d[d].roff, T.d[d].ridx, (int32_t)c, T.d[d], T.h[d], R, nuR, T.vel[d], nu);
+            const float al = tr_mean(T.d[d].loff, T.d[d].lidx, (int32_t)c, T.d[d], T.h[d], R, nuR, T.vel[d], nu);
+            rt = rt + (ar - al) / T.h[d][c];
+        }
+        out[c] = rt;
+    }
+}
+
 inline int tgrid(int64_t n) {
     int g = ibh_grid(n, TB);
     return g > 4096 ? 4096 : g;
@@ -253,6 +300,23 @@ int ibh_turb_wray_agarwal(int nd, int64_t n, const float* R, const float* S, con
     else
         hipLaunchKernelGGL(k_wray_agarwal<3>, dim3(tgrid(n)), dim3(TB), 0, ibh_stream, n, R, S, gradR, ldr, gradS, lds, sigmaR,
                            C1, kappa, nut, nuR, Sout);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_scalar_transport(const ibh_part* p, const float* R, const float* nuR, float nu, const float* vel, int64_t ldv,
+                         const float* S, float* out) {
+    IBH_REQUIRE(p && R && nuR && vel && S && out && (p->nd == 2 || p->nd == 3), "ibh_scalar_transport: bad argument");
+    if (p->nc == 0) return 0;
+    TransportDims T;
+    for (int d = 0; d < p->nd; ++d) {
+        T.d[d] = p->dim[d];
+        T.h[d] = p->spacing + (int64_t)d * p->nc;
+        T.vel[d] = vel + (int64_t)d * ldv;
+    }
+    if (p->nd == 2)
+        hipLaunchKernelGGL(k_scalar_transport<2>, dim3(tgrid(p->nc)), dim3(TB), 0, ibh_stream, p->nc, T, R, nuR, nu, S, out);
+    else
+        hipLaunchKernelGGL(k_scalar_transport<3>, dim3(tgrid(p->nc)), dim3(TB), 0, ibh_stream, p->nc, T, R, nuR, nu, S, out);
     IBH_LAUNCH_CHECK();
     return 0;
 }

@@ -376,6 +376,13 @@ int ibh_turb_wray_agarwal(int nd, int64_t n, const float* R, const float* S, con
                           const float* gradS, int64_t lds, float sigmaR, float C1, float kappa, float* nut, float* nuR,
                           float* Sout);
 /* Ducros_sensor :252-282; WALE_nuSGS :291-337 (3-D only) */
+/* transport of a scalar with variable diffusivity, all dimensions in one launch:
+ *   out = S + sum_d green_gauss(at_faces(nu + nuR, d) .* face_gradient(R, d) .- at_faces(vel[:, d] .* R, d), d)
+ * (the right-hand side a one-equation turbulence model such as Wray_Agarwal, turbulence.jl:222-241, is closed with):
+ * the operator composition of ImmersedBoundary.jl:899-943, 1039-1043 evaluated face by face, bit-identical to calling the
+ * operators one after the other. */
+int ibh_scalar_transport(const ibh_part*, const float* R, const float* nuR, float nu, const float* vel, int64_t ldv,
+                         const float* S, float* out);
 int ibh_turb_ducros(int nd, int64_t n, const float* const* g, float* out);
 int ibh_turb_wale(int64_t n, const float* Delta, const float* const* g, float Cw, float* out);
 

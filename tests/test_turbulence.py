@@ -87,3 +87,31 @@ def test_gpu_wall_function_matches_oracle():
     gw3, ow3 = gt.wall_function(ibamd.hip(y), ibamd.hip(u), ibamd.hip(nu)), ot.wall_function(y, u, nu)
     for key in ow3:
         assert rel_inf(ibamd.to_host(gw3[key]), ow3[key]) <= 2e-5, key
+
+
+@pytest.mark.gpu
+def test_scalar_transport_is_the_operator_composition(rae_domains):
+    """``ibh_scalar_transport`` -- S + sum_d green_gauss(at_faces(nu + nuR) .* face_gradient(R) .- at_faces(u_d .* R)) in
+    one launch -- against the same expression composed from the operator kernels (2-D partitions with skirts; the 3-D
+    case is tests/test_config5.py through the closure): bit for bit."""
+    import torch
+    import ibamd
+    from ibamd import turbulence as T
+    dp, _ = rae_domains
+    rng = np.random.default_rng(4)
+    for k in (1, 3):
+        part = dp.partitions[k]
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        nc = part.centers.shape[0]
+        R = ibamd.hip((4.5e-5 * (1 + 0.5 * rng.uniform(0, 1, nc))).astype(f32))
+        nuR = ibamd.hip((1e-5 * rng.uniform(0.5, 2, nc)).astype(f32))
+        S = ibamd.hip(rng.uniform(-1, 1, nc).astype(f32))
+        vel = ibamd.hip(np.stack([100 * (1 + 0.1 * rng.uniform(-1, 1, nc)), 10 * rng.uniform(-1, 1, nc)], axis=1).astype(f32))
+        nu = 1.5e-5
+        got = T.scalar_transport(dpart, R, nuR, vel, nu, S)
+        rt = S.clone()
+        for d in range(2):
+            conv = ibamd.at_faces(dpart, vel[:, d].contiguous() * R, d + 1)
+            diff = ibamd.at_faces(dpart, float(nu) + nuR, d + 1) * ibamd.face_gradient(dpart, R, d + 1)
+            rt += ibamd.green_gauss(dpart, diff - conv, d + 1)
+        assert torch.equal(got, rt)
