@@ -49,6 +49,7 @@ _SIGS = {
     "ibh_at_faces": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_green_gauss": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64, c_int],
     "ibh_cell_gradient": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_cell_gradient_all": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_cell_gradient_nd": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64],
     "ibh_face_distance": [c_vp, c_int, c_vp],
     "ibh_owner_distance": [c_vp, c_int, c_vp],
@@ -59,6 +60,7 @@ _SIGS = {
     "ibh_acc_create": [C.POINTER(c_vp), C.c_int32, C.c_int32, c_vp, c_vp, c_vp, c_int],
     "ibh_acc_destroy": [c_vp],
     "ibh_accumulate": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64],
+    "ibh_accumulate_diff_add": [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_bc_create": [C.POINTER(c_vp), C.c_int32, c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_int],
     "ibh_bc_destroy": [c_vp],
     "ibh_bc_interp": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64],

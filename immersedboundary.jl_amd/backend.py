@@ -273,6 +273,18 @@ class DeviceAccumulator:
         call("ibh_accumulate", self.handle, _ptr(v), nv, ld, _ptr(out), self.n_output)
         return out
 
+    def diff_add(self, out, a, b):
+        """``out .+= acc(a .- b)`` in one launch (``ibh_accumulate_diff_add``); same arithmetic as the separate operations."""
+        a, nv, ld = _field(a, self.n_input)
+        b, nvb, ldb = _field(b, self.n_input)
+        o, nvo, ldo = _field_inplace(out, self.n_output, "out")
+        if nvb != nv or nvo != nv or ldb != ld:
+            out += self(a - b)
+            return out
+        _stream()
+        call("ibh_accumulate_diff_add", self.handle, _ptr(a), _ptr(b), nv, ld, _ptr(o), ldo)
+        return out
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
@@ -483,8 +495,8 @@ def cell_gradient(part, u, dim=None):
         u, nv, ld = _field(u, part.nc)
         nd, nc = part.nd, part.nc
         _stream()
-        if nv == 1:
-            # gradients + sensor back to back: the kernel writes them in place (no copy out of a workspace)
+        if nv == 1 and part.info["full_blocks"] > 0:
+            # gradients + sensor back to back: the block sweep writes them in place (no copy out of a workspace)
             buf = colmajor_empty(nc, nd + 1)
             call("ibh_cell_gradient_nd", part.handle, _ptr(u), 1, ld, _ptr(buf), nc, c_vp(buf.data_ptr() + 4 * nd * nc), nc)
         else:

@@ -32,5 +32,5 @@ def euler_wray_agarwal_residual(part, Q, nu=1.5e-5, out=None):
     gS = B.cell_gradient_array(part, S)
     wa = T.Wray_Agarwal(R, S, gR, gS)
     # S + sum_d green_gauss(at_faces(nu + nuR) .* face_gradient(R) .- at_faces(u_d .* R)) in one launch, straight into r
-    r[:, nvp] = T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"])
+    T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"], out=r[:, nvp])
     return r

@@ -1406,10 +1406,9 @@ int ibh_cell_gradient_nd(ibh_part* p, const float* u, int nv, int64_t ldu, float
     const int nd = p->nd;
     const bool blocks = p->bs == 8 && p->nblk > 0 && (nd == 2 ? p->blocks2 != nullptr : p->blocks3 != nullptr);
     if (!blocks) {
-        for (int d = 0; d < nd; ++d) {
-            int rc = ibh_cell_gradient(p, d + 1, u, nv, ldu, out + (size_t)d * nv * ldo, ldo);
-            if (rc) return rc;
-        }
+        // no block structure (e.g. the coarse levels of multigrid()): every dimension in one face-list launch
+        const int rc = ibh_cell_gradient_all(p, u, nv, ldu, out, ldo);
+        if (rc) return rc;
         if (sensor) return ibh_jst_sensor(p, 0, u, nv, ldu, sensor, lds);
         return 0;
     }

@@ -110,6 +110,27 @@ __device__ __forceinline__ float csr_mean_face_avg(const int32_t* __restrict__ o
     return s;
 }
 
+// cell_gradient(part, u), the tuple form, on partitions without the block structure: all dimensions in one launch
+// (thread per cell and field; out[(d * nv + v) * ldo + c], the layout of ibh_cell_gradient_nd)
+struct GradDims {
+    DimData d[IBH_MAXD];
+    const float* h[IBH_MAXD];
+};
+template <int ND>
+__global__ void k_cell_gradient_all(int32_t nc, GradDims G, const float* __restrict__ u, int64_t ldu, int nv,
+                                    float* __restrict__ out, int64_t ldo) {
+    const int64_t v = blockIdx.y;
+    const float* uv = u + v * ldu;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const float ar = csr_mean_face_avg(G.d[d].roff, G.d[d].ridx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], uv);
+            const float al = csr_mean_face_avg(G.d[d].loff, G.d[d].lidx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], uv);
+            out[c + ((int64_t)d * nv + v) * ldo] = (ar - al) / G.h[d][c];
+        }
+    }
+}
+
 __global__ void k_cell_gradient(int32_t nc, DimData D, const float* __restrict__ h, const float* __restrict__ u,
                                 int64_t ldu, float* __restrict__ out, int64_t ldo) {
     int64_t v = blockIdx.y;
@@ -222,13 +243,16 @@ __global__ void k_accumulate(int32_t n_out, const int32_t* __restrict__ off, con
 
 // The same for several fields at once: one thread per row, the row's indices and weights read once for up to NVB
 // fields (the per-(row, field) form reads them once per field).  Same sum order per field.
-template <int NVB>
+// v2 (optional): the stencil is applied to v - v2 (elementwise difference first, like `acc(a .- b)`); ADD: out .+= result
+template <int NVB, bool ADD = false>
 __global__ void k_accumulate_rows(int32_t n_out, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
                                   const float* __restrict__ w, const int32_t* __restrict__ remap,
-                                  const float* __restrict__ v, int64_t ldv, float* __restrict__ out, int64_t ldo, int nv) {
+                                  const float* __restrict__ v, int64_t ldv, float* __restrict__ out, int64_t ldo, int nv,
+                                  const float* __restrict__ v2 = nullptr) {
     const int v0 = blockIdx.y * NVB;
     const int nb = min(NVB, nv - v0);
     const float* vv = v + (int64_t)v0 * ldv;
+    const float* vv2 = v2 ? v2 + (int64_t)v0 * ldv : nullptr;
     float* oo = out + (int64_t)v0 * ldo;
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
         const int32_t b = off[r], e = off[r + 1];
@@ -242,7 +266,8 @@ __global__ void k_accumulate_rows(int32_t n_out, const int32_t* __restrict__ off
 #pragma unroll
             for (int q = 0; q < NVB; ++q) {
                 if (q < nb) {
-                    const float x = vv[j + (int64_t)q * ldv];
+                    float x = vv[j + (int64_t)q * ldv];
+                    if (vv2) x = x - vv2[j + (int64_t)q * ldv];
                     const float t = w ? x * wk : x;
                     s[q] = (k == b) ? t : s[q] + t;
                 }
@@ -250,7 +275,7 @@ __global__ void k_accumulate_rows(int32_t n_out, const int32_t* __restrict__ off
         }
 #pragma unroll
         for (int q = 0; q < NVB; ++q)
-            if (q < nb) oo[r + (int64_t)q * ldo] = s[q];
+            if (q < nb) oo[r + (int64_t)q * ldo] = ADD ? oo[r + (int64_t)q * ldo] + s[q] : s[q];
     }
 }
 
@@ -304,10 +329,15 @@ static inline void launch_accumulate(int32_t n_out, const int32_t* off, const in
     if (nv == 1) {
         hipLaunchKernelGGL(k_accumulate, grid2(n_out, 1), dim3(OPS_BLOCK), 0, ibh_stream, n_out, off, idx, w, remap, v, ldv,
                            out, ldo);
+    } else if (nv > 4 && nv <= 8) {
+        // 5..8 fields (a state vector): indices and weights read ONCE for all of them (2.0 -> 1.3 ms per application of the
+        // transfer operators of a 33.6 M-cell level to 6 fields)
+        hipLaunchKernelGGL(k_accumulate_rows<8>, grid2(n_out, 1), dim3(OPS_BLOCK), 0, ibh_stream, n_out, off, idx, w, remap, v,
+                           ldv, out, ldo, nv, (const float*)nullptr);
     } else {
         dim3 g = grid2(n_out, (nv + 3) / 4);
         hipLaunchKernelGGL(k_accumulate_rows<4>, g, dim3(OPS_BLOCK), 0, ibh_stream, n_out, off, idx, w, remap, v, ldv, out,
-                           ldo, nv);
+                           ldo, nv, (const float*)nullptr);
     }
 }
 
@@ -374,6 +404,23 @@ int ibh_green_gauss(const ibh_part* p, int dim, const float* uf, int nv, int64_t
     return 0;
 }
 
+int ibh_cell_gradient_all(const ibh_part* p, const float* u, int nv, int64_t ldu, float* out, int64_t ldo) {
+    IBH_REQUIRE(p && u && out && (p->nd == 2 || p->nd == 3), "ibh_cell_gradient_all: bad argument");
+    CHECK_NV(nv);
+    if (p->nc == 0) return 0;
+    GradDims G;
+    for (int d = 0; d < p->nd; ++d) {
+        G.d[d] = p->dim[d];
+        G.h[d] = p->spacing + (int64_t)d * p->nc;
+    }
+    if (p->nd == 2)
+        hipLaunchKernelGGL(k_cell_gradient_all<2>, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, u, ldu, nv, out, ldo);
+    else
+        hipLaunchKernelGGL(k_cell_gradient_all<3>, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, u, ldu, nv, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
 int ibh_cell_gradient(const ibh_part* p, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo) {
     CHECK_DIM(p, dim);
     CHECK_NV(nv);
@@ -435,6 +482,21 @@ int ibh_accumulate(const ibh_acc* a, const float* v, int nv, int64_t ldv, float*
     CHECK_NV(nv);
     if (a->n_out == 0) return 0;
     launch_accumulate(a->n_out, a->off, a->idx, a->w, (const int32_t*)nullptr, v, ldv, out, ldo, nv);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_accumulate_diff_add(const ibh_acc* a, const float* v, const float* v2, int nv, int64_t ldv, float* out,
+                            int64_t ldo) {
+    IBH_REQUIRE(a && v && v2 && out, "ibh_accumulate_diff_add: null argument");
+    CHECK_NV(nv);
+    if (a->n_out == 0) return 0;
+    for (int v0 = 0; v0 < nv; v0 += 8) {
+        const int nb = nv - v0 < 8 ? nv - v0 : 8;
+        hipLaunchKernelGGL((k_accumulate_rows<8, true>), grid2(a->n_out, 1), dim3(OPS_BLOCK), 0, ibh_stream, a->n_out, a->off,
+                           a->idx, a->w, (const int32_t*)nullptr, v + (int64_t)v0 * ldv, ldv, out + (int64_t)v0 * ldo, ldo,
+                           nb, v2 + (int64_t)v0 * ldv);
+    }
     IBH_LAUNCH_CHECK();
     return 0;
 }

@@ -83,7 +83,7 @@ def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level
             multigrid_level=multigrid_level + 1, n_iter=n_iter, atol=atol, rtol=rtol, norm=norm,
             check_every=check_every, exchange=exchange, level_norm=level_norm)
         xch(l + 1, Qc)
-        Q += prolong(Qc - Qcold)
+        prolong.diff_add(Q, Qc, Qcold)       # Q .+= prolong(Qc .- Qcold), one launch
     check_every = max(1, int(check_every))
     for it in range(n_iter):
         xch(l, Q)

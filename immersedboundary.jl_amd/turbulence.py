@@ -104,7 +104,7 @@ def Wray_Agarwal(R, S, gradR, gradS, sigmaR=0.72, C1=0.0829, kappa=0.41):
     return dict(zip(("nut", "nuR", "S"), out))
 
 
-def scalar_transport(part, R, nuR, vel, nu, S):
+def scalar_transport(part, R, nuR, vel, nu, S, out=None):
     """``S + sum_d green_gauss(part, at_faces(part, nu .+ nuR, d) .* face_gradient(part, R, d) .- at_faces(part, vel[:, d] .* R, d), d)``
     in one launch (``ibh_scalar_transport``): the transport terms of a one-equation turbulence model, bit-identical to the
     operator-by-operator composition."""
@@ -115,7 +115,12 @@ def scalar_transport(part, R, nuR, vel, nu, S):
     v, nd, ldv = B._field(vel, part.nc)
     if nd != part.nd:
         raise ValueError("vel must be (nc, nd)")
-    out = B.colmajor_empty(part.nc)
+    if out is None:
+        out = B.colmajor_empty(part.nc)
+    else:
+        out, nvo, _ = B._field_inplace(out, part.nc, "out")
+        if nvo != 1:
+            raise ValueError("out must be a vector")
     B._stream()
     B.call("ibh_scalar_transport", part.handle, B._ptr(R), B._ptr(nuR), _f(nu), B._ptr(v), ldv, B._ptr(S), B._ptr(out))
     return out

@@ -162,6 +162,9 @@ int ibh_at_faces(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, 
 int ibh_green_gauss(const ibh_part*, int dim, const float* uf, int nv, int64_t ldf, float* out, int64_t ldo,
                     int unsigned_sum);                                                                         /* :918, :934 */
 int ibh_cell_gradient(const ibh_part*, int dim, const float* u, int nv, int64_t ldu, float* out, int64_t ldo); /* :965 */
+/* every dimension in one face-list launch: out[(d * nv + v) * ldo + c] (what ibh_cell_gradient_nd calls on partitions
+ * without the block structure) */
+int ibh_cell_gradient_all(const ibh_part*, const float* u, int nv, int64_t ldu, float* out, int64_t ldo);
 /* cell_gradient(part, u): the tuple form, src/ImmersedBoundary.jl:980-988 -- all dimensions in one sweep per field:
  * out (nc, nd*nv), gradient of field v along dimension d in column d*nv + v; sensor (nc, nv) or NULL: JST_sensor(part, u)
  * (:1077-1097, dim = 0) of every field for free.  Block-structured partitions: pass A of the two-kernel sweeps (tuned
@@ -186,6 +189,9 @@ int ibh_acc_create(ibh_acc** out, int32_t n_output, int32_t n_input,
                    const int32_t* off, const int32_t* idx, const float* w, int index_base);
 int ibh_acc_destroy(ibh_acc*);
 int ibh_accumulate(const ibh_acc*, const float* v, int nv, int64_t ldv, float* out, int64_t ldo);
+/* out .+= acc(v .- v2) in one launch (the prolongation step of FAS!, solver.jl:76: Q .+= prolong(Qc .- Qcold)); same
+ * arithmetic as the three separate operations */
+int ibh_accumulate_diff_add(const ibh_acc*, const float* v, const float* v2, int nv, int64_t ldv, float* out, int64_t ldo);
 
 /* ---- ghost-cell BC: impose_bc! (ImmersedBoundary.jl:1197-1247) ----------------
  * Boundary data: ghost ids (global rows of `a`), image-point interpolator
