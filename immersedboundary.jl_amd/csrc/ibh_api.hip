@@ -220,6 +220,30 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         if ((rc = ibh_upload(&D.roff, v.roff[d].data(), v.roff[d].size()))) return rc;
         if ((rc = ibh_upload(&D.ridx, v.ridx[d].data(), v.ridx[d].size()))) return rc;
     }
+    {
+        std::vector<int32_t> side((size_t)2 * nd * nc);
+        int64_t direct = 0;
+        for (int d = 0; d < nd; ++d)
+            for (int s = 0; s < 2; ++s) {
+                const std::vector<int32_t>& off = s ? v.roff[d] : v.loff[d];
+                const std::vector<int32_t>& idx = s ? v.ridx[d] : v.lidx[d];
+                int32_t* T = side.data() + (size_t)(2 * d + s) * nc;
+                for (int32_t c = 0; c < nc; ++c) {
+                    const int32_t b = off[c], e = off[c + 1];
+                    int32_t t = -1;
+                    if (e == b) t = -2;
+                    else if (e == b + 1) {
+                        const int32_t f = idx[b];
+                        const int32_t o = v.owners[d][f], n = v.neighbors[d][f];
+                        if (s ? (o == c) : (n == c)) t = s ? n : o;      // right faces: c owns; left faces: c is the neighbour
+                    }
+                    T[c] = t;
+                    direct += t >= 0;
+                }
+            }
+        if ((rc = ibh_upload(&p->side, side.data(), side.size()))) return rc;
+        p->info[17] = direct;
+    }
     p->n_image = n_image;
     if (n_image > 0 && image_in_domain) {
         std::vector<int32_t> iid = rebased(image_in_domain, n_image, index_base);
@@ -411,6 +435,7 @@ int ibh_partition_destroy(ibh_part* p) {
         hipFree(D.loff); hipFree(D.lidx); hipFree(D.roff); hipFree(D.ridx);
     }
     hipFree(p->image_in_domain);
+    hipFree(p->side);
     hipFree(p->blocks2);
     hipFree(p->htab);
     hipFree(p->etab);

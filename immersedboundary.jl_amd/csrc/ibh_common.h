@@ -86,6 +86,10 @@ struct ibh_part {
     float* spacing = nullptr;  // (nc, nd) column-major
     float* centers = nullptr;  // (nc, nd) or null
     DimData dim[IBH_MAXD];
+    // side table [2 * nd][nc]: entry (2 d + s, c) = the cell across the ONE face cell c has on its left (s = 0) / right
+    // (s = 1) in dimension d; -2 = no face on that side, -1 = anything else (several faces, a face that does not list c
+    // where the CSR says): the face-list kernels take the direct form for entries >= 0 and the CSR walk otherwise
+    int32_t* side = nullptr;
     int32_t n_image = 0;
     int32_t* image_in_domain = nullptr;
     // block-structured fast path

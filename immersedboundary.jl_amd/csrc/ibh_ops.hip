@@ -112,9 +112,12 @@ __device__ __forceinline__ float csr_mean_face_avg(const int32_t* __restrict__ o
 
 // cell_gradient(part, u), the tuple form, on partitions without the block structure: all dimensions in one launch
 // (thread per cell and field; out[(d * nv + v) * ldo + c], the layout of ibh_cell_gradient_nd)
+// Sides with ONE face (side table of the partition, ibh_common.h) are evaluated directly from the cell across -- the same
+// expression the CSR walk evaluates for its single entry (weight 1.0f) -- the others walk the lists.
 struct GradDims {
     DimData d[IBH_MAXD];
     const float* h[IBH_MAXD];
+    const int32_t* side;
 };
 template <int ND>
 __global__ void k_cell_gradient_all(int32_t nc, GradDims G, const float* __restrict__ u, int64_t ldu, int nv,
@@ -122,11 +125,22 @@ __global__ void k_cell_gradient_all(int32_t nc, GradDims G, const float* __restr
     const int64_t v = blockIdx.y;
     const float* uv = u + v * ldu;
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        int32_t sd[2 * ND];
+#pragma unroll
+        for (int s = 0; s < 2 * ND; ++s) sd[s] = G.side[(int64_t)s * nc + c];
+        const float uc = uv[c];
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const float ar = csr_mean_face_avg(G.d[d].roff, G.d[d].ridx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], uv);
-            const float al = csr_mean_face_avg(G.d[d].loff, G.d[d].lidx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], uv);
-            out[c + ((int64_t)d * nv + v) * ldo] = (ar - al) / G.h[d][c];
+            const float hc = G.h[d][c];
+            const int32_t l = sd[2 * d], r = sd[2 * d + 1];
+            float ar, al;
+            if (r >= 0) ar = face_avg(uc, uv[r], hc, G.h[d][r]) * 1.0f;
+            else if (r == -2) ar = 0.0f;
+            else ar = csr_mean_face_avg(G.d[d].roff, G.d[d].ridx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], uv);
+            if (l >= 0) al = face_avg(uv[l], uc, G.h[d][l], hc) * 1.0f;
+            else if (l == -2) al = 0.0f;
+            else al = csr_mean_face_avg(G.d[d].loff, G.d[d].lidx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], uv);
+            out[c + ((int64_t)d * nv + v) * ldo] = (ar - al) / hc;
         }
     }
 }
@@ -259,7 +273,43 @@ __global__ void k_accumulate_rows(int32_t n_out, const int32_t* __restrict__ off
         float s[NVB];
 #pragma unroll
         for (int q = 0; q < NVB; ++q) s[q] = 0.0f;
-        for (int32_t k = b; k < e; ++k) {
+        int32_t k = b;
+        // rows that start on a 16-byte boundary (the 2^nd-point transfer operators: every row) take their entries four
+        // at a time: one dwordx4 of indices, one of weights, the gathers of the four entries in flight together; the
+        // sum keeps the entry order
+        if ((b & 3) == 0 && w)
+            for (; k + 4 <= e; k += 4) {
+                const int4 j4 = *reinterpret_cast<const int4*>(idx + k);
+                const float4 w4 = *reinterpret_cast<const float4*>(w + k);
+                int32_t jj[4] = {j4.x, j4.y, j4.z, j4.w};
+                const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                if (remap) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) jj[i] = remap[jj[i]];
+                }
+                float x[4][NVB];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < NVB; ++q)
+                        if (q < nb) x[i][q] = vv[jj[i] + (int64_t)q * ldv];
+                if (vv2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < NVB; ++q)
+                            if (q < nb) x[i][q] = x[i][q] - vv2[jj[i] + (int64_t)q * ldv];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < NVB; ++q)
+                        if (q < nb) {
+                            const float t = x[i][q] * ww[i];
+                            s[q] = (k + i == b) ? t : s[q] + t;
+                        }
+            }
+        for (; k < e; ++k) {
             int32_t j = idx[k];
             if (remap) j = remap[j];
             const float wk = w ? w[k] : 1.0f;
@@ -413,6 +463,7 @@ int ibh_cell_gradient_all(const ibh_part* p, const float* u, int nv, int64_t ldu
         G.d[d] = p->dim[d];
         G.h[d] = p->spacing + (int64_t)d * p->nc;
     }
+    G.side = p->side;
     if (p->nd == 2)
         hipLaunchKernelGGL(k_cell_gradient_all<2>, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, u, ldu, nv, out, ldo);
     else

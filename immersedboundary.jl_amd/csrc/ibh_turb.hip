@@ -186,11 +186,11 @@ struct TransportDims {
     DimData d[IBH_MAXD];
     const float* h[IBH_MAXD];
     const float* vel[IBH_MAXD];
+    const int32_t* side;      // side table of the partition: sides with one face are evaluated from the cell across
 };
 __device__ __forceinline__ float tr_face_avg(float uo, float un, float ho, float hn) { return (uo * hn + un * ho) / (hn + ho); }
-__device__ __forceinline__ float tr_flux(const DimData& D, const float* __restrict__ h, const float* __restrict__ R,
-                                         const float* __restrict__ nuR, const float* __restrict__ vel, float nu, int32_t f) {
-    const int32_t o = D.owners[f], n = D.neighbors[f];
+__device__ __forceinline__ float tr_flux_on(int32_t o, int32_t n, const float* __restrict__ h, const float* __restrict__ R,
+                                            const float* __restrict__ nuR, const float* __restrict__ vel, float nu) {
     const float ho = h[o], hn = h[n];
     const float Ro = R[o], Rn = R[n];
     const float conv = tr_face_avg(vel[o] * Ro, vel[n] * Rn, ho, hn);       // at_faces(vel_d .* R)
@@ -198,6 +198,10 @@ __device__ __forceinline__ float tr_flux(const DimData& D, const float* __restri
     const float fd = (ho + hn) / 2.0f;                                      // face_distance
     const float fg = (Rn - Ro) / fd;                                        // face_gradient(R)
     return nuf * fg - conv;
+}
+__device__ __forceinline__ float tr_flux(const DimData& D, const float* __restrict__ h, const float* __restrict__ R,
+                                         const float* __restrict__ nuR, const float* __restrict__ vel, float nu, int32_t f) {
+    return tr_flux_on(D.owners[f], D.neighbors[f], h, R, nuR, vel, nu);
 }
 __device__ __forceinline__ float tr_mean(const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int32_t c,
                                          const DimData& D, const float* __restrict__ h, const float* __restrict__ R,
@@ -214,10 +218,19 @@ __global__ void k_scalar_transport(int32_t nc, TransportDims T, const float* __r
                                    float nu, const float* __restrict__ S, float* __restrict__ out) {
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         float rt = S[c];
+        int32_t sd[2 * ND];
+#pragma unroll
+        for (int s = 0; s < 2 * ND; ++s) sd[s] = T.side[(int64_t)s * nc + c];
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const float ar = tr_mean(T.d[d].roff, T.d[d].ridx, (int32_t)c, T.d[d], T.h[d], R, nuR, T.vel[d], nu);
-            const float al = tr_mean(T.d[d].loff, T.d[d].lidx, (int32_t)c, T.d[d], T.h[d], R, nuR, T.vel[d], nu);
+            const int32_t l = sd[2 * d], r = sd[2 * d + 1];
+            float ar, al;
+            if (r >= 0) ar = tr_flux_on((int32_t)c, r, T.h[d], R, nuR, T.vel[d], nu) * 1.0f;
+            else if (r == -2) ar = 0.0f;
+            else ar = tr_mean(T.d[d].roff, T.d[d].ridx, (int32_t)c, T.d[d], T.h[d], R, nuR, T.vel[d], nu);
+            if (l >= 0) al = tr_flux_on(l, (int32_t)c, T.h[d], R, nuR, T.vel[d], nu) * 1.0f;
+            else if (l == -2) al = 0.0f;
+            else al = tr_mean(T.d[d].loff, T.d[d].lidx, (int32_t)c, T.d[d], T.h[d], R, nuR, T.vel[d], nu);
             rt = rt + (ar - al) / T.h[d][c];
         }
         out[c] = rt;
@@ -313,6 +326,7 @@ int ibh_scalar_transport(const ibh_part* p, const float* R, const float* nuR, fl
         T.h[d] = p->spacing + (int64_t)d * p->nc;
         T.vel[d] = vel + (int64_t)d * ldv;
     }
+    T.side = p->side;
     if (p->nd == 2)
         hipLaunchKernelGGL(k_scalar_transport<2>, dim3(tgrid(p->nc)), dim3(TB), 0, ibh_stream, p->nc, T, R, nuR, nu, S, out);
     else
