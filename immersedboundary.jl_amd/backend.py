@@ -778,3 +778,48 @@ def impose_bc(f, dom, bname, *args, conv_to_backend=None, conv_from_backend=None
         for h, (a, _, _) in zip(host_args, fields):
             if not on_device(h):
                 h[...] = conv_from_backend(a)
+
+
+class GraphedClosure:
+    """A user closure at operator granularity captured ONCE in a HIP graph and replayed.
+
+    The reference calls ``f(part, args...)`` once per partition and per iteration (ImmersedBoundary.jl:848-850); every
+    operator and broadcast of such a closure is a kernel launch here, a few microseconds of GPU work behind tens of
+    microseconds of host work each.  The launches of one call are fixed (same partition, same arrays), so they are
+    recorded on a capture stream -- every libibhip launch goes to ``ibh_set_stream(current stream)``, temporaries come
+    from the graph's private pool -- and ``g()`` replays them as one graph launch: the arrays are read and written in
+    place, so new contents of the same arrays are what a replay sees.
+
+    ``GraphedClosure(f, part, u, ud, C)`` runs ``f`` ``warmup`` times eagerly first (library workspaces are allocated on
+    first use and nothing may be allocated during capture); the contents of the array arguments are saved before and
+    restored after, so constructing it does not change them.  The closure must not read values back to the host
+    (``.item()``, ``to_host``): that cannot be captured and raises.
+    """
+
+    def __init__(self, f, *args, warmup=2, **kwargs):
+        from .hiparray import HipArray
+        tens = [a.t if isinstance(a, HipArray) else a for a in args]
+        tens = [t for t in tens if isinstance(t, torch.Tensor) and t.is_cuda]
+        saved = [t.clone() for t in tens]
+        self._keep = (f, args, kwargs)
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(1, int(warmup))):
+                f(*args, **kwargs)
+            for t, s in zip(tens, saved):
+                t.copy_(s)
+        self.stream.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.result = f(*args, **kwargs)
+            for a in args:                      # pending broadcasts of the arguments belong to the call
+                if isinstance(a, HipArray):
+                    a.t
+            if isinstance(self.result, HipArray):
+                self.result.t
+        _stream()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.result

@@ -32,7 +32,47 @@ struct PartView {
     int32_t nc;
     const float* spacing;
     DimData dim[IBH_MAXD];
+    const int32_t* side;  // side table (ibh_common.h): the cell across the one face of a side, -2 none, -1 walk the lists
 };
+
+// The faces of cell c on one side of dimension d.  A side with ONE face is taken from the side table -- the cell across,
+// no offsets / face ids / owner and neighbour lookups (four dependent loads become one) -- with the weight 1.0f / 1 the
+// walk would use; anything else walks the CSR lists.  Same faces, same order, same arithmetic.
+struct SideIter {
+    int32_t b, e, o, n;
+    const int32_t* idx;
+    bool direct;
+};
+__device__ __forceinline__ SideIter side_iter(const PartView& p, int d, int side, int32_t c) {
+    const DimData& dd = p.dim[d];
+    SideIter it;
+    it.idx = side ? dd.ridx : dd.lidx;
+    const int32_t t = p.side[(int64_t)(2 * d + side) * p.nc + c];
+    it.direct = t >= 0;
+    it.o = side ? c : t;
+    it.n = side ? t : c;
+    if (t >= 0) {
+        it.b = 0;
+        it.e = 1;
+    } else if (t == -2) {
+        it.b = it.e = 0;
+    } else {
+        const int32_t* off = side ? dd.roff : dd.loff;
+        it.b = off[c];
+        it.e = off[c + 1];
+    }
+    return it;
+}
+__device__ __forceinline__ void side_face(const DimData& dd, const SideIter& it, int32_t k, int32_t& o, int32_t& n) {
+    if (it.direct) {
+        o = it.o;
+        n = it.n;
+    } else {
+        const int32_t f = it.idx[k];
+        o = dd.owners[f];
+        n = dd.neighbors[f];
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // face-list bodies
@@ -53,11 +93,12 @@ __device__ __forceinline__ void passA_cell(const PartView& p, const float* __res
 #pragma unroll
         for (int v = 0; v < NV; ++v) sr[v] = sl[v] = 0.f;
         {
-            int32_t b = dd.roff[c], e = dd.roff[c + 1];
+            const SideIter it = side_iter(p, d, 1, c);
+            const int32_t b = it.b, e = it.e;
             float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
             for (int32_t k = b; k < e; ++k) {
-                int32_t f = dd.ridx[k];
-                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                int32_t o, n;
+                side_face(dd, it, k, o, n);
                 float ho = h[o], hn = h[n];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
@@ -74,11 +115,12 @@ __device__ __forceinline__ void passA_cell(const PartView& p, const float* __res
             }
         }
         {
-            int32_t b = dd.loff[c], e = dd.loff[c + 1];
+            const SideIter it = side_iter(p, d, 0, c);
+            const int32_t b = it.b, e = it.e;
             float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
             for (int32_t k = b; k < e; ++k) {
-                int32_t f = dd.lidx[k];
-                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                int32_t o, n;
+                side_face(dd, it, k, o, n);
                 float ho = h[o], hn = h[n];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
@@ -118,21 +160,23 @@ __device__ __forceinline__ void passB_adv_cell(const PartView& p, const float* _
         const float* Cd = C + (int64_t)d * ldc;
         float fr = 0.f, fl = 0.f;
         {
-            int32_t b = dd.roff[c], e = dd.roff[c + 1];
+            const SideIter it = side_iter(p, d, 1, c);
+            const int32_t b = it.b, e = it.e;
             float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
             for (int32_t k = b; k < e; ++k) {
-                int32_t f = dd.ridx[k];
-                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                int32_t o, n;
+                side_face(dd, it, k, o, n);
                 float t = adv_flux(u[o], u[n], g[o], g[n], Ds[o], Ds[n], Cd[o], Cd[n], h[o], h[n]) * w;
                 fr = (k == b) ? t : fr + t;
             }
         }
         {
-            int32_t b = dd.loff[c], e = dd.loff[c + 1];
+            const SideIter it = side_iter(p, d, 0, c);
+            const int32_t b = it.b, e = it.e;
             float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
             for (int32_t k = b; k < e; ++k) {
-                int32_t f = dd.lidx[k];
-                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                int32_t o, n;
+                side_face(dd, it, k, o, n);
                 float t = adv_flux(u[o], u[n], g[o], g[n], Ds[o], Ds[n], Cd[o], Cd[n], h[o], h[n]) * w;
                 fl = (k == b) ? t : fl + t;
             }
@@ -161,14 +205,13 @@ __device__ __forceinline__ void passB_euler_cell(const PartView& p, const float*
         for (int v = 0; v < NV; ++v) fr[v] = fl[v] = 0.0;
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
-            const int32_t* off = side ? dd.roff : dd.loff;
-            const int32_t* idx = side ? dd.ridx : dd.lidx;
             double* acc = side ? fr : fl;
-            int32_t b = off[c], e = off[c + 1];
+            const SideIter it = side_iter(p, d, side, c);
+            const int32_t b = it.b, e = it.e;
             float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
             for (int32_t k = b; k < e; ++k) {
-                int32_t f = idx[k];
-                int32_t o = dd.owners[f], n = dd.neighbors[f];
+                int32_t o, n;
+                side_face(dd, it, k, o, n);
                 float Po[NV], Pn[NV], dPo[NV], dPn[NV];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
@@ -1036,6 +1079,7 @@ PartView view(const ibh_part* p) {
     v.nc = p->nc;
     v.spacing = p->spacing;
     for (int d = 0; d < IBH_MAXD; ++d) v.dim[d] = p->dim[d];
+    v.side = p->side;
     return v;
 }
 

@@ -132,12 +132,13 @@ function _ew(op, a::HipArray, out::Union{HipArray, Nothing} = nothing)
     o
 end
 
-# recursive evaluation of a (possibly nested, `@.`-fused) Broadcasted tree; n-ary + and * fold left like Julia does
+# recursive evaluation of a (possibly nested, `@.`-fused) Broadcasted tree; n-ary + * max min fold left like Julia does
+# (`max.(a, b, 1f-7)` of the reference's MUSCL, src/ImmersedBoundary.jl:1113-1157)
 _eval(x) = x
 _eval(bc::Base.Broadcast.Broadcasted) = _node(bc.f, map(_eval, bc.args)...)
 _node(f, a) = a isa HipArray ? _ew(f, a) : f(a)
 _node(f, a, b) = _ew(f, a, b)
-_node(f::Union{typeof(+), typeof(*)}, a, b, c, rest...) = _node(f, _ew(f, a, b), c, rest...)
+_node(f::Union{typeof(+), typeof(*), typeof(max), typeof(min)}, a, b, c, rest...) = _node(f, _node(f, a, b), c, rest...)
 
 # ---- the whole (fused) Broadcasted tree as ONE launch: a postfix program for ibh_ew_eval (at most 48 instructions,
 # 8 arrays, 8 scalars, stack depth 8); n-ary + and * fold left like Julia does.  `nothing` = does not fit / unsupported
@@ -180,7 +181,7 @@ function _push!(P::_Prog, bc::Base.Broadcast.Broadcasted)
         push!(P.code, _unop[f])
         return d
     end
-    (haskey(_binop, f) && (length(args) == 2 || f === (+) || f === (*))) || return nothing
+    (haskey(_binop, f) && (length(args) == 2 || f === (+) || f === (*) || f === max || f === min)) || return nothing
     depth = _push!(P, args[1])
     isnothing(depth) && return nothing
     for a in args[2:end]
@@ -418,6 +419,13 @@ function to_backend(acc::Accumulator, ::Union{typeof(hip), HipConv})
     end
 end
 
+"`out .+= acc(a .- b)` in one launch (the prolongation step of `FAS!`, src/solver.jl:76)."
+function accumulate_diff_add!(out::HipArray, acc::HipAccumulator, a::HipArray, b::HipArray)
+    check(ccall((:ibh_accumulate_diff_add, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64),
+        acc.handle, a.ptr, b.ptr, nv(a), ld(a), out.ptr, ld(out)))
+    out
+end
 function (acc::HipAccumulator)(v::HipArray)
     out = out_like(v, acc.n_output)
     check(ccall((:ibh_accumulate, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64),
@@ -512,6 +520,56 @@ function residual_euler_hll!(R::HipArray, part::HipPartition, P::HipArray, fluid
         (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{IbhFluid}, Cint),
         part.handle, P.ptr, ld(P), R.ptr, ld(R), f, flags))
     R
+end
+
+# ---------------------------------------------------------------------------------------------------
+# an explicit solver step, device resident: the body of `march!` (test/advection.jl:61-89)
+# ---------------------------------------------------------------------------------------------------
+"An ordered list of `impose_bc!` calls whose closures are `value` constants or `copy(u)` (test/advection.jl:30-46),
+compiled once; `apply!(set, u)` has the semantics of the sequential calls."
+mutable struct HipBCSet
+    handle::Ptr{Cvoid}
+    bcs::Vector{Any}          # keeps the HipBoundary structs alive
+end
+function HipBCSet(bcs::Vector, closures::Vector)   # closures[i] = :copy or a number
+    modes = Int32[c === :copy ? 1 : 0 for c in closures]
+    vals = Float32[c === :copy ? 0f0 : Float32(c) for c in closures]
+    hs = Ptr{Cvoid}[b.handle for b in bcs]
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve hs modes vals check(ccall((:ibh_bcset_create, lib), Cint,
+        (Ptr{Ptr{Cvoid}}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Int32}, Ptr{Cfloat}), out, length(hs), hs, modes, vals))
+    s = HipBCSet(out[], collect(Any, bcs))
+    finalizer(x -> ccall((:ibh_bcset_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), s)
+    s
+end
+apply!(s::HipBCSet, u::HipArray{Float32}) = (check(ccall((:ibh_bcset_apply, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}),
+    s.handle, u.ptr)); u)
+
+"`dt = scale * 0.5 / maximum(max.(unsigned_green_gauss(at_faces(C_d, d), d)...))` (test/advection.jl:52-59, 65) left in
+device memory (`dt::HipArray` of length 1)."
+function timestep_advection!(dt::HipArray{Float32}, part::HipPartition, C::HipArray{Float32}; scale = 1f0)
+    check(ccall((:ibh_timestep_advection, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cfloat, Ptr{Cvoid}),
+        part.handle, C.ptr, ld(C), Float32(scale), dt.ptr))
+    dt
+end
+
+"`u_out = u + dt * R(u)` (closure of test/advection.jl:67-83 + `u .+= ud .* dt`, :86) in one launch, then the BC set."
+function step_advection!(u_out::HipArray{Float32}, part::HipPartition, u::HipArray{Float32}, C::HipArray{Float32},
+                         dt::HipArray{Float32}, bcs::Union{HipBCSet, Nothing} = nothing)
+    check(ccall((:ibh_step_advection, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+        part.handle, u.ptr, u_out.ptr, C.ptr, ld(C), dt.ptr, isnothing(bcs) ? C_NULL : bcs.handle))
+    u_out
+end
+
+"`S .+ Σ_d green_gauss(at_faces(ν .+ νR, d) .* face_gradient(R, d) .- at_faces(vel[:, d] .* R, d), d)` in one launch
+(the transport residual closed by `Wray_Agarwal`, src/turbulence.jl:222-241), bit-identical to the composition."
+function scalar_transport!(out::HipArray{Float32}, part::HipPartition, R::HipArray{Float32}, νR::HipArray{Float32},
+                           ν::Real, vel::HipArray{Float32}, S::HipArray{Float32})
+    check(ccall((:ibh_scalar_transport, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+        part.handle, R.ptr, νR.ptr, Float32(ν), vel.ptr, ld(vel), S.ptr, out.ptr))
+    out
 end
 
 # flags of the fused sweeps (include/ibhip.h)

@@ -23,19 +23,27 @@ profile_one() {   # tag, bench args...
   python3 scripts/summarize_pmc.py $O/p_$tag > $O/pmc_summary_$tag.json
   rm -rf $O/kt_$tag $O/p_$tag $O/kt_$tag.log
 }
+MODE=${2:-all}   # quick: the five profiled workloads + probes; big: the large lines only; all: both
+if [ "$MODE" != "big" ]; then
 say "headline with the cpu baseline"; python3 bench.py > $O/bench.json 2>$O/bench.err
 profile_one headline
 profile_one euler2d --residual euler
 profile_one 3d_4.6M --workload sphere3d_4.6M --steps 100 --warmup 10
 profile_one 3d_euler_4.6M --workload sphere3d_4.6M --residual euler --steps 50 --warmup 5
 profile_one 3.47M --workload rae2822_3.47M
-if [ "$2" != "quick" ]; then
+fi
+if [ "$MODE" != "quick" ]; then
   say 28M; python3 bench.py --no-cpu-baseline --workload rae2822_28M --steps 50 --warmup 5 --repeats 5 > $O/bench_28M.json 2>>$O/bench.err
   say "3d euler 33M"; bash scripts/with_heartbeat.sh $O/progress.log python3 bench.py --no-cpu-baseline --workload sphere3d_33M --residual euler --steps 20 --warmup 3 --repeats 5 > $O/bench_3d_euler_33M.json 2>>$O/bench.err
   say "3d 33M"; bash scripts/with_heartbeat.sh $O/progress.log python3 bench.py --no-cpu-baseline --workload sphere3d_33M --steps 50 --warmup 5 --repeats 5 > $O/bench_3d_33M.json 2>>$O/bench.err
   say config4; python3 bench.py --no-cpu-baseline --workload sphere3d_8M --residual euler --step config4 --steps 20 --warmup 3 --repeats 5 > $O/bench_config4_8M.json 2>>$O/bench.err
   say "config5 33M"; bash scripts/with_heartbeat.sh $O/progress.log python3 bench.py --no-cpu-baseline --workload sphere3d_33M --residual euler --step config5 --steps 3 --warmup 1 --repeats 2 > $O/bench_config5_33M.json 2>>$O/bench.err
+  say "config5 33M kernel trace"
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c5 -o kt -- python3 bench.py --no-cpu-baseline --workload sphere3d_33M --residual euler --step config5 --steps 3 --warmup 1 --repeats 1 > $O/kt_c5.log 2>&1 || say "kernel trace failed: config5"
+  cp $(find $O/kt_c5 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_config5_33M.csv 2>/dev/null; rm -rf $O/kt_c5 $O/kt_c5.log
+  say "march"; python3 bench.py --no-cpu-baseline --step march > $O/bench_march.json 2>>$O/bench.err
 fi
+if [ "$MODE" = "big" ]; then say done; exit 0; fi
 say probes
 python3 scripts/probe_3d_euler.py sphere3d_1.6M > $O/probe_3d_euler_1.6M.json 2>>$O/bench.err
 python3 scripts/probe_3d_euler.py sphere3d_4.6M > $O/probe_3d_euler_4.6M.json 2>>$O/bench.err

@@ -54,4 +54,21 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 out["operator_closure_gpu_us"] = round(e0.elapsed_time(e1) * 1e3 / 20, 1)
+# the same closure captured once in a HIP graph (ibamd.GraphedClosure) and replayed
+g = ibamd.GraphedClosure(closure, dpart, u, ud, C)
+ref = ud.t.clone()
+closure(dpart, u, ud, C)
+eager = ud.t.clone()
+ud.t.copy_(ref)
+g()
+torch.cuda.synchronize()
+out["graphed_closure_equals_eager"] = bool(torch.equal(ud.t, eager))
+out["graphed_closure_wall_us"] = round(wall(g), 1)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(20):
+    g()
+e1.record()
+torch.cuda.synchronize()
+out["graphed_closure_gpu_us"] = round(e0.elapsed_time(e1) * 1e3 / 20, 1)
 print(json.dumps(out))

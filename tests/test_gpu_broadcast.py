@@ -177,3 +177,39 @@ def test_in_place_broadcast_that_reads_a_column_of_its_destination():
     Q = ibamd.HipArray(A.copy())
     Q *= Q.col(3)
     assert np.array_equal(Q.to_host(), A * A[:, 2:3])
+
+
+def test_graphed_closure_replays_the_operator_closure(adv_domains):
+    """ibamd.GraphedClosure: the closure of advection.jl:67-83 at operator granularity, captured once in a HIP graph;
+    a replay is bit-identical to the eager call, reads the CURRENT contents of its arrays, and building it leaves the
+    arrays as they were."""
+    dp, _ = adv_domains
+    part = dp.partitions[1]
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    X = part.centers
+    rng = np.random.default_rng(5)
+    u = ibamd.HipArray(seeded_field(X, kind="smooth"))
+    C = ibamd.HipArray(np.ones((X.shape[0], 2), f32))
+    ud = ibamd.HipArray(np.zeros(X.shape[0], f32))
+
+    def closure(part, u, ud, C):
+        D = ibamd.JST_sensor(part, u)
+        for dim in range(1, part.ndims + 1):
+            Cf = ibamd.at_faces(part, C.col(dim), dim)
+            gu = ibamd.cell_gradient(part, u, dim)
+            uL, uR = ibamd.MUSCL(part, u, gu, dim, D=D, high_order=True)
+            ud -= ibamd.green_gauss(part, (uL + uR) * Cf / 2 + abs(Cf) * (uL - uR) / 2, dim)
+
+    u0 = u.to_host()
+    g = ibamd.GraphedClosure(closure, dpart, u, ud, C)
+    assert np.array_equal(u.to_host(), u0) and not ud.to_host().any()     # construction left the arrays alone
+    for trial in range(2):
+        un = (u0 + f32(0.1) * rng.standard_normal(u0.shape).astype(f32)) if trial else u0
+        u.t.copy_(ibamd.hip(un))
+        ud.t.zero_()
+        closure(dpart, u, ud, C)
+        eager = ud.to_host()
+        ud.t.zero_()
+        g()
+        assert np.array_equal(ud.to_host(), eager)
+        assert np.abs(eager).max() > 0
