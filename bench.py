@@ -753,7 +753,8 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "current_pmc.json")) as f:
             pm = json.load(f)
-        if pm.get("workload") == args.workload and pm.get("kernel") == kernel and world == 1:
+        pm = next((e_ for e_ in pm.get("entries", [pm]) if e_.get("workload") == args.workload and e_.get("kernel") == kernel), {})
+        if pm and world == 1:
             traffic = round((2.0 * pm["fetch_kb"] + pm["write_kb"]) * 1024.0)
             pmc_extra = {k: pm[k] for k in ("valu_insts_per_wave", "valu_busy_frac", "lds_insts_per_wave",
                                             "wave_wait_frac") if k in pm}
@@ -856,7 +857,7 @@ def main():
                                                             "direction relaxation (2 sweeps)"}}
     if march:
         out["metric"] = "Mcells*steps/s, explicit march (device dt + sweep and update in one launch + BC set), 2D RAE2822"
-        out["config"]["step"] = {"ghost_cells": int(bcs_m.n_ghost), "bc_set_levels": int(bcs_m.n_levels),
+        out["config"]["step"] = {"ghost_cells": int(bcs_m.n_ghost), "bc_set_levels": int(bcs_m.n_levels), "bc_set_levels_in_one_launch": int(bcs_m.n_direct_levels),
                                  "dt_reduction_every": 10, "finite": bool(torch.isfinite(um[0]).all().item()),
                                  "what": "test/advection.jl:61-89 without the host in the loop: ibh_timestep_advection every "
                                          "10 steps, ibh_step_advection (k_sweep_quad storing u + dt ud, then the BC set) "

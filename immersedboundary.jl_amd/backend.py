@@ -630,7 +630,8 @@ class BCSet:
         self.handle = h
         ng, nl = C.c_int32(0), C.c_int32(0)
         call("ibh_bcset_info", h, C.byref(ng), C.byref(nl))
-        self.n_ghost, self.n_levels = int(ng.value), int(nl.value)
+        self.n_ghost, self.n_levels = int(ng.value), int(nl.value) & 0xffff
+        self.n_direct_levels = int(nl.value) >> 16      # levels blended straight into the field (one launch each)
 
     def apply(self, u):
         """The boundary conditions on the device field ``u`` (in place)."""

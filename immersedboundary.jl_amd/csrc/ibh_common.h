@@ -137,7 +137,7 @@ struct ibh_part {
     int64_t info[24] = {0};
     // workspace for per-cell gradients + sensor (pass A output)
     float* G = nullptr;
-    float* march_tmp = nullptr;  // scratch of ibh_timestep_advection: [max nf | nd x nc] floats + one word
+    float* march_tmp = nullptr;  // two words of ibh_timestep_advection's reduction (maximum, finished workgroups)
     size_t march_tmp_n = 0;
     size_t G_bytes = 0;
 };
@@ -166,6 +166,7 @@ struct ibh_bcset {
     int nbc = 0, nlev = 0;
     int32_t ng = 0;                 // ghost cells of all boundaries, ordered by level
     int32_t seg[IBH_MAX_BC + 1] = {0};  // ghost ranges of the levels
+    bool direct[IBH_MAX_BC] = {false};  // no ghost cell of the level is a donor of the level: blended straight into the field
     int32_t *ghost = nullptr, *off = nullptr, *donor = nullptr, *bidx = nullptr;
     float *eta = nullptr, *w = nullptr, *gval = nullptr, *value = nullptr;
     int32_t* mode = nullptr;

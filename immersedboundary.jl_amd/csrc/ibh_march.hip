@@ -4,8 +4,8 @@
 //     (ImmersedBoundary.jl:1197-1247: every ghost cell of a boundary is interpolated BEFORE any of them is written; a later
 //     boundary sees the earlier ones): boundaries that do not read each other's ghost cells form a level, a level is two
 //     launches (interpolate + closure + blend into a side buffer, scatter) whatever the number of boundaries;
-//   * ibh_timestep_advection: dt = scale * 0.5 / max over cells and dimensions of unsigned_green_gauss(at_faces(C_d, d), d)
-//     (advection.jl:52-59) left in device memory -- no host read-back in the step loop.
+//   * ibh_timestep_advection (ibh_ops.hip): dt = scale * 0.5 / max over cells and dimensions of
+//     unsigned_green_gauss(at_faces(C_d, d), d) (advection.jl:52-59) left in device memory -- no host read-back in the loop.
 // The step itself (sweep + u += dt ud in one launch) is ibh_step_advection in ibh_fused.hip.
 // Arithmetic: the operator kernels' (ibh_ops.hip): -ffp-contract=off, the reference's evaluation order.
 #include <algorithm>
@@ -34,13 +34,16 @@ __device__ __forceinline__ float bc_interp1(const int32_t* __restrict__ off, con
 __global__ void k_bcset_interp(int32_t g0, int32_t g1, const float* __restrict__ eta, const int32_t* __restrict__ off,
                                const int32_t* __restrict__ donor, const float* __restrict__ w,
                                const int32_t* __restrict__ bidx, const int32_t* __restrict__ mode,
-                               const float* __restrict__ value, const float* __restrict__ a, float* __restrict__ gval) {
+                               const float* __restrict__ value, const float* __restrict__ a, float* __restrict__ gval,
+                               const int32_t* __restrict__ ghost, float* a_out) {
     for (int32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += gridDim.x * blockDim.x) {
         const float i = bc_interp1(off, donor, w, a, g);
         const int32_t k = bidx[g];
         const float e = eta[g];
         const float b = mode[k] ? i : value[k];
-        gval[g] = e * i + (1.0f - e) * b;
+        const float v = e * i + (1.0f - e) * b;
+        if (ghost) a_out[ghost[g]] = v;  // (level without a ghost cell among its donors: nobody reads what is written here)
+        else gval[g] = v;
     }
 }
 __global__ void k_bcset_scatter(int32_t g0, int32_t g1, const int32_t* __restrict__ ghost, const float* __restrict__ gval,
@@ -54,18 +57,6 @@ __global__ void k_update_dev(int64_t n, const float* __restrict__ dt, const floa
     const float h = *dt;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = u[i] + r[i] * h;
-}
-
-__global__ void k_max_cells(int64_t n, int nd, const float* __restrict__ t, unsigned int* __restrict__ word) {
-    float m = 0.0f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        for (int d = 0; d < nd; ++d) m = fmaxf(m, t[i + (int64_t)d * n]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    // non-negative floats order like their bit patterns
-    if ((threadIdx.x & 63) == 0) atomicMax(word, __float_as_uint(m));
-}
-__global__ void k_dt_from_max(const unsigned int* __restrict__ word, float scale, float* __restrict__ dt) {
-    *dt = (0.5f / __uint_as_float(*word)) * scale;  // advection.jl:53 and :65
 }
 
 }  // namespace
@@ -127,6 +118,14 @@ int ibh_bcset_create(ibh_bcset** out, int nbc, const ibh_bc* const* bcs, const i
         }
     }
     s->seg[nlev] = s->ng = (int32_t)ghost.size();
+    for (int lv = 0; lv < nlev; ++lv) {  // a level none of whose ghost cells is one of its donors needs no side buffer
+        std::vector<int32_t> gl(ghost.begin() + s->seg[lv], ghost.begin() + s->seg[lv + 1]);
+        std::sort(gl.begin(), gl.end());
+        bool hazard = false;
+        for (int32_t j = off[s->seg[lv]]; j < off[s->seg[lv + 1]] && !hazard; ++j)
+            hazard = std::binary_search(gl.begin(), gl.end(), donor[j]);
+        s->direct[lv] = !hazard;
+    }
     int rc;
     if ((rc = ibh_upload(&s->ghost, ghost.data(), ghost.size()))) return rc;
     if ((rc = ibh_upload(&s->eta, eta.data(), eta.size()))) return rc;
@@ -152,7 +151,11 @@ int ibh_bcset_destroy(ibh_bcset* s) {
 int ibh_bcset_info(const ibh_bcset* s, int32_t* n_ghost, int32_t* n_levels) {
     IBH_REQUIRE(s, "ibh_bcset_info: null set");
     if (n_ghost) *n_ghost = s->ng;
-    if (n_levels) *n_levels = s->nlev;
+    if (n_levels) {
+        int nd = 0;
+        for (int lv = 0; lv < s->nlev; ++lv) nd += s->direct[lv];
+        *n_levels = s->nlev | (nd << 16);  // low half: levels; high half: how many of them are blended in one launch
+    }
     return 0;
 }
 
@@ -162,8 +165,13 @@ int ibh_bcset_apply(const ibh_bcset* s, float* a) {
         const int32_t g0 = s->seg[lv], g1 = s->seg[lv + 1];
         if (g1 == g0) continue;
         const int nwg = std::min(ibh_grid(g1 - g0, MARCH_BLOCK), 2048);
+        if (s->direct[lv]) {
+            hipLaunchKernelGGL(k_bcset_interp, dim3(nwg), dim3(MARCH_BLOCK), 0, ibh_stream, g0, g1, s->eta, s->off, s->donor,
+                               s->w, s->bidx, s->mode, s->value, a, s->gval, s->ghost, a);
+            continue;
+        }
         hipLaunchKernelGGL(k_bcset_interp, dim3(nwg), dim3(MARCH_BLOCK), 0, ibh_stream, g0, g1, s->eta, s->off, s->donor,
-                           s->w, s->bidx, s->mode, s->value, a, s->gval);
+                           s->w, s->bidx, s->mode, s->value, a, s->gval, (const int32_t*)nullptr, (float*)nullptr);
         hipLaunchKernelGGL(k_bcset_scatter, dim3(nwg), dim3(MARCH_BLOCK), 0, ibh_stream, g0, g1, s->ghost, s->gval, a);
     }
     IBH_LAUNCH_CHECK();
@@ -175,34 +183,6 @@ int ibh_update_dev(int64_t n, const float* dt_dev, const float* u, const float* 
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_update_dev, dim3(std::min(ibh_grid(n, MARCH_BLOCK), 2048)), dim3(MARCH_BLOCK), 0, ibh_stream, n,
                        dt_dev, u, r, out);
-    IBH_LAUNCH_CHECK();
-    return 0;
-}
-
-int ibh_timestep_advection(ibh_part* p, const float* C, int64_t ldc, float scale, float* dt_dev) {
-    IBH_REQUIRE(p && C && dt_dev && p->nd >= 1, "ibh_timestep_advection: bad argument");
-    const int nd = p->nd;
-    int32_t nfmax = 0;
-    for (int d = 0; d < nd; ++d) nfmax = std::max(nfmax, p->dim[d].nf);
-    const size_t need = (size_t)nfmax + (size_t)nd * p->nc + 1;
-    if (p->march_tmp_n < need) {
-        if (p->march_tmp) IBH_HIP(hipFree(p->march_tmp));
-        p->march_tmp = nullptr;
-        IBH_HIP(hipMalloc((void**)&p->march_tmp, sizeof(float) * need));
-        p->march_tmp_n = need;
-    }
-    float* tf = p->march_tmp;
-    float* tc = tf + nfmax;
-    unsigned int* word = (unsigned int*)(tc + (size_t)nd * p->nc);
-    IBH_HIP(hipMemsetAsync(word, 0, sizeof(unsigned int), ibh_stream));
-    for (int d = 0; d < nd; ++d) {
-        int rc = ibh_at_faces(p, d + 1, C + (size_t)d * ldc, 1, p->nc, tf, nfmax);
-        if (!rc) rc = ibh_green_gauss(p, d + 1, tf, 1, nfmax, tc + (size_t)d * p->nc, p->nc, 1);
-        if (rc) return rc;
-    }
-    const int nwg = std::min(ibh_grid(p->nc, MARCH_BLOCK), 1024);
-    hipLaunchKernelGGL(k_max_cells, dim3(nwg), dim3(MARCH_BLOCK), 0, ibh_stream, (int64_t)p->nc, nd, tc, word);
-    hipLaunchKernelGGL(k_dt_from_max, dim3(1), dim3(1), 0, ibh_stream, word, scale, dt_dev);
     IBH_LAUNCH_CHECK();
     return 0;
 }

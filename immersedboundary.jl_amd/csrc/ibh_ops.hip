@@ -145,6 +145,55 @@ __global__ void k_cell_gradient_all(int32_t nc, GradDims G, const float* __restr
     }
 }
 
+// dt of an explicit advection step (test/advection.jl:52-59, :65): max over cells and dimensions of
+// unsigned_green_gauss(at_faces(C_d, d), d) -- the same expressions as k_at_faces + k_green_gauss(unsigned), a face value
+// evaluated by both of its cells instead of being written and read back -- reduced in ONE launch: wave and workgroup
+// maxima, one atomicMax per workgroup (non-negative floats order like their bit patterns), and the last workgroup to
+// finish writes dt = (0.5 / max) * scale and resets the two words for the next call.
+template <int ND>
+__global__ __launch_bounds__(OPS_BLOCK) void k_timestep_advection(int32_t nc, GradDims G, const float* __restrict__ C,
+                                                                  int64_t ldc, float scale, unsigned int* __restrict__ words,
+                                                                  float* __restrict__ dt) {
+    float m = 0.0f;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        int32_t sd[2 * ND];
+#pragma unroll
+        for (int s = 0; s < 2 * ND; ++s) sd[s] = G.side[(int64_t)s * nc + c];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const float* Cd = C + (int64_t)d * ldc;
+            const float hc = G.h[d][c], uc = Cd[c];
+            const int32_t l = sd[2 * d], r = sd[2 * d + 1];
+            float ar, al;
+            if (r >= 0) ar = face_avg(uc, Cd[r], hc, G.h[d][r]) * 1.0f;
+            else if (r == -2) ar = 0.0f;
+            else ar = csr_mean_face_avg(G.d[d].roff, G.d[d].ridx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], Cd);
+            if (l >= 0) al = face_avg(Cd[l], uc, G.h[d][l], hc) * 1.0f;
+            else if (l == -2) al = 0.0f;
+            else al = csr_mean_face_avg(G.d[d].loff, G.d[d].lidx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], Cd);
+            m = fmaxf(m, (ar + al) / hc);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[OPS_BLOCK / 64];
+    __shared__ bool last;
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = wm[0];
+        for (int w = 1; w < OPS_BLOCK / 64; ++w) b = fmaxf(b, wm[w]);
+        atomicMax(&words[0], __float_as_uint(b));
+        __threadfence();
+        last = atomicAdd(&words[1], 1u) == gridDim.x - 1;
+        if (last) {
+            __threadfence();
+            const unsigned int w = atomicExch(&words[0], 0u);
+            words[1] = 0u;
+            *dt = (0.5f / __uint_as_float(w)) * scale;  // advection.jl:53 and :65
+        }
+    }
+}
+
 __global__ void k_cell_gradient(int32_t nc, DimData D, const float* __restrict__ h, const float* __restrict__ u,
                                 int64_t ldu, float* __restrict__ out, int64_t ldo) {
     int64_t v = blockIdx.y;
@@ -468,6 +517,30 @@ int ibh_cell_gradient_all(const ibh_part* p, const float* u, int nv, int64_t ldu
         hipLaunchKernelGGL(k_cell_gradient_all<2>, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, u, ldu, nv, out, ldo);
     else
         hipLaunchKernelGGL(k_cell_gradient_all<3>, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, u, ldu, nv, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_timestep_advection(ibh_part* p, const float* C, int64_t ldc, float scale, float* dt_dev) {
+    IBH_REQUIRE(p && C && dt_dev && (p->nd == 2 || p->nd == 3) && p->nc > 0, "ibh_timestep_advection: bad argument");
+    if (!p->march_tmp) {  // two words: running maximum, finished workgroups (both left at zero by every call)
+        IBH_HIP(hipMalloc((void**)&p->march_tmp, 2 * sizeof(unsigned int)));
+        IBH_HIP(hipMemset(p->march_tmp, 0, 2 * sizeof(unsigned int)));
+        p->march_tmp_n = 2;
+    }
+    GradDims G;
+    for (int d = 0; d < p->nd; ++d) {
+        G.d[d] = p->dim[d];
+        G.h[d] = p->spacing + (int64_t)d * p->nc;
+    }
+    G.side = p->side;
+    const int nwg = std::min(ibh_grid(p->nc, OPS_BLOCK), 1024);
+    if (p->nd == 2)
+        hipLaunchKernelGGL(k_timestep_advection<2>, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, C, ldc, scale,
+                           (unsigned int*)p->march_tmp, dt_dev);
+    else
+        hipLaunchKernelGGL(k_timestep_advection<3>, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, C, ldc, scale,
+                           (unsigned int*)p->march_tmp, dt_dev);
     IBH_LAUNCH_CHECK();
     return 0;
 }

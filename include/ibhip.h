@@ -341,6 +341,7 @@ int ibh_step_advection_xgmi(ibh_part*, float* u, const float* C, int64_t ldc, fl
 typedef struct ibh_bcset ibh_bcset;
 int ibh_bcset_create(ibh_bcset** out, int n_bc, const ibh_bc* const* bcs, const int32_t* modes, const float* values);
 int ibh_bcset_destroy(ibh_bcset*);
+/* n_levels: low 16 bits = levels, high 16 bits = levels none of whose ghost cells is a donor of the level (one launch) */
 int ibh_bcset_info(const ibh_bcset*, int32_t* n_ghost, int32_t* n_levels);
 int ibh_bcset_apply(const ibh_bcset*, float* a);
 int ibh_timestep_advection(ibh_part*, const float* C, int64_t ldc, float scale, float* dt_device);
