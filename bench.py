@@ -631,7 +631,12 @@ def main():
     # times: a block is a fraction of a millisecond, its wall time moves with launch jitter; the median is reported
     dts, gts = [], []
     ev_stream = side if graph is not None else torch.cuda.current_stream()
-    for _ in range(max(1, args.repeats)):
+    # short blocks (a graph of 20 sweeps is ~0.13 ms): 20 blocks are over before the device clocks have settled (the
+    # median drifts from 7.3 to 7.0 us per sweep between 20 and >= 200 blocks) -- keep going until the blocks add up to 0.2 s
+    # or 400 of them have run; every block is exactly `steps` steps between barrier + synchronize
+    n_rep = max(1, args.repeats)
+    n_goal = None                      # total number of blocks, decided (by all ranks alike) after the first n_rep
+    while len(dts) < n_rep or len(dts) < n_goal:
         barrier()
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -641,6 +646,13 @@ def main():
         barrier()
         dts.append(time.perf_counter() - t0)
         gts.append(g0.elapsed_time(g1) * 1e-3)   # GPU side of the same block (events on the launch stream)
+        if len(dts) == n_rep and n_goal is None:
+            tot = sum(dts)
+            if world > 1:                # the same count on every rank: the slowest rank's total decides
+                tt = torch.tensor([tot], dtype=torch.float64, device=u.device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tot = float(tt.item())
+            n_goal = n_rep if tot >= 0.2 else min(max(n_rep, 400), int(n_rep * 0.2 / max(tot, 1e-9)) + 1)
     if world > 1:
         red_dev = u.device if args.backend == "nccl" else "cpu"
         tmax = torch.tensor(dts, dtype=torch.float64, device=red_dev)
