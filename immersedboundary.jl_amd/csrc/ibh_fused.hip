@@ -643,7 +643,9 @@ __device__ __forceinline__ void dbg_stamp(int32_t slot, int k, unsigned long lon
     if (ibh_dbg_buf && threadIdx.x % 64 == 0) ibh_dbg_buf[(size_t)slot * 8 + k] = v;
 }
 
-template <bool DT, bool STAMP, int GM = 127, bool STEP = false>
+// RS: the blocks outside quads take the row sweep, EIGHT per wave (rows2::sweep_rows over the list), instead of the per-block
+// body -- `nwgs`, `siters` then count waves of eight
+template <bool DT, bool STAMP, int GM = 127, bool STEP = false, bool RS = false>
 __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict__ u, const float* __restrict__ C,
                                                          uint32_t ldc, float* __restrict__ ud,
                                                          const QuadDesc2* __restrict__ qd,
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
                                                          const int32_t* __restrict__ singles, int32_t ns, int32_t nwgs,
                                                          int32_t singles_first, int32_t siters,
                                                          const float* __restrict__ dtp = nullptr) {
-    __shared__ __attribute__((aligned(16))) float lds[QUAD_WG_LDS];
+    __shared__ __attribute__((aligned(16))) float lds[RS && WPB * ROWS_LDS > QUAD_WG_LDS ? WPB * ROWS_LDS : QUAD_WG_LDS];
     float dt = 0.0f;
     if constexpr (STEP) dt = *dtp;  // (scalar load: the time step lives on the device, ibh_timestep_advection)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -673,6 +675,11 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
                                                STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr, dt);
     } else {
         const int32_t wgs = singles_first ? (int32_t)blockIdx.x : (int32_t)blockIdx.x - nwgq;
+        if constexpr (RS) {
+            const int32_t first8 = __builtin_amdgcn_readfirstlane((xcd_remap(wgs, nwgs) * WPB + wave) * 8);
+            if (first8 < ns) rows2::sweep_rows(blocks, etab, first8, ns, u, C, ldc, ud, lds + wave * ROWS_LDS, lane, singles);
+            return;
+        }
         const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(wgs, nwgs) * (WPB * siters) + wave);
         if (first < ns) {
             const int32_t nb = __builtin_amdgcn_readfirstlane(min(siters, (ns - first + WPB - 1) / WPB));
@@ -695,11 +702,12 @@ __global__ __launch_bounds__(64 * WPBR) void k_sweep_rows(const float* __restric
                                                           uint32_t ldc, float* __restrict__ ud,
                                                           const BlockDesc2* __restrict__ blocks,
                                                           const int32_t* __restrict__ etab, int32_t b0, int32_t n,
-                                                          int32_t nwg) {
+                                                          int32_t nwg, const int32_t* __restrict__ list) {
     __shared__ __attribute__((aligned(16))) float lds[WPBR * ROWS_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t first = __builtin_amdgcn_readfirstlane((xcd_remap(blockIdx.x, nwg) * WPBR + wave) * 8);
-    if (first < n) rows2::sweep_rows(blocks + b0, etab + (size_t)b0 * 16, first, n, u, C, ldc, ud, lds + wave * ROWS_LDS, lane);
+    if (first < n)
+        rows2::sweep_rows(blocks + b0, etab + (size_t)b0 * 16, first, n, u, C, ldc, ud, lds + wave * ROWS_LDS, lane, list);
 }
 
 // One step of a rank of a multi-GPU run in ONE launch: the xGMI halo exchange of u (ibh_halo_dev.h) and the image-only
@@ -1073,6 +1081,10 @@ int ibh_rows = getenv("IBH_ROWS") ? atoi(getenv("IBH_ROWS")) : 0;
 // ibh_set_tuning(key, v): "quad_variant" 4 = wave time stamps (scripts/wave_timeline.py); "quad_parts" 1 / 2 = only the
 // quads / only the single blocks of a quad sweep (measurement); "quad_singles_first" = grid order
 int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_first = 0, ibh_quad_singles_iters = 1;
+int ibh_rows_singles = getenv("IBH_ROWS_SINGLES") ? atoi(getenv("IBH_ROWS_SINGLES")) : -1;
+// measured (profiles/r3_final/rows_for_singles.json): 1 441 single blocks 5.96 -> 10.6 us, 5 937: 15.5 -> 19.0 us (a row wave
+// lives ~3 us whatever the load, and the second launch is serial), 47 272: 126.1 -> 119.0 us
+#define IBH_ROWS_SINGLES_MIN 24000
 
 PartView view(const ibh_part* p) {
     PartView v;
@@ -1126,6 +1138,7 @@ int ibh_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "quad_singles_first")) ibh_quad_singles_first = value;
     else if (!strcmp(key, "quad_singles_iters")) ibh_quad_singles_iters = value;
     else if (!strcmp(key, "rows")) ibh_rows = value;
+    else if (!strcmp(key, "rows_singles")) ibh_rows_singles = value;
     else return ibh_fail(-1, "ibh_set_tuning: unknown key", __FILE__, __LINE__);
     return 0;
 }
@@ -1226,22 +1239,37 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         if (q1 - q0 + s1 - s0 <= 0) return;
         if (ibh_quad_parts == 1) s1 = s0;  // measurement: quads only / single blocks only
         if (ibh_quad_parts == 2) q1 = q0;
+        // The blocks outside quads as a SECOND launch of the row sweep (rows2::sweep_rows over the list: any eight complete
+        // blocks per wave, 110 vector instructions per block against 365 in the per-block kernel) where a second launch
+        // is cheap against the sweep ("rows_singles": -1 = by size, 0 / 1 = never / always)
+        const bool rows_singles = k == 0 && p->rows_ok && p->n_dt == 0 && ibh_quad_variant == 0 && s1 > s0 &&
+                                  (ibh_rows_singles < 0 ? s1 - s0 >= IBH_ROWS_SINGLES_MIN : ibh_rows_singles > 0);
+        const int32_t rs0 = s0, rs1 = s1;
+        const bool rows_inside = k == 0 && p->rows_ok && p->n_dt == 0 && ibh_quad_variant == 0 && s1 > s0 && ibh_rows_singles == 2;
+        if (rows_singles && !rows_inside) s1 = s0;
         const int32_t siters = ibh_quad_singles_iters > 0 ? ibh_quad_singles_iters : 1;
-        const int32_t nwgq = (q1 - q0 + WPB - 1) / WPB, nwgs = (s1 - s0 + WPB * siters - 1) / (WPB * siters);
-        if (nwgq + nwgs == 0) return;
+        const int32_t nwgq = (q1 - q0 + WPB - 1) / WPB,
+                      nwgs = rows_inside ? (s1 - s0 + WPB * 8 - 1) / (WPB * 8) : (s1 - s0 + WPB * siters - 1) / (WPB * siters);
+        if (nwgq + nwgs == 0 && !rows_singles) return;
 #define QUAD_LAUNCH(DT, STAMP, ...)                                                                                    \
     hipLaunchKernelGGL((k_sweep_quad<DT, STAMP, ##__VA_ARGS__>), dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C,              \
                        (uint32_t)ldc, ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq,            \
                        p->blocks2, p->htab, p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs, ibh_quad_singles_first, siters)
-        if (p->n_dt > 0) QUAD_LAUNCH(true, false);
+        if (rows_inside) QUAD_LAUNCH(false, false, 127, false, true);
+        else if (p->n_dt > 0) QUAD_LAUNCH(true, false);
         else if (ibh_quad_variant == 4) QUAD_LAUNCH(false, true);
         else if (ibh_quad_variant == 126) QUAD_LAUNCH(false, false, 126);  // A/B: seven 4-byte gathers
         else if (ibh_quad_variant == 85) QUAD_LAUNCH(false, false, 85);  // measurement: subsets of the halo gathers
         else if (ibh_quad_variant == 69) QUAD_LAUNCH(false, false, 69);
         else if (ibh_quad_variant == 5) QUAD_LAUNCH(false, false, 5);
         else if (ibh_quad_variant == 100) QUAD_LAUNCH(false, false, 0);
-        else QUAD_LAUNCH(false, false);
+        else if (nwgq + nwgs > 0) QUAD_LAUNCH(false, false);
 #undef QUAD_LAUNCH
+        if (rows_singles && !rows_inside) {
+            const int32_t nw = (rs1 - rs0 + 7) / 8, nwgr = (nw + WPBR - 1) / WPBR;
+            hipLaunchKernelGGL(k_sweep_rows, dim3(nwgr), dim3(64 * WPBR), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->blocks2,
+                               p->etab, 0, rs1 - rs0, nwgr, p->qsingles[k] + rs0);
+        }
     };
     if (tuned2 && (flags & IBH_IMAGE_ONLY) && p->img_all_fz && !p->fuse_all) {
         // only the image cells are wanted (a rank of a multi-GPU run) and every image block is eligible: one launch
@@ -1264,7 +1292,7 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
             const int32_t nw = (b1 - b0 + 7) / 8, nwg = (nw + WPBR - 1) / WPBR;
             if (nwg > 0)
                 hipLaunchKernelGGL(k_sweep_rows, dim3(nwg), dim3(64 * WPBR), 0, ibh_stream, u, C, (uint32_t)ldc, ud,
-                                   p->blocks2, p->etab, b0, b1 - b0, nwg);
+                                   p->blocks2, p->etab, b0, b1 - b0, nwg, (const int32_t*)nullptr);
         } else if (quads_ok(0)) launch_quads(0, ph1, ph2);
         else launch_sweep(nullptr, b0, b1 - b0);
         IBH_LAUNCH_CHECK();

@@ -295,14 +295,15 @@ __device__ __forceinline__ void slot_means(const Slot2& s, float m, float& hm, f
     ha = 0.5f * (fabsf(s.hu.x - m) + fabsf(s.hu.y - m));
 }
 
-// ---- eight blocks first .. first + 7 (n blocks in all) by one wave
+// ---- eight blocks first .. first + 7 (n blocks in all; entries of `list` if given: any eight blocks) by one wave
 __device__ __forceinline__ void sweep_rows(const BlockDesc2* __restrict__ blocks, const int32_t* __restrict__ etab,
                                            int32_t first, int32_t n, const float* __restrict__ u,
                                            const float* __restrict__ C, uint32_t ldc, float* __restrict__ ud, float* lds,
-                                           int lane) {
+                                           int lane, const int32_t* __restrict__ list = nullptr) {
     const int g = lane >> 3, i = lane & 7;
     const bool valid = first + g < n;
-    const int32_t blk = valid ? first + g : n - 1;  // (lanes past the end repeat the last block and store nothing)
+    const int32_t pos = valid ? first + g : n - 1;  // (lanes past the end repeat the last block and store nothing)
+    const int32_t blk = list ? list[pos] : pos;
     const float* Cy = C + ldc;
     const Blk B = load_blk(blocks, blk);
     const int32_t* et = etab + (size_t)blk * 16;
