@@ -806,10 +806,15 @@ __global__ __launch_bounds__(64 * WPBE) void k_sweep_euler(const float* __restri
 // Quad form of the Euler sweep (quad2::sweep_quad_euler): grid = [quad workgroups | single-block workgroups], like
 // k_sweep_quad
 #define QUADE_WG_LDS (WPBE * (QE_LDS > BLK2_SWEEP_EULER_LDS ? QE_LDS : BLK2_SWEEP_EULER_LDS))
-// 206 VGPRs = 2 waves per SIMD.  Forcing 3 (168 VGPRs, 25 spilled) measured 15.4 us against 12.1 us for the quads of
-// the 0.87 M-cell mesh, 4 (128, 139 spilled) 32.8 us; the quad path is 1441 vector instructions per wave (569 of them
-// packed), i.e. ~80 % of the time of the quad part is VALU issue (profiles/r2_final/probe_euler.json).
-__global__ __launch_bounds__(64 * WPBE) void k_sweep_quad_euler(const float* __restrict__ P, uint32_t ldp,
+// Waves per SIMD (QE_WAVES).  Round 2: 206 VGPRs = 2 waves; forcing 3 spilled 25 registers (15.4 against 12.1 us for the quads
+// of the 0.87 M-cell mesh).  Round 3: HLL regrouped by state (the physical fluxes of the two sides are never held), edge
+// faces first, residual accumulated direction by direction -> 188 VGPRs as the compiler schedules it freely, 136 with no
+// spill when asked for 3 waves, 128 with 6 spilled for 4.  Same box, whole sweep: 2 / 3 / 4 waves 15.8 / 14.8 / 15.0 us at
+// 0.87 M cells, 48.1 / 41.9 / 43.2 us at 3.47 M (profiles/r3_final/euler2d_waves.json).
+#ifndef QE_WAVES
+#define QE_WAVES 3
+#endif
+__global__ __launch_bounds__(64 * WPBE) __attribute__((amdgpu_waves_per_eu(QE_WAVES, QE_WAVES))) void k_sweep_quad_euler(const float* __restrict__ P, uint32_t ldp,
                                                                 float* __restrict__ R, uint32_t ldr, float Rgas,
                                                                 float gamma, const QuadDesc2* __restrict__ qd,
                                                                 const int32_t* __restrict__ qtab, int32_t nq,

@@ -39,25 +39,24 @@ __device__ __forceinline__ v2f sqrt2(v2f x) { return v2f{__builtin_amdgcn_sqrtf(
 __device__ __forceinline__ v2f max2(v2f a, v2f b) { return v2f{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
 __device__ __forceinline__ v2f min2(v2f a, v2f b) { return v2f{fminf(a.x, b.x), fminf(a.y, b.y)}; }
 
-__device__ __forceinline__ void euler_side2(const v2f* P, bool dn, const blk2::Gas& gas, v2f* Q, v2f* F, v2f& un, v2f& a) {
-    const v2f p = P[0];
+// conserved state, pressure, normal velocity and speed of sound of one side of a face pair
+__device__ __forceinline__ void euler_state2(const v2f* P, bool dn, const blk2::Gas& gas, v2f* Q, v2f& p, v2f& un, v2f& a) {
+    p = P[0];
     const v2f T = max2(P[1], v2f{10.0f, 10.0f});
     const v2f k = 0.5f * (P[2] * P[2] + P[3] * P[3]);
     const v2f rho = p * rcp2(gas.R * T);
-    const v2f E = rho * (gas.R / (gas.gamma - 1.0f) * T + k);
     Q[0] = rho;
-    Q[1] = E;
+    Q[1] = rho * (gas.R / (gas.gamma - 1.0f) * T + k);
     Q[2] = rho * P[2];
     Q[3] = rho * P[3];
     un = dn ? P[3] : P[2];
     a = sqrt2((gas.gamma * gas.R) * T);
-    const v2f z = v2f{0.0f, 0.0f};
-    F[0] = Q[0] * un;
-    F[1] = (Q[1] + p) * un;
-    F[2] = Q[2] * un + (dn ? z : p);
-    F[3] = Q[3] * un + (dn ? p : z);
 }
 
+// MUSCL states from undivided slopes, then HLL: F = (SL FL - SR FR + SL SR (QR - QL)) / (SL - SR) with FL = QL unL +
+// pressure terms, regrouped by state (as strip3e::euler_flux): F = QL (wL unL - c) + QR (c - wR unR) + pressure terms,
+// wL = SL / (SL - SR), wR = SR / (SL - SR), c = SL wR -- two instructions per variable instead of five, and the physical
+// fluxes of the two sides are never held
 __device__ __forceinline__ void euler_flux_w2(const v2f* Pa, const v2f* Pb, const v2f* Sa, const v2f* Sb, v2f Da, v2f Db,
                                               float wa, bool dn, const blk2::Gas& gas, v2f* F) {
     v2f PL[4], PR[4];
@@ -74,16 +73,23 @@ __device__ __forceinline__ void euler_flux_w2(const v2f* Pa, const v2f* Pb, cons
         PL[v] = uf + Df * ((s - wa * d) - t16);
         PR[v] = uf + Df * ((wb * d - s) - t16);
     }
-    v2f QL[4], FL[4], QR[4], FR[4], uL, aL, uR, aR;
-    euler_side2(PL, dn, gas, QL, FL, uL, aL);
-    euler_side2(PR, dn, gas, QR, FR, uR, aR);
+    v2f QL[4], QR[4], pL, pR, uL, aL, uR, aR;
+    euler_state2(PL, dn, gas, QL, pL, uL, aL);
+    euler_state2(PR, dn, gas, QR, pR, uR, aR);
     const v2f z = v2f{0.0f, 0.0f};
     const v2f SR = min2(uR - aR, z);
     const v2f SL = max2(uL + aL, z);
     const v2f rs = rcp2(SL - SR);
-    const v2f SLR = SR * SL;
+    const v2f wL = SL * rs, wR = SR * rs;
+    const v2f c = SL * wR;
+    const v2f cL = wL * uL - c, cR = c - wR * uR;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) F[v] = (SL * FL[v] - SR * FR[v] + SLR * (QR[v] - QL[v])) * rs;
+    for (int v = 0; v < 4; ++v) F[v] = QL[v] * cL + QR[v] * cR;
+    const v2f mL = wL * pL, mR = wR * pR;
+    const v2f m = mL - mR;
+    F[2] += dn ? z : m;
+    F[3] += dn ? m : z;
+    F[1] += mL * uL - mR * uR;
 }
 
 __device__ __forceinline__ void sweep_quad_euler(const QuadDesc2* __restrict__ qd, const int32_t* __restrict__ qtab,
@@ -247,63 +253,9 @@ __device__ __forceinline__ void sweep_quad_euler(const QuadDesc2* __restrict__ q
         }
     }
 
-    // ---- interior faces: right (x+) and top (y+) face of every cell, two at a time (x = 15 / y = 15: replaced by the
-    // edge fluxes below)
-    v4f FR[QE_NV], FT[QE_NV];
-    {
-        const int up = (lane + 16) << 2;
-        float nP[QE_NV], nS[QE_NV];
-#pragma unroll
-        for (int v = 0; v < QE_NV; ++v) {
-            nP[v] = bperm(up, U[v].x);
-            nS[v] = bperm(up, SX[v].x);
-        }
-        const float nD = bperm(up, D.x);
-        v2f Pa[QE_NV], Pb[QE_NV], Sa[QE_NV], Sb[QE_NV], F[QE_NV];
-#pragma unroll
-        for (int v = 0; v < QE_NV; ++v) {
-            Pa[v] = U[v].xy;
-            Sa[v] = SX[v].xy;
-            Pb[v] = U[v].yz;
-            Sb[v] = SX[v].yz;
-        }
-        euler_flux_w2(Pa, Pb, Sa, Sb, D.xy, D.yz, 0.5f, false, gas, F);
-#pragma unroll
-        for (int v = 0; v < QE_NV; ++v) {
-            FR[v].xy = F[v];
-            Pa[v] = U[v].zw;
-            Sa[v] = SX[v].zw;
-            Pb[v] = v2f{U[v].w, nP[v]};
-            Sb[v] = v2f{SX[v].w, nS[v]};
-        }
-        euler_flux_w2(Pa, Pb, Sa, Sb, D.zw, v2f{D.w, nD}, 0.5f, false, gas, F);
-#pragma unroll
-        for (int v = 0; v < QE_NV; ++v) FR[v].zw = F[v];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            v2f Dbt;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int c = 2 * h + k;
-#pragma unroll
-                for (int v = 0; v < QE_NV; ++v) {
-                    Pa[v][k] = U[v][c];
-                    Sa[v][k] = SY[v][c];
-                    Pb[v][k] = dpp_shl1(U[v][c], U[v][c]);   // lanes t = 15 keep their own state: a finite, unused flux
-                    Sb[v][k] = dpp_shl1(SY[v][c], SY[v][c]);
-                }
-                Dbt[k] = dpp_shl1(D[c], D[c]);
-            }
-            euler_flux_w2(Pa, Pb, Sa, Sb, h ? D.zw : D.xy, Dbt, 0.5f, true, gas, F);
-#pragma unroll
-            for (int v = 0; v < QE_NV; ++v) {
-                if (h) FT[v].zw = F[v];
-                else FT[v].xy = F[v];
-            }
-        }
-    }
-
-    // ---- edge faces: both sub-faces of this lane's boundary cell
+    // ---- edge faces first: both sub-faces of this lane's boundary cell (everything the halo slots hold is dead after
+    // this; the residual is then accumulated direction by direction, so neither the x fluxes nor the slopes of a direction
+    // outlive it -- 188 -> fewer live registers than holding FR and FT of all cells for a final Green-Gauss pass)
     wave_lds_sync();  // SY, D rows
     float edge[QE_NV];
     {
@@ -336,21 +288,83 @@ __device__ __forceinline__ void sweep_quad_euler(const QuadDesc2* __restrict__ q
     for (int v = 0; v < QE_NV; ++v) exf[v * 64 + wrow * 16 + t] = edge[v];
     wave_lds_sync();
 
-    // ---- Green-Gauss
+    // ---- x faces: right face of every cell, two at a time (x = 15: replaced by the edge flux), Green-Gauss in x
+    v4f res[QE_NV];
+    {
+        const int up = (lane + 16) << 2;
+        float nP[QE_NV], nS[QE_NV];
 #pragma unroll
-    for (int v = 0; v < QE_NV; ++v) {
-        const float FRm = bperm((lane - 16) << 2, FR[v].w);
-        const v4f FL = v4f{g0 ? edge[v] : FRm, FR[v].x, FR[v].y, FR[v].z};
-        const v4f FRf = v4f{FR[v].x, FR[v].y, FR[v].z, g3 ? edge[v] : FR[v].w};
-        const v4f ex = *(const v4f*)(exf + v * 64 + my);
-        v4f FB, FTf;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            FB[c] = dpp_shr1(ex[c], FT[v][c]);
-            FTf[c] = t15 ? ex[c] : FT[v][c];
+        for (int v = 0; v < QE_NV; ++v) {
+            nP[v] = bperm(up, U[v].x);
+            nS[v] = bperm(up, SX[v].x);
         }
-        const v4f res = -((FRf - FL) * rhx) - ((FTf - FB) * rhy);
-        *(v4f_g*)((char*)(Rr + (size_t)v * ldr) + ((size_t)a0 << 2)) = res;
+        const float nD = bperm(up, D.x);
+        v4f FR[QE_NV];
+        v2f Pa[QE_NV], Pb[QE_NV], Sa[QE_NV], Sb[QE_NV], F[QE_NV];
+#pragma unroll
+        for (int v = 0; v < QE_NV; ++v) {
+            Pa[v] = U[v].xy;
+            Sa[v] = SX[v].xy;
+            Pb[v] = U[v].yz;
+            Sb[v] = SX[v].yz;
+        }
+        euler_flux_w2(Pa, Pb, Sa, Sb, D.xy, D.yz, 0.5f, false, gas, F);
+#pragma unroll
+        for (int v = 0; v < QE_NV; ++v) {
+            FR[v].xy = F[v];
+            Pa[v] = U[v].zw;
+            Sa[v] = SX[v].zw;
+            Pb[v] = v2f{U[v].w, nP[v]};
+            Sb[v] = v2f{SX[v].w, nS[v]};
+        }
+        euler_flux_w2(Pa, Pb, Sa, Sb, D.zw, v2f{D.w, nD}, 0.5f, false, gas, F);
+#pragma unroll
+        for (int v = 0; v < QE_NV; ++v) {
+            FR[v].zw = F[v];
+            const float FRm = bperm((lane - 16) << 2, FR[v].w);
+            const v4f FL = v4f{g0 ? edge[v] : FRm, FR[v].x, FR[v].y, FR[v].z};
+            const v4f FRf = v4f{FR[v].x, FR[v].y, FR[v].z, g3 ? edge[v] : FR[v].w};
+            res[v] = -((FRf - FL) * rhx);
+        }
+    }
+    // ---- y faces: top face of every cell (y = 15: the edge flux), Green-Gauss in y, store
+    {
+        v4f FT[QE_NV];
+        v2f Pa[QE_NV], Pb[QE_NV], Sa[QE_NV], Sb[QE_NV], F[QE_NV];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v2f Dbt;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = 2 * h + k;
+#pragma unroll
+                for (int v = 0; v < QE_NV; ++v) {
+                    Pa[v][k] = U[v][c];
+                    Sa[v][k] = SY[v][c];
+                    Pb[v][k] = dpp_shl1(U[v][c], U[v][c]);   // lanes t = 15 keep their own state: a finite, unused flux
+                    Sb[v][k] = dpp_shl1(SY[v][c], SY[v][c]);
+                }
+                Dbt[k] = dpp_shl1(D[c], D[c]);
+            }
+            euler_flux_w2(Pa, Pb, Sa, Sb, h ? D.zw : D.xy, Dbt, 0.5f, true, gas, F);
+#pragma unroll
+            for (int v = 0; v < QE_NV; ++v) {
+                if (h) FT[v].zw = F[v];
+                else FT[v].xy = F[v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < QE_NV; ++v) {
+            const v4f ex = *(const v4f*)(exf + v * 64 + my);
+            v4f FB, FTf;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                FB[c] = dpp_shr1(ex[c], FT[v][c]);
+                FTf[c] = t15 ? ex[c] : FT[v][c];
+            }
+            const v4f r = res[v] - ((FTf - FB) * rhy);
+            *(v4f_g*)((char*)(Rr + (size_t)v * ldr) + ((size_t)a0 << 2)) = r;
+        }
     }
 }
 
