@@ -420,6 +420,28 @@ __global__ void k_sumsq(int64_t n, const float* __restrict__ x, double* __restri
     }
 }
 
+// q += clamp(omega, 0, 1) * r and out += sum r^2 in one pass over r (solver.jl:82 and the norm of :84 on the same array)
+__global__ void k_axpy_clamped_sumsq(int64_t n, float omega, const float* __restrict__ r, float* __restrict__ q,
+                                     double* __restrict__ out) {
+    const float w = fminf(fmaxf(omega, 0.0f), 1.0f);
+    double s = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float ri = r[i];
+        q[i] = q[i] + w * ri;
+        s += (double)ri * (double)ri;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ double part[OPS_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) part[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < OPS_BLOCK / 64; ++i) t += part[i];
+        atomicAdd(out, t);
+    }
+}
+
 inline dim3 grid2(int64_t n, int nv) { return dim3(ibh_grid(n, OPS_BLOCK) > 4096 ? 4096 : ibh_grid(n, OPS_BLOCK), nv); }
 
 // launch of the accumulation kernels: per (row, field) for one field, per row over blocks of up to 4 fields otherwise
@@ -670,6 +692,15 @@ int ibh_axpy_clamped(int64_t n, float omega, const float* r, float* q) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_axpy_clamped, dim3(ibh_grid(n, OPS_BLOCK) > 2048 ? 2048 : ibh_grid(n, OPS_BLOCK)),
                        dim3(OPS_BLOCK), 0, ibh_stream, n, omega, r, q);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_axpy_clamped_sumsq(int64_t n, float omega, const float* r, float* q, double* out) {
+    IBH_REQUIRE(out, "ibh_axpy_clamped_sumsq: null argument");
+    IBH_HIP(hipMemsetAsync(out, 0, sizeof(double), ibh_stream));
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_axpy_clamped_sumsq, dim3(ibh_grid(n, OPS_BLOCK) > 2048 ? 2048 : ibh_grid(n, OPS_BLOCK)),
+                       dim3(OPS_BLOCK), 0, ibh_stream, n, omega, r, q, out);
     IBH_LAUNCH_CHECK();
     return 0;
 }

@@ -43,6 +43,20 @@ def _update(Q, omega, r):
     B.call("ibh_axpy_clamped", int(Q.numel()), C.c_float(float(omega)), B._ptr(rf), B._ptr(Q))
 
 
+def _update_norm(Q, omega, r):
+    """``_update`` and ``_norm(r)`` in one pass over ``r`` (``ibh_axpy_clamped_sumsq``); None if the arrays do not allow it."""
+    if isinstance(omega, torch.Tensor):
+        return None
+    Qf, _, ldq = B._field(Q)
+    rf, _, ldr = B._field(r)
+    if Qf.data_ptr() != Q.data_ptr() or (Q.ndim == 2 and (ldq != Q.shape[0] or ldr != r.shape[0])) or Q.shape != r.shape:
+        return None
+    out = torch.empty(1, dtype=torch.float64, device=r.device)
+    B._stream()
+    B.call("ibh_axpy_clamped_sumsq", int(Q.numel()), C.c_float(float(omega)), B._ptr(rf), B._ptr(Q), B._ptr(out))
+    return float(out.item()) ** 0.5
+
+
 def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level=0, n_iter=50,
         rtol=1e-1, atol=1e-7, norm=None, check_every=1, exchange=None, level_norm=None):
     """``FAS!(f, Q; coarseners, prolongators, perscribed_f, multigrid_level, n_iter, rtol, atol)``.
@@ -58,6 +72,7 @@ def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level
     residual evaluation and around the coarse solve, where the prolongation reads coarse skirt rows -- and
     ``level_norm(level, r)`` is the norm over the owned cells of all ranks (``Reductions.norm`` of that level).
     """
+    local_norm = level_norm is None and norm is None      # the library's own norm: fused with the update below
     if level_norm is not None:
         def _norm(r, _l=multigrid_level):
             return level_norm(_l, r)
@@ -90,9 +105,12 @@ def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level
         r, omega = f(l, Q)
         if source is not None:
             r = r + source
-        _update(Q, omega, r)
-        if (it + 1) % check_every == 0 or it == n_iter - 1:
-            nr = _norm(r)
+        check = (it + 1) % check_every == 0 or it == n_iter - 1
+        fused = _update_norm(Q, omega, r) if (check and local_norm) else None
+        if fused is None:
+            _update(Q, omega, r)
+        if check:
+            nr = fused if fused is not None else _norm(r)
             if nr < nr0 * rtol + atol:
                 break
     return nr / (nr0 + _eps32)

@@ -353,6 +353,8 @@ int ibh_axpy_clamped(int64_t n, float omega, const float* r, float* q);
 int ibh_axpy(int64_t n, float a, const float* x, float* y);
 /* *out (device, double) = sum(x^2) */
 int ibh_sumsq(int64_t n, const float* x, double* out);
+/* q += clamp(omega,0,1) * r and *out = sum(r^2) in one pass (solver.jl:82 + the norm of :84 on the same array) */
+int ibh_axpy_clamped_sumsq(int64_t n, float omega, const float* r, float* q, double* out);
 
 /* FlowBC call (cfd.jl:243-300): boundary state [p T u v (w)] from the image-point primitives P and the unit normals.
  * u_inf: nd components, or ONE component (the normal velocity) when normal_flow != 0.  image_distances / dudn: both
