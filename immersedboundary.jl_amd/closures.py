@@ -24,13 +24,11 @@ def euler_wray_agarwal_residual(part, Q, nu=1.5e-5, out=None):
     r = out if out is not None else B.colmajor_empty(Q.shape[0], nvp + 1)
     B.residual_euler_hll(part, Q[:, :nvp], out=r[:, :nvp])
     R = Q[:, nvp].contiguous()
-    vel = [Q[:, 2 + i].contiguous() for i in range(nd)]
-    # cell_gradient(part, u): the tuple form, one sweep per field for all dimensions
-    gu = [list(B.cell_gradient(part, vel[i])) for i in range(nd)]
-    S = T.shear_rate(gu)
-    gR = B.cell_gradient_array(part, R)      # (nc, nd): the buffer of the tuple form, no copies
-    gS = B.cell_gradient_array(part, S)
-    wa = T.Wray_Agarwal(R, S, gR, gS)
+    # S = shear_rate(cell_gradient(part, u_i) ...); Wray_Agarwal(R, S, cell_gradient(part, R), cell_gradient(part, S)):
+    # one launch each where the partition is made of complete blocks (the gradients are consumed where they are made),
+    # the operator-by-operator composition elsewhere
+    S = T.shear_rate_of_velocity(part, Q[:, 2:2 + nd])
+    wa = T.Wray_Agarwal_of(part, R, S)
     # S + sum_d green_gauss(at_faces(nu + nuR) .* face_gradient(R) .- at_faces(u_d .* R)) in one launch, straight into r
     T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"], out=r[:, nvp])
     return r

@@ -1364,6 +1364,73 @@ __device__ __forceinline__ void passA_wave_nv(const BlockDesc3* __restrict__ blo
 }
 
 
+// gradients of NV cell fields of one block in registers, g[v][k][d] (plane k of this lane's column, dimension d): the
+// arithmetic of passA_wave_nv without the stores and the sensor -- for kernels that consume the gradients where they
+// are made (shear rate of a velocity field, the Wray-Agarwal closure: ibh_fused.hip).  Blocks without GENERAL sides only.
+template <int NV>
+__device__ __forceinline__ void wave_gradients(const BlockDesc3& bb, const int32_t* __restrict__ htab,
+                                               const int32_t* __restrict__ ftab, int32_t blk, const float* const* F,
+                                               float* lds, int lane, float (&g)[NV][8][3]) {
+    float* tile = lds;          // [k][lane]
+    float* Hm = lds + 512;      // [side][t]: mean neighbour value across the side
+    uint32_t hid[6];
+    hid[0] = halo_cell3s<0>(bb, htab, blk, lane);
+    hid[1] = halo_cell3s<1>(bb, htab, blk, lane);
+    hid[2] = halo_cell3s<2>(bb, htab, blk, lane);
+    hid[3] = halo_cell3s<3>(bb, htab, blk, lane);
+    hid[4] = halo_cell3s<4>(bb, htab, blk, lane);
+    hid[5] = halo_cell3s<5>(bb, htab, blk, lane);
+    const int i = lane & 7, j = lane >> 3;
+    const bool e0 = i == 0, e1 = i == 7, e2 = j == 0, e3 = j == 7;
+    const float q0 = e0 ? bb.q[0] : 0.5f, q1 = e1 ? bb.q[1] : 0.5f, q2 = e2 ? bb.q[2] : 0.5f, q3 = e3 ? bb.q[3] : 0.5f;
+    float uka[NV][8], hva[NV][6];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) uka[v][k] = ldg(F[v], (uint32_t)bb.base + lane + 64 * k);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) hva[v][s] = ldg(F[v], hid[s]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float* u = F[v];
+        if (v) blk2::wave_lds_sync();  // the previous field's LDS reads are done
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[k * 64 + lane] = uka[v][k];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            float vm = hva[v][s];
+            if (bb.type[s] == SIDE_FINE) {  // wave-uniform: three more fine cells behind this slot
+                const int32_t* ft = ftab + (((size_t)bb.fine * 6 + s) * 64 + lane) * 3;
+                const float v1 = ldg(u, (uint32_t)ft[0]), v2 = ldg(u, (uint32_t)ft[1]), v3 = ldg(u, (uint32_t)ft[2]);
+                vm = 0.25f * (hva[v][s] + v1 + v2 + v3);
+            }
+            Hm[s * 64 + lane] = vm;
+        }
+        blk2::wave_lds_sync();
+        const float zlm = Hm[4 * 64 + lane], zhm = Hm[5 * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float uc = uka[v][k];
+            const float* tk = tile + k * 64;
+            float vm[6];
+            vm[0] = e0 ? Hm[0 * 64 + j + 8 * k] : tk[lane - 1];
+            vm[1] = e1 ? Hm[1 * 64 + j + 8 * k] : tk[lane + 1];
+            vm[2] = e2 ? Hm[2 * 64 + i + 8 * k] : tk[lane - 8];
+            vm[3] = e3 ? Hm[3 * 64 + i + 8 * k] : tk[lane + 8];
+            vm[4] = k == 0 ? zlm : uka[v][k > 0 ? k - 1 : 0];
+            vm[5] = k == 7 ? zhm : uka[v][k < 7 ? k + 1 : 7];
+            const float ql[3] = {q0, q2, k == 0 ? bb.q[4] : 0.5f}, qh[3] = {q1, q3, k == 7 ? bb.q[5] : 0.5f};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float fr = uc + qh[d] * (vm[2 * d + 1] - uc);
+                const float fl = uc + ql[d] * (vm[2 * d] - uc);
+                g[v][k][d] = (fr - fl) * bb.rh[d];
+            }
+        }
+    }
+}
+
 #pragma clang fp contract(off)
 
 }  // namespace blk3

@@ -1074,6 +1074,69 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_euler(PartView p, const floa
     passB_euler_cell<ND>(p, P, ldp, G, R, ldr, Rgas, gamma, c);
 }
 
+// ---- closures of a turbulence model on an all-block 3-D partition, gradients consumed where they are made (one wavefront
+// per 8^3 block, blk3::wave_gradients: the arithmetic of the tuple cell_gradient's block sweep; the pointwise formulas are
+// those of ibh_turb.hip, evaluated without contraction):
+//   k_shear_of_velocity3: S = shear_rate(cell_gradient(u), cell_gradient(v), cell_gradient(w))      (turbulence.jl:110-124)
+//   k_wray_agarwal_of3:   (nut, nuR, S) = Wray_Agarwal(R, S, cell_gradient(R), cell_gradient(S))    (turbulence.jl:222-241)
+// 12 B in + 4 B out per cell instead of 3 x (4 in + 16 out) + 36 in + 4 out; 8 in + 12 out instead of 2 x 20 + 44.
+template <int NV>
+struct FieldPtrs {
+    const float* f[NV];
+};
+__global__ __launch_bounds__(256) void k_shear_of_velocity3(const BlockDesc3* __restrict__ blocks,
+                                                            const int32_t* __restrict__ htab,
+                                                            const int32_t* __restrict__ ftab, int32_t nblk, int32_t nwg,
+                                                            FieldPtrs<3> V, float* __restrict__ S) {
+    __shared__ float lds[4 * BLK3W_PASSA_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * 4 + wave);
+    if (blk >= nblk) return;
+    const BlockDesc3 bb = blocks[blk];
+    float g[3][8][3];
+    blk3::wave_gradients<3>(bb, htab, ftab, blk, V.f, lds + wave * BLK3W_PASSA_LDS, lane, g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float t = (g[i][k][j] + g[j][k][i]) / 2.0f;
+                s = s + t * t;
+            }
+        S[(uint32_t)bb.base + lane + 64 * k] = sqrtf(2.0f * s);
+    }
+}
+__global__ __launch_bounds__(256) void k_wray_agarwal_of3(const BlockDesc3* __restrict__ blocks,
+                                                          const int32_t* __restrict__ htab,
+                                                          const int32_t* __restrict__ ftab, int32_t nblk, int32_t nwg,
+                                                          FieldPtrs<2> RS, float sigmaR, float C1, float kappa,
+                                                          float* __restrict__ nut, float* __restrict__ nuR,
+                                                          float* __restrict__ Sout) {
+    __shared__ float lds[4 * BLK3W_PASSA_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * 4 + wave);
+    if (blk >= nblk) return;
+    const BlockDesc3 bb = blocks[blk];
+    float g[2][8][3];
+    blk3::wave_gradients<2>(bb, htab, ftab, blk, RS.f, lds + wave * BLK3W_PASSA_LDS, lane, g);
+    const float C2 = sigmaR + C1 / (kappa * kappa);
+    constexpr float EPS32 = 1.1920929e-07f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t c = (uint32_t)bb.base + lane + 64 * k;
+        float dot = g[0][k][0] * g[1][k][0];
+        dot = dot + g[0][k][1] * g[1][k][1];
+        dot = dot + g[0][k][2] * g[1][k][2];
+        const float r = RS.f[0][c], s = RS.f[1][c];
+        const float src = C1 * r * s + C2 * dot * (r / (s + EPS32));
+        nut[c] = r;
+        nuR[c] = r * sigmaR;
+        Sout[c] = fminf(src, 10.0f * r);
+    }
+}
+
 // 1: wave-per-block form of the 3-D scalar pass A (IBH_3D_WAVE=0 for the 512-thread form, A/B)
 const int ibh_3d_wave = getenv("IBH_3D_WAVE") ? atoi(getenv("IBH_3D_WAVE")) : 1;
 // blocks per wave of the single-kernel sweep; 0 = automatic (IBH_SWEEP_ITERS overrides, for tuning)
@@ -1511,6 +1574,35 @@ int ibh_cell_gradient_nd(ibh_part* p, const float* u, int nv, int64_t ldu, float
             IBH_HIP(hipMemcpyAsync(sensor + (size_t)v * lds, p->G + (size_t)nd * p->nc, sizeof(float) * p->nc,
                                    hipMemcpyDeviceToDevice, ibh_stream));
     }
+    return 0;
+}
+
+// every cell of the partition in a complete 8^3 block without a GENERAL side (what the fused closures below need)
+static bool all_blocks3(const ibh_part* p) {
+    return p->nd == 3 && p->bs == 8 && p->blocks3 && p->nblk > 0 && p->n_irr == 0 && (int64_t)p->nblk * 512 == p->nc &&
+           p->info[6] == 0;
+}
+int ibh_shear_rate_of_velocity(ibh_part* p, const float* vel, int64_t ldv, float* S) {
+    IBH_REQUIRE(p && vel && S, "ibh_shear_rate_of_velocity: null argument");
+    IBH_REQUIRE(all_blocks3(p), "ibh_shear_rate_of_velocity: needs a 3-D partition made of complete blocks (compose "
+                                "cell_gradient and shear_rate otherwise)");
+    FieldPtrs<3> V{{vel, vel + ldv, vel + 2 * ldv}};
+    const int32_t nwg = (p->nblk + 3) / 4;
+    hipLaunchKernelGGL(k_shear_of_velocity3, dim3(nwg), dim3(256), 0, ibh_stream, p->blocks3, p->htab3, p->ftab3, p->nblk, nwg,
+                       V, S);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_wray_agarwal_of(ibh_part* p, const float* R, const float* S, float sigmaR, float C1, float kappa, float* nut,
+                        float* nuR, float* Sout) {
+    IBH_REQUIRE(p && R && S && nut && nuR && Sout, "ibh_wray_agarwal_of: null argument");
+    IBH_REQUIRE(all_blocks3(p), "ibh_wray_agarwal_of: needs a 3-D partition made of complete blocks (compose cell_gradient "
+                                "and Wray_Agarwal otherwise)");
+    FieldPtrs<2> RS{{R, S}};
+    const int32_t nwg = (p->nblk + 3) / 4;
+    hipLaunchKernelGGL(k_wray_agarwal_of3, dim3(nwg), dim3(256), 0, ibh_stream, p->blocks3, p->htab3, p->ftab3, p->nblk, nwg,
+                       RS, sigmaR, C1, kappa, nut, nuR, Sout);
+    IBH_LAUNCH_CHECK();
     return 0;
 }
 

@@ -104,6 +104,47 @@ def Wray_Agarwal(R, S, gradR, gradS, sigmaR=0.72, C1=0.0829, kappa=0.41):
     return dict(zip(("nut", "nuR", "S"), out))
 
 
+def all_blocks(part):
+    """True where every cell of the partition lies in a complete 8^3 block without a GENERAL side: the fused closures below
+    (gradients consumed where they are made) apply; elsewhere they compose the operators, same result."""
+    part = B._part(part)
+    i = part.info
+    return (part.nd == 3 and i["full_blocks"] > 0 and i["full_blocks"] * 512 == part.nc and i["irregular_cells"] == 0
+            and i["sides_general"] == 0)
+
+
+def shear_rate_of_velocity(part, vel):
+    """``shear_rate([cell_gradient(part, vel[:, i]) ...])`` (:110-124 over the tuple ``cell_gradient``,
+    ImmersedBoundary.jl:980-988): ONE launch on an all-block 3-D partition (``ibh_shear_rate_of_velocity``), the composition
+    elsewhere -- bit-identical."""
+    part = B._part(part)
+    v, nd, ldv = B._field(vel, part.nc)
+    if nd != part.nd:
+        raise ValueError("vel must be (nc, nd)")
+    if all_blocks(part):
+        S = B.colmajor_empty(part.nc)
+        B._stream()
+        B.call("ibh_shear_rate_of_velocity", part.handle, B._ptr(v), ldv, B._ptr(S))
+        return S
+    return shear_rate([list(B.cell_gradient(part, vel[:, i].contiguous())) for i in range(nd)])
+
+
+def Wray_Agarwal_of(part, R, S, sigmaR=0.72, C1=0.0829, kappa=0.41):
+    """``Wray_Agarwal(R, S, cell_gradient(part, R), cell_gradient(part, S))`` (:222-241): ONE launch on an all-block 3-D
+    partition (``ibh_wray_agarwal_of``), the composition elsewhere -- bit-identical."""
+    part = B._part(part)
+    R = _vec(R, part.nc)
+    S = _vec(S, part.nc)
+    if all_blocks(part):
+        out = [B.colmajor_empty(part.nc) for _ in range(3)]
+        B._stream()
+        B.call("ibh_wray_agarwal_of", part.handle, B._ptr(R), B._ptr(S), _f(sigmaR), _f(C1), _f(kappa),
+               *[B._ptr(o) for o in out])
+        return dict(zip(("nut", "nuR", "S"), out))
+    return Wray_Agarwal(R, S, B.cell_gradient_array(part, R), B.cell_gradient_array(part, S), sigmaR=sigmaR, C1=C1,
+                        kappa=kappa)
+
+
 def scalar_transport(part, R, nuR, vel, nu, S, out=None):
     """``S + sum_d green_gauss(part, at_faces(part, nu .+ nuR, d) .* face_gradient(part, R, d) .- at_faces(part, vel[:, d] .* R, d), d)``
     in one launch (``ibh_scalar_transport``): the transport terms of a one-equation turbulence model, bit-identical to the

@@ -115,3 +115,40 @@ def test_scalar_transport_is_the_operator_composition(rae_domains):
             diff = ibamd.at_faces(dpart, float(nu) + nuR, d + 1) * ibamd.face_gradient(dpart, R, d + 1)
             rt += ibamd.green_gauss(dpart, diff - conv, d + 1)
         assert torch.equal(got, rt)
+
+
+@pytest.mark.gpu
+def test_fused_closures_on_an_all_block_octree_are_the_composition():
+    """``ibh_shear_rate_of_velocity`` / ``ibh_wray_agarwal_of`` (gradients consumed inside the block sweep, 3-D partition of
+    complete 8^3 blocks with SAME / MIRROR / COARSE / FINE sides) against the same closures composed from
+    ``cell_gradient`` + the pointwise kernels -- bit for bit -- and, on a partition with skirt fragments (where the fused
+    kernels do not apply), that the wrappers take the composition."""
+    import torch
+    import ibamd
+    from ibamd import Ball, Mesh
+    from ibamd import turbulence as T
+    msh = Mesh(f32([-2, -2, -2]), f32([4, 4, 4]), block_size=8,
+               refinement_regions=[(Ball(np.array([1.2, 1.2, 1.2]), 0.1), f32(0.1))])
+    n = len(msh)
+    rng = np.random.default_rng(21)
+    for nparts in (1, 2):
+        mps = -(-(-(-n // nparts)) // 512) * 512
+        dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=False)
+        part = dom.partitions[1]
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        assert T.all_blocks(dpart) == (nparts == 1)
+        nc = part.centers.shape[0]
+        X = part.centers
+        vel_h = np.stack([np.sin(2 * X[:, 0]) * np.cos(X[:, 1]), np.cos(X[:, 2] + X[:, 0]), X[:, 1] * X[:, 2]],
+                         axis=1).astype(f32) + f32(0.05) * rng.standard_normal((nc, 3)).astype(f32)
+        vel = ibamd.hip(vel_h)
+        R = ibamd.hip((4.5e-5 * (1 + 0.5 * rng.uniform(0, 1, nc))).astype(f32))
+        S_fused = T.shear_rate_of_velocity(dpart, vel)
+        gu = [list(ibamd.cell_gradient(dpart, vel[:, i].contiguous())) for i in range(3)]
+        S_comp = T.shear_rate(gu)
+        assert torch.equal(S_fused, S_comp)
+        assert float(S_comp.abs().max()) > 0
+        wa_f = T.Wray_Agarwal_of(dpart, R, S_comp)
+        wa_c = T.Wray_Agarwal(R, S_comp, ibamd.cell_gradient_array(dpart, R), ibamd.cell_gradient_array(dpart, S_comp))
+        for k in ("nut", "nuR", "S"):
+            assert torch.equal(wa_f[k], wa_c[k]), k
