@@ -502,7 +502,7 @@ int ibh_acc_create(ibh_acc** out, int32_t n_output, int32_t n_input, const int32
 
 int ibh_acc_destroy(ibh_acc* a) {
     if (!a) return 0;
-    hipFree(a->off); hipFree(a->idx); hipFree(a->w);
+    hipFree(a->off); hipFree(a->idx); hipFree(a->w); hipFree(a->packed);
     delete a;
     return 0;
 }

@@ -146,6 +146,7 @@ struct ibh_acc {
     int32_t n_out = 0, n_in = 0;
     int32_t *off = nullptr, *idx = nullptr;
     float* w = nullptr;
+    float* packed = nullptr;  // [n_in][8] scratch of ibh_accumulate_diff_add: the fields of a donor side by side
 };
 
 struct ibh_bc {

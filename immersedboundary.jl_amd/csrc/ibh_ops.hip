@@ -378,6 +378,68 @@ __global__ void k_accumulate_rows(int32_t n_out, const int32_t* __restrict__ off
     }
 }
 
+// out .+= acc(a .- b) for up to 8 fields with the donors' fields side by side: a pre-pass writes d[j][0..7] = a[j, :] - b[j, :]
+// (32 bytes per donor), the row kernel then takes a donor with TWO 16-byte gathers instead of two 4-byte gathers per field
+// (6 fields x 8 donors: 16 gather instructions per row instead of 96) -- same differences, same products, same order.
+__global__ void k_pack_diff8(int32_t n_in, int nv, const float* __restrict__ a, const float* __restrict__ b, int64_t ld,
+                             float* __restrict__ d) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < (int64_t)n_in * 8; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = t >> 3;
+        const int q = (int)(t & 7);
+        d[t] = q < nv ? a[j + (int64_t)q * ld] - b[j + (int64_t)q * ld] : 0.0f;
+    }
+}
+template <int NV>
+__global__ void k_accumulate_packed_add(int32_t n_out, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                        const float* __restrict__ w, const float4* __restrict__ d, float* __restrict__ out,
+                                        int64_t ldo) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t b = off[r], e = off[r + 1];
+        float s[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[q] = 0.0f;
+        int32_t k = b;
+        if ((b & 3) == 0)
+            for (; k + 4 <= e; k += 4) {
+                const int4 j4 = *reinterpret_cast<const int4*>(idx + k);
+                const float4 w4 = *reinterpret_cast<const float4*>(w + k);
+                const int32_t jj[4] = {j4.x, j4.y, j4.z, j4.w};
+                const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                float4 lo[4], hi[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] = d[2 * (int64_t)jj[i]];
+                    if (NV > 4) hi[i] = d[2 * (int64_t)jj[i] + 1];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x[8] = {lo[i].x, lo[i].y, lo[i].z, lo[i].w, NV > 4 ? hi[i].x : 0.0f, NV > 4 ? hi[i].y : 0.0f,
+                                        NV > 4 ? hi[i].z : 0.0f, NV > 4 ? hi[i].w : 0.0f};
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) {
+                        const float t = x[q] * ww[i];
+                        s[q] = (k + i == b) ? t : s[q] + t;
+                    }
+                }
+            }
+        for (; k < e; ++k) {
+            const int64_t j = idx[k];
+            const float wk = w[k];
+            const float4 lo = d[2 * j];
+            float4 hi = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (NV > 4) hi = d[2 * j + 1];
+            const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const float t = x[q] * wk;
+                s[q] = (k == b) ? t : s[q] + t;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) out[r + (int64_t)q * ldo] = out[r + (int64_t)q * ldo] + s[q];
+    }
+}
+
 // a[ghost] = eta*ia + (1-eta)*ba (:1242-1245); ba from array, constant, or ia (copy BC)
 __global__ void k_bc_blend(int32_t ng, const int32_t* __restrict__ ghost, const float* __restrict__ eta,
                            float* __restrict__ a, int64_t lda, const float* __restrict__ ia, int64_t ldi,
@@ -637,6 +699,29 @@ int ibh_accumulate_diff_add(const ibh_acc* a, const float* v, const float* v2, i
     IBH_REQUIRE(a && v && v2 && out, "ibh_accumulate_diff_add: null argument");
     CHECK_NV(nv);
     if (a->n_out == 0) return 0;
+    if (a->w && nv >= 2 && nv <= 8 && (int64_t)a->n_out >= 4 * (int64_t)a->n_in) {
+        // many rows per donor (a prolongation): pack the donors' differences once, gather them 16 bytes at a time
+        ibh_acc* am = const_cast<ibh_acc*>(a);
+        if (!am->packed) IBH_HIP(hipMalloc((void**)&am->packed, sizeof(float) * 8 * (size_t)a->n_in));
+        hipLaunchKernelGGL(k_pack_diff8, grid2((int64_t)a->n_in * 8, 1), dim3(OPS_BLOCK), 0, ibh_stream, a->n_in, nv, v, v2,
+                           ldv, am->packed);
+        const float4* d4 = reinterpret_cast<const float4*>(am->packed);
+#define PACKED_LAUNCH(N)                                                                                               \
+    hipLaunchKernelGGL(k_accumulate_packed_add<N>, grid2(a->n_out, 1), dim3(OPS_BLOCK), 0, ibh_stream, a->n_out, a->off,  \
+                       a->idx, a->w, d4, out, ldo)
+        switch (nv) {
+            case 2: PACKED_LAUNCH(2); break;
+            case 3: PACKED_LAUNCH(3); break;
+            case 4: PACKED_LAUNCH(4); break;
+            case 5: PACKED_LAUNCH(5); break;
+            case 6: PACKED_LAUNCH(6); break;
+            case 7: PACKED_LAUNCH(7); break;
+            default: PACKED_LAUNCH(8); break;
+        }
+#undef PACKED_LAUNCH
+        IBH_LAUNCH_CHECK();
+        return 0;
+    }
     for (int v0 = 0; v0 < nv; v0 += 8) {
         const int nb = nv - v0 < 8 ? nv - v0 : 8;
         hipLaunchKernelGGL((k_accumulate_rows<8, true>), grid2(a->n_out, 1), dim3(OPS_BLOCK), 0, ibh_stream, a->n_out, a->off,

@@ -30,6 +30,31 @@ def test_unweighted_accumulator():
     assert np.array_equal(out, np.array([[6, 60], [3, 30]], dtype=f32))
 
 
+@pytest.mark.parametrize("nv", [1, 3, 6, 8, 11])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_accumulate_diff_add_is_the_three_operations(nv, ragged):
+    """``out .+= acc(a .- b)`` in one call (``ibh_accumulate_diff_add``: the prolongation step of FAS!, solver.jl:76) against
+    ``out += acc(a - b)`` through the separate kernels, bit for bit: rows of eight entries (the packed-donor form for 2..8
+    fields: many rows per donor), ragged rows incl. empty ones, and more fields than one pass takes."""
+    rng = np.random.default_rng(100 + nv)
+    n_in, n_out = 500, 4000
+    cnt = rng.integers(0, 12, n_out) if ragged else np.full(n_out, 8)
+    idx = [rng.integers(0, n_in, c).tolist() for c in cnt]
+    w = [rng.uniform(0.05, 1.0, c).astype(f32).tolist() for c in cnt]
+    acc = ibamd.to_backend(ibamd.Accumulator(idx, w, n_input=n_in))
+    a, b = rng.standard_normal((n_in, nv)).astype(f32), rng.standard_normal((n_in, nv)).astype(f32)
+    o0 = rng.standard_normal((n_out, nv)).astype(f32)
+    if nv == 1:
+        a, b, o0 = a[:, 0], b[:, 0], o0[:, 0]
+    da, db = ibamd.hip(a), ibamd.hip(b)
+    got = ibamd.hip(o0)
+    acc.diff_add(got, da, db)
+    ref = ibamd.hip(o0)
+    ref += acc(da - db)
+    assert torch.equal(got, ref)
+    assert not torch.equal(got, ibamd.hip(o0))
+
+
 def test_row_major_and_strided_fields_are_accepted(adv_domains):
     dp, do = adv_domains
     part, opart = dp.partitions[2], do.partitions[2]
