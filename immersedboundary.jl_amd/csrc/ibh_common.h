@@ -173,6 +173,11 @@ struct ibh_bcset {
     int32_t* mode = nullptr;
 };
 
+// internal: face-list forms of the fused turbulence closures (ibh_ops.hip), dispatched from ibh_fused.hip
+extern "C" int ibh_shear_rate_of_velocity_cells(const ibh_part* p, const float* vel, int64_t ldv, float* S);
+extern "C" int ibh_wray_agarwal_of_cells(const ibh_part* p, const float* R, const float* S, float sigmaR, float C1,
+                                         float kappa, float* nut, float* nuR, float* Sout);
+
 // thread-local state
 extern thread_local std::string ibh_err;
 extern thread_local hipStream_t ibh_stream;

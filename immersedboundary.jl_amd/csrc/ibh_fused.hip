@@ -83,17 +83,39 @@ __device__ __forceinline__ void passA_cell(const PartView& p, const float* __res
                                            float* __restrict__ G, int32_t c) {
     const int64_t nc = p.nc;
     float D = 1e-7f;
+    float uc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) uc[v] = u[c + v * ldu];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
         const DimData& dd = p.dim[d];
         const float* h = p.spacing + d * nc;
         float hc = h[c];
-        float sr[NV], sl[NV];
-        float dr = 0.f, ar = 0.f, dl = 0.f, al = 0.f;
+        float s2[2][NV];
+        float ds[2] = {0.f, 0.f}, as[2] = {0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < NV; ++v) sr[v] = sl[v] = 0.f;
-        {
-            const SideIter it = side_iter(p, d, 1, c);
+        for (int side = 1; side >= 0; --side) {   // right faces, then left faces
+            float* s = s2[side];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s[v] = 0.f;
+            const SideIter it = side_iter(p, d, side, c);
+            if (it.direct) {
+                // one face: own values from registers, the cell across gathered (weight 1.0f / 1)
+                const int32_t x = side ? it.n : it.o;
+                const float hx = h[x];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float ux = u[x + v * ldu];
+                    const float uo = side ? uc[v] : ux, un = side ? ux : uc[v];
+                    s[v] = face_avg(uo, un, side ? hc : hx, side ? hx : hc) * 1.0f;
+                    if (v == 0) {
+                        const float df = un - uo;
+                        ds[side] = df * 1.0f;
+                        as[side] = fabsf(df) * 1.0f;
+                    }
+                }
+                continue;
+            }
             const int32_t b = it.b, e = it.e;
             float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
             for (int32_t k = b; k < e; ++k) {
@@ -104,42 +126,20 @@ __device__ __forceinline__ void passA_cell(const PartView& p, const float* __res
                 for (int v = 0; v < NV; ++v) {
                     float uo = u[o + v * ldu], un = u[n + v * ldu];
                     float t = face_avg(uo, un, ho, hn) * w;
-                    sr[v] = (k == b) ? t : sr[v] + t;
+                    s[v] = (k == b) ? t : s[v] + t;
                     if (v == 0) {
                         float df = un - uo;
                         float td = df * w, ta = fabsf(df) * w;
-                        dr = (k == b) ? td : dr + td;
-                        ar = (k == b) ? ta : ar + ta;
-                    }
-                }
-            }
-        }
-        {
-            const SideIter it = side_iter(p, d, 0, c);
-            const int32_t b = it.b, e = it.e;
-            float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
-            for (int32_t k = b; k < e; ++k) {
-                int32_t o, n;
-                side_face(dd, it, k, o, n);
-                float ho = h[o], hn = h[n];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    float uo = u[o + v * ldu], un = u[n + v * ldu];
-                    float t = face_avg(uo, un, ho, hn) * w;
-                    sl[v] = (k == b) ? t : sl[v] + t;
-                    if (v == 0) {
-                        float df = un - uo;
-                        float td = df * w, ta = fabsf(df) * w;
-                        dl = (k == b) ? td : dl + td;
-                        al = (k == b) ? ta : al + ta;
+                        ds[side] = (k == b) ? td : ds[side] + td;
+                        as[side] = (k == b) ? ta : as[side] + ta;
                     }
                 }
             }
         }
 #pragma unroll
-        for (int v = 0; v < NV; ++v) G[(int64_t)(d * NV + v) * nc + c] = (sr[v] - sl[v]) / hc;
-        float gg = (dr - dl) / hc;
-        float ugg = (ar + al) / hc;
+        for (int v = 0; v < NV; ++v) G[(int64_t)(d * NV + v) * nc + c] = (s2[1][v] - s2[0][v]) / hc;
+        float gg = (ds[1] - ds[0]) / hc;
+        float ugg = (as[1] + as[0]) / hc;
         D = fmaxf(D, (1e-7f + fabsf(gg)) / (1e-7f + ugg));
     }
     G[(int64_t)(ND * NV) * nc + c] = D;
@@ -193,20 +193,46 @@ __device__ __forceinline__ void passB_euler_cell(const PartView& p, const float*
     constexpr int NV = ND + 2;
     const int64_t nc = p.nc;
     const float* Ds = G + (int64_t)(ND * NV) * nc;
-    float res[NV];
+    float res[NV], Pc[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) res[v] = 0.0f;
+    for (int v = 0; v < NV; ++v) {
+        res[v] = 0.0f;
+        Pc[v] = P[c + v * ldp];
+    }
+    const float Dc = Ds[c];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
         const DimData& dd = p.dim[d];
         const float* h = p.spacing + d * nc;
         double fr[NV], fl[NV];
+        float dPc[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) fr[v] = fl[v] = 0.0;
+        for (int v = 0; v < NV; ++v) {
+            fr[v] = fl[v] = 0.0;
+            dPc[v] = G[(int64_t)(d * NV + v) * nc + c];
+        }
+        const float hcf = h[c];
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             double* acc = side ? fr : fl;
             const SideIter it = side_iter(p, d, side, c);
+            if (it.direct) {
+                // one face: the cell's own values are in registers, only the cell across is gathered (weight 1.0f / 1)
+                const int32_t x = side ? it.n : it.o;
+                float Px[NV], dPx[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    Px[v] = P[x + v * ldp];
+                    dPx[v] = G[(int64_t)(d * NV + v) * nc + x];
+                }
+                const float Dx = Ds[x], hx = h[x];
+                double F[NV];
+                if (side) euler_face_flux<ND>(Pc, Px, dPc, dPx, Dc, Dx, hcf, hx, d, Rgas, gamma, F);
+                else euler_face_flux<ND>(Px, Pc, dPx, dPc, Dx, Dc, hx, hcf, d, Rgas, gamma, F);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] = F[v] * (double)1.0f;
+                continue;
+            }
             const int32_t b = it.b, e = it.e;
             float w = (e > b) ? 1.0f / (float)(e - b) : 0.f;
             for (int32_t k = b; k < e; ++k) {
@@ -229,7 +255,7 @@ __device__ __forceinline__ void passB_euler_cell(const PartView& p, const float*
                 }
             }
         }
-        double hc = (double)h[c];
+        double hc = (double)hcf;
 #pragma unroll
         for (int v = 0; v < NV; ++v) res[v] = (float)((double)res[v] - (fr[v] - fl[v]) / hc);
     }
@@ -1582,10 +1608,16 @@ static bool all_blocks3(const ibh_part* p) {
     return p->nd == 3 && p->bs == 8 && p->blocks3 && p->nblk > 0 && p->n_irr == 0 && (int64_t)p->nblk * 512 == p->nc &&
            p->info[6] == 0;
 }
+// no block structure at all: the tuple cell_gradient is the face-list kernel there (ibh_cell_gradient_nd)
+static bool no_blocks(const ibh_part* p) {
+    return !(p->bs == 8 && p->nblk > 0 && (p->nd == 2 ? p->blocks2 != nullptr : p->blocks3 != nullptr));
+}
 int ibh_shear_rate_of_velocity(ibh_part* p, const float* vel, int64_t ldv, float* S) {
     IBH_REQUIRE(p && vel && S, "ibh_shear_rate_of_velocity: null argument");
-    IBH_REQUIRE(all_blocks3(p), "ibh_shear_rate_of_velocity: needs a 3-D partition made of complete blocks (compose "
-                                "cell_gradient and shear_rate otherwise)");
+    if (p->nc == 0) return 0;
+    if (no_blocks(p)) return ibh_shear_rate_of_velocity_cells(p, vel, ldv, S);
+    IBH_REQUIRE(all_blocks3(p), "ibh_shear_rate_of_velocity: needs a 3-D partition made of complete blocks or one without "
+                                "block structure (compose cell_gradient and shear_rate otherwise)");
     FieldPtrs<3> V{{vel, vel + ldv, vel + 2 * ldv}};
     const int32_t nwg = (p->nblk + 3) / 4;
     hipLaunchKernelGGL(k_shear_of_velocity3, dim3(nwg), dim3(256), 0, ibh_stream, p->blocks3, p->htab3, p->ftab3, p->nblk, nwg,
@@ -1596,8 +1628,10 @@ int ibh_shear_rate_of_velocity(ibh_part* p, const float* vel, int64_t ldv, float
 int ibh_wray_agarwal_of(ibh_part* p, const float* R, const float* S, float sigmaR, float C1, float kappa, float* nut,
                         float* nuR, float* Sout) {
     IBH_REQUIRE(p && R && S && nut && nuR && Sout, "ibh_wray_agarwal_of: null argument");
-    IBH_REQUIRE(all_blocks3(p), "ibh_wray_agarwal_of: needs a 3-D partition made of complete blocks (compose cell_gradient "
-                                "and Wray_Agarwal otherwise)");
+    if (p->nc == 0) return 0;
+    if (no_blocks(p)) return ibh_wray_agarwal_of_cells(p, R, S, sigmaR, C1, kappa, nut, nuR, Sout);
+    IBH_REQUIRE(all_blocks3(p), "ibh_wray_agarwal_of: needs a 3-D partition made of complete blocks or one without block "
+                                "structure (compose cell_gradient and Wray_Agarwal otherwise)");
     FieldPtrs<2> RS{{R, S}};
     const int32_t nwg = (p->nblk + 3) / 4;
     hipLaunchKernelGGL(k_wray_agarwal_of3, dim3(nwg), dim3(256), 0, ibh_stream, p->blocks3, p->htab3, p->ftab3, p->nblk, nwg,

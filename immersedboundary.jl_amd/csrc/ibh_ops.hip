@@ -194,6 +194,73 @@ __global__ __launch_bounds__(OPS_BLOCK) void k_timestep_advection(int32_t nc, Gr
     }
 }
 
+// gradient of one field at cell c in every dimension: the expressions of k_cell_gradient_all
+template <int ND>
+__device__ __forceinline__ void cell_gradient_at(const GradDims& G, const int32_t (&sd)[2 * ND], int32_t nc, int32_t c,
+                                                 const float* __restrict__ uv, float (&g)[ND]) {
+    const float uc = uv[c];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const float hc = G.h[d][c];
+        const int32_t l = sd[2 * d], r = sd[2 * d + 1];
+        float ar, al;
+        if (r >= 0) ar = face_avg(uc, uv[r], hc, G.h[d][r]) * 1.0f;
+        else if (r == -2) ar = 0.0f;
+        else ar = csr_mean_face_avg(G.d[d].roff, G.d[d].ridx, c, G.d[d].owners, G.d[d].neighbors, G.h[d], uv);
+        if (l >= 0) al = face_avg(uv[l], uc, G.h[d][l], hc) * 1.0f;
+        else if (l == -2) al = 0.0f;
+        else al = csr_mean_face_avg(G.d[d].loff, G.d[d].lidx, c, G.d[d].owners, G.d[d].neighbors, G.h[d], uv);
+        g[d] = (ar - al) / hc;
+    }
+}
+// shear_rate of the gradients of a velocity field / Wray_Agarwal of the gradients of (R, S), face-list partitions: thread per
+// cell, the gradients never leave the registers (same expressions as k_cell_gradient_all + ibh_turb.hip's k_shear /
+// k_wray_agarwal: bit-identical to the composition)
+template <int ND>
+__global__ void k_shear_of_velocity_cells(int32_t nc, GradDims G, const float* __restrict__ vel, int64_t ldv,
+                                          float* __restrict__ S) {
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        int32_t sd[2 * ND];
+#pragma unroll
+        for (int s = 0; s < 2 * ND; ++s) sd[s] = G.side[(int64_t)s * nc + c];
+        float g[ND][ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) cell_gradient_at<ND>(G, sd, nc, (int32_t)c, vel + (int64_t)i * ldv, g[i]);
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const float t = (g[i][j] + g[j][i]) / 2.0f;
+                s = s + t * t;
+            }
+        S[c] = sqrtf(2.0f * s);
+    }
+}
+template <int ND>
+__global__ void k_wray_agarwal_of_cells(int32_t nc, GradDims G, const float* __restrict__ R, const float* __restrict__ S,
+                                        float sigmaR, float C1, float kappa, float* __restrict__ nut,
+                                        float* __restrict__ nuR, float* __restrict__ Sout) {
+    const float C2 = sigmaR + C1 / (kappa * kappa);
+    constexpr float EPS32 = 1.1920929e-07f;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        int32_t sd[2 * ND];
+#pragma unroll
+        for (int s = 0; s < 2 * ND; ++s) sd[s] = G.side[(int64_t)s * nc + c];
+        float gR[ND], gS[ND];
+        cell_gradient_at<ND>(G, sd, nc, (int32_t)c, R, gR);
+        cell_gradient_at<ND>(G, sd, nc, (int32_t)c, S, gS);
+        float dot = gR[0] * gS[0];
+#pragma unroll
+        for (int d = 1; d < ND; ++d) dot = dot + gR[d] * gS[d];
+        const float r = R[c], s = S[c];
+        const float src = C1 * r * s + C2 * dot * (r / (s + EPS32));
+        nut[c] = r;
+        nuR[c] = r * sigmaR;
+        Sout[c] = fminf(src, 10.0f * r);
+    }
+}
+
 __global__ void k_cell_gradient(int32_t nc, DimData D, const float* __restrict__ h, const float* __restrict__ u,
                                 int64_t ldu, float* __restrict__ out, int64_t ldo) {
     int64_t v = blockIdx.y;
@@ -601,6 +668,39 @@ int ibh_cell_gradient_all(const ibh_part* p, const float* u, int nv, int64_t ldu
         hipLaunchKernelGGL(k_cell_gradient_all<2>, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, u, ldu, nv, out, ldo);
     else
         hipLaunchKernelGGL(k_cell_gradient_all<3>, grid2(p->nc, nv), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, u, ldu, nv, out, ldo);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+static GradDims grad_dims(const ibh_part* p) {
+    GradDims G;
+    for (int d = 0; d < p->nd; ++d) {
+        G.d[d] = p->dim[d];
+        G.h[d] = p->spacing + (int64_t)d * p->nc;
+    }
+    G.side = p->side;
+    return G;
+}
+// face-list forms of ibh_shear_rate_of_velocity / ibh_wray_agarwal_of (ibh_fused.hip dispatches here on partitions
+// without block structure)
+int ibh_shear_rate_of_velocity_cells(const ibh_part* p, const float* vel, int64_t ldv, float* S) {
+    const GradDims G = grad_dims(p);
+    if (p->nd == 2)
+        hipLaunchKernelGGL(k_shear_of_velocity_cells<2>, grid2(p->nc, 1), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, vel, ldv, S);
+    else
+        hipLaunchKernelGGL(k_shear_of_velocity_cells<3>, grid2(p->nc, 1), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, vel, ldv, S);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_wray_agarwal_of_cells(const ibh_part* p, const float* R, const float* S, float sigmaR, float C1, float kappa,
+                              float* nut, float* nuR, float* Sout) {
+    const GradDims G = grad_dims(p);
+    if (p->nd == 2)
+        hipLaunchKernelGGL(k_wray_agarwal_of_cells<2>, grid2(p->nc, 1), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, R, S, sigmaR,
+                           C1, kappa, nut, nuR, Sout);
+    else
+        hipLaunchKernelGGL(k_wray_agarwal_of_cells<3>, grid2(p->nc, 1), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, R, S, sigmaR,
+                           C1, kappa, nut, nuR, Sout);
     IBH_LAUNCH_CHECK();
     return 0;
 }

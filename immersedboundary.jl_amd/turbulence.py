@@ -105,12 +105,18 @@ def Wray_Agarwal(R, S, gradR, gradS, sigmaR=0.72, C1=0.0829, kappa=0.41):
 
 
 def all_blocks(part):
-    """True where every cell of the partition lies in a complete 8^3 block without a GENERAL side: the fused closures below
-    (gradients consumed where they are made) apply; elsewhere they compose the operators, same result."""
+    """True where every cell of the partition lies in a complete 8^3 block without a GENERAL side."""
     part = B._part(part)
     i = part.info
     return (part.nd == 3 and i["full_blocks"] > 0 and i["full_blocks"] * 512 == part.nc and i["irregular_cells"] == 0
             and i["sides_general"] == 0)
+
+
+def fused_closures_apply(part):
+    """The fused closures below (gradients consumed where they are made) apply on partitions made of complete 3-D blocks and
+    on partitions without block structure; elsewhere (blocks + face-list cells) they compose the operators, same result."""
+    part = B._part(part)
+    return all_blocks(part) or part.info["full_blocks"] == 0
 
 
 def shear_rate_of_velocity(part, vel):
@@ -121,7 +127,7 @@ def shear_rate_of_velocity(part, vel):
     v, nd, ldv = B._field(vel, part.nc)
     if nd != part.nd:
         raise ValueError("vel must be (nc, nd)")
-    if all_blocks(part):
+    if fused_closures_apply(part):
         S = B.colmajor_empty(part.nc)
         B._stream()
         B.call("ibh_shear_rate_of_velocity", part.handle, B._ptr(v), ldv, B._ptr(S))
@@ -135,7 +141,7 @@ def Wray_Agarwal_of(part, R, S, sigmaR=0.72, C1=0.0829, kappa=0.41):
     part = B._part(part)
     R = _vec(R, part.nc)
     S = _vec(S, part.nc)
-    if all_blocks(part):
+    if fused_closures_apply(part):
         out = [B.colmajor_empty(part.nc) for _ in range(3)]
         B._stream()
         B.call("ibh_wray_agarwal_of", part.handle, B._ptr(R), B._ptr(S), _f(sigmaR), _f(C1), _f(kappa),

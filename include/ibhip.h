@@ -393,7 +393,8 @@ int ibh_turb_wray_agarwal(int nd, int64_t n, const float* R, const float* S, con
 int ibh_scalar_transport(const ibh_part*, const float* R, const float* nuR, float nu, const float* vel, int64_t ldv,
                          const float* S, float* out);
 /* On a 3-D partition made of complete 8^3 blocks (ibh_partition_info: full_blocks * 512 == nc, no face-list cells, no
- * GENERAL sides; an error otherwise -- compose the operators then), the gradients consumed where they are made:
+ * GENERAL sides) or on a partition without block structure (full_blocks == 0: the coarse levels of multigrid()) -- an
+ * error otherwise: compose the operators then -- the gradients consumed where they are made:
  *   S = shear_rate(cell_gradient(part, u), cell_gradient(part, v), cell_gradient(part, w))        turbulence.jl:110-124
  *   (nut, nuR, Sout) = Wray_Agarwal(R, S, cell_gradient(part, R), cell_gradient(part, S))          turbulence.jl:222-241
  * with the arithmetic of the tuple cell_gradient's block sweep (ibh_cell_gradient_nd) and of the pointwise kernels. */

@@ -152,3 +152,36 @@ def test_fused_closures_on_an_all_block_octree_are_the_composition():
         wa_c = T.Wray_Agarwal(R, S_comp, ibamd.cell_gradient_array(dpart, R), ibamd.cell_gradient_array(dpart, S_comp))
         for k in ("nut", "nuR", "S"):
             assert torch.equal(wa_f[k], wa_c[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd", [2, 3])
+def test_fused_closures_on_face_list_partitions_are_the_composition(nd):
+    """The same two closures on partitions WITHOUT block structure (4-cell blocks: the coarse levels of ``multigrid()``):
+    thread-per-cell kernels over the side table (``k_shear_of_velocity_cells`` / ``k_wray_agarwal_of_cells``) against the
+    composition of ``cell_gradient`` and the pointwise kernels, bit for bit, 2-D and 3-D with 2:1 interfaces."""
+    import torch
+    import ibamd
+    from ibamd import Ball, Mesh
+    from ibamd import turbulence as T
+    o, w = f32([-2] * nd), f32([4] * nd)
+    msh = Mesh(o, w, block_size=4, refinement_regions=[(Ball(np.array([1.2] * nd), 0.1), f32(0.05 if nd == 2 else 0.12))])
+    dom = ibamd.Domain(msh, max_partition_size=10 ** 9, boundaries=False)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    assert dpart.info["full_blocks"] == 0 and T.fused_closures_apply(dpart) and not T.all_blocks(dpart)
+    assert 0 < dpart.info["direct_sides"] < 2 * nd * dpart.nc          # some sides take the CSR walk (2:1 interfaces)
+    nc = part.centers.shape[0]
+    X = part.centers
+    rng = np.random.default_rng(33)
+    vel_h = np.stack([np.sin(2 * X[:, (i + 1) % nd]) * np.cos(X[:, i]) for i in range(nd)], axis=1).astype(f32)
+    vel_h += f32(0.05) * rng.standard_normal((nc, nd)).astype(f32)
+    vel = ibamd.hip(vel_h)
+    R = ibamd.hip((4.5e-5 * (1 + 0.5 * rng.uniform(0, 1, nc))).astype(f32))
+    S_fused = T.shear_rate_of_velocity(dpart, vel)
+    S_comp = T.shear_rate([list(ibamd.cell_gradient(dpart, vel[:, i].contiguous())) for i in range(nd)])
+    assert torch.equal(S_fused, S_comp) and float(S_comp.abs().max()) > 0
+    wa_f = T.Wray_Agarwal_of(dpart, R, S_comp)
+    wa_c = T.Wray_Agarwal(R, S_comp, ibamd.cell_gradient_array(dpart, R), ibamd.cell_gradient_array(dpart, S_comp))
+    for k in ("nut", "nuR", "S"):
+        assert torch.equal(wa_f[k], wa_c[k]), k
