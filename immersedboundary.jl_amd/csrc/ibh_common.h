@@ -178,6 +178,9 @@ extern "C" int ibh_shear_rate_of_velocity_cells(const ibh_part* p, const float* 
 extern "C" int ibh_wray_agarwal_of_cells(const ibh_part* p, const float* R, const float* S, float sigmaR, float C1,
                                          float kappa, float* nut, float* nuR, float* Sout);
 
+extern "C" int ibh_scalar_transport_blocks(const ibh_part* p, const float* R, const float* nuR, float nu, const float* vel,
+                                           int64_t ldv, const float* S, float* out, int* done);
+
 // thread-local state
 extern thread_local std::string ibh_err;
 extern thread_local hipStream_t ibh_stream;

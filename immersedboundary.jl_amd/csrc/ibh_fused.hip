@@ -1163,6 +1163,132 @@ __global__ __launch_bounds__(256) void k_wray_agarwal_of3(const BlockDesc3* __re
     }
 }
 
+// ---- transport of a scalar with variable diffusivity on an all-block 3-D partition (ibh_scalar_transport, ibh_turb.hip, is
+// the face-list form): out = S + sum_d green_gauss(at_faces(nu + nuR, d) .* face_gradient(R, d) .- at_faces(u_d .* R, d), d).
+// One wavefront per 8^3 block, lane = (i, j) with its z-column of R, nu + nuR and u_d R in registers; x / y neighbours from
+// four LDS tiles; lane t also owns slot t of the six sides: it gathers the cell(s) across, evaluates the side's face flux(es)
+// -- one, or the mean of four behind a FINE side -- and leaves it for the boundary cell.  The expressions and their order
+// are those of the face-list kernel (no contraction): equal bit for bit wherever a side has one face.
+#define TR3_LDS (4 * 512 + 384)
+__device__ __forceinline__ float tr3_avg(float uo, float un, float ho, float hn) { return (uo * hn + un * ho) / (hn + ho); }
+__device__ __forceinline__ float tr3_flux(float Ro, float Rn, float To, float Tn, float Ao, float An, float ho, float hn) {
+    const float conv = tr3_avg(Ao, An, ho, hn);   // at_faces(u_d .* R)
+    const float nuf = tr3_avg(To, Tn, ho, hn);    // at_faces(nu .+ nuR)
+    const float fd = (ho + hn) / 2.0f;            // face_distance
+    const float fg = (Rn - Ro) / fd;              // face_gradient(R)
+    return nuf * fg - conv;
+}
+__global__ __launch_bounds__(256) void k_scalar_transport_blocks3(const BlockDesc3* __restrict__ blocks,
+                                                                  const int32_t* __restrict__ htab,
+                                                                  const int32_t* __restrict__ ftab, int32_t nblk,
+                                                                  int32_t nwg, uint32_t nc, const float* __restrict__ hsp,
+                                                                  const float* __restrict__ R, const float* __restrict__ nuR,
+                                                                  float nu, const float* __restrict__ vel, uint32_t ldv,
+                                                                  const float* __restrict__ S, float* __restrict__ out) {
+    using blk2::ldg;
+    __shared__ float lds_all[4 * TR3_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * 4 + wave);
+    if (blk >= nblk) return;
+    float* lds = lds_all + wave * TR3_LDS;
+    float *tR = lds, *tT = lds + 512, *tAx = lds + 1024, *tAy = lds + 1536, *Hf = lds + 2048;
+    const BlockDesc3 bb = blocks[blk];
+    const uint32_t base = (uint32_t)bb.base;
+    const float h[3] = {hsp[base], hsp[nc + base], hsp[2 * (size_t)nc + base]};   // the block's spacing as the cells hold it
+    float Rk[8], Tk[8], Ak[3][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t c = base + lane + 64 * k;
+        Rk[k] = ldg(R, c);
+        Tk[k] = nu + ldg(nuR, c);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) Ak[d][k] = ldg(vel + (size_t)d * ldv, c) * Rk[k];
+    }
+    uint32_t hid[6];
+    hid[0] = blk3::halo_cell3s<0>(bb, htab, blk, lane);
+    hid[1] = blk3::halo_cell3s<1>(bb, htab, blk, lane);
+    hid[2] = blk3::halo_cell3s<2>(bb, htab, blk, lane);
+    hid[3] = blk3::halo_cell3s<3>(bb, htab, blk, lane);
+    hid[4] = blk3::halo_cell3s<4>(bb, htab, blk, lane);
+    hid[5] = blk3::halo_cell3s<5>(bb, htab, blk, lane);
+    float hR[6], hT[6], hA[6], hh[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int d = s >> 1;
+        hR[s] = ldg(R, hid[s]);
+        hT[s] = nu + ldg(nuR, hid[s]);
+        hA[s] = ldg(vel + (size_t)d * ldv, hid[s]) * hR[s];
+        hh[s] = ldg(hsp + (size_t)d * nc, hid[s]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        tR[k * 64 + lane] = Rk[k];
+        tT[k * 64 + lane] = Tk[k];
+        tAx[k * 64 + lane] = Ak[0][k];
+        tAy[k * 64 + lane] = Ak[1][k];
+    }
+    blk2::wave_lds_sync();
+    // side fluxes: slot t = lane of side s belongs to boundary cell pos(s, t) of the tile
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int d = s >> 1;
+        const bool low = (s & 1) == 0;
+        const int sd = d == 0 ? 1 : d == 1 ? 8 : 64, sa = d == 0 ? 8 : 1, sb = d == 2 ? 8 : 64;
+        const int pos = (low ? 0 : 7) * sd + (lane & 7) * sa + (lane >> 3) * sb;
+        const float Rb = tR[pos], Tb = tT[pos];
+        const float Ab = d == 0 ? tAx[pos] : d == 1 ? tAy[pos] : (low ? Ak[2][0] : Ak[2][7]);
+        const float hb = h[d];
+        // the halo cell is the owner on a low side, the neighbour on a high side
+        float F = low ? tr3_flux(hR[s], Rb, hT[s], Tb, hA[s], Ab, hh[s], hb) : tr3_flux(Rb, hR[s], Tb, hT[s], Ab, hA[s], hb, hh[s]);
+        if (bb.type[s] == SIDE_FINE) {  // wave-uniform: three more faces behind this slot, mean of the four fluxes
+            const int32_t* ft = ftab + (((size_t)bb.fine * 6 + s) * 64 + lane) * 3;
+            F = F * 0.25f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const uint32_t x = (uint32_t)ft[q];
+                const float Rx = ldg(R, x), Tx = nu + ldg(nuR, x), Ax = ldg(vel + (size_t)d * ldv, x) * Rx;
+                const float hx = ldg(hsp + (size_t)d * nc, x);
+                const float Fq = low ? tr3_flux(Rx, Rb, Tx, Tb, Ax, Ab, hx, hb) : tr3_flux(Rb, Rx, Tb, Tx, Ab, Ax, hb, hx);
+                F = F + Fq * 0.25f;
+            }
+        } else {
+            F = F * 1.0f;
+        }
+        Hf[s * 64 + lane] = F;
+    }
+    blk2::wave_lds_sync();
+    const int i = lane & 7, j = lane >> 3;
+    const bool e0 = i == 0, e1 = i == 7, e2 = j == 0, e3 = j == 7;
+    const float fzl = Hf[4 * 64 + lane], fzh = Hf[5 * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t c = base + lane + 64 * k;
+        const float *r = tR + k * 64, *t = tT + k * 64, *ax = tAx + k * 64, *ay = tAy + k * 64;
+        const float Rc = Rk[k], Tc = Tk[k];
+        float fl[3], fr[3];
+        // x and y: inside the plane or the side's flux (x sides: slot j + 8 k, y sides: slot i + 8 k)
+        const int xl = e0 ? lane : lane - 1, xr = e1 ? lane : lane + 1, yl = e2 ? lane : lane - 8, yr = e3 ? lane : lane + 8;
+        const float fxl = tr3_flux(r[xl], Rc, t[xl], Tc, ax[xl], Ak[0][k], h[0], h[0]) * 1.0f;
+        const float fxr = tr3_flux(Rc, r[xr], Tc, t[xr], Ak[0][k], ax[xr], h[0], h[0]) * 1.0f;
+        const float fyl = tr3_flux(r[yl], Rc, t[yl], Tc, ay[yl], Ak[1][k], h[1], h[1]) * 1.0f;
+        const float fyr = tr3_flux(Rc, r[yr], Tc, t[yr], Ak[1][k], ay[yr], h[1], h[1]) * 1.0f;
+        fl[0] = e0 ? Hf[0 * 64 + j + 8 * k] : fxl;
+        fr[0] = e1 ? Hf[1 * 64 + j + 8 * k] : fxr;
+        fl[1] = e2 ? Hf[2 * 64 + i + 8 * k] : fyl;
+        fr[1] = e3 ? Hf[3 * 64 + i + 8 * k] : fyr;
+        // z: registers
+        const int kl = k > 0 ? k - 1 : 0, kh = k < 7 ? k + 1 : 7;
+        const float fzl_in = tr3_flux(Rk[kl], Rc, Tk[kl], Tc, Ak[2][kl], Ak[2][k], h[2], h[2]) * 1.0f;
+        const float fzr_in = tr3_flux(Rc, Rk[kh], Tc, Tk[kh], Ak[2][k], Ak[2][kh], h[2], h[2]) * 1.0f;
+        fl[2] = k == 0 ? fzl : fzl_in;
+        fr[2] = k == 7 ? fzh : fzr_in;
+        float rt = ldg(S, c);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) rt = rt + (fr[d] - fl[d]) / h[d];
+        out[c] = rt;
+    }
+}
+
 // 1: wave-per-block form of the 3-D scalar pass A (IBH_3D_WAVE=0 for the 512-thread form, A/B)
 const int ibh_3d_wave = getenv("IBH_3D_WAVE") ? atoi(getenv("IBH_3D_WAVE")) : 1;
 // blocks per wave of the single-kernel sweep; 0 = automatic (IBH_SWEEP_ITERS overrides, for tuning)
@@ -1175,6 +1301,7 @@ int ibh_rows = getenv("IBH_ROWS") ? atoi(getenv("IBH_ROWS")) : 0;
 // ibh_set_tuning(key, v): "quad_variant" 4 = wave time stamps (scripts/wave_timeline.py); "quad_parts" 1 / 2 = only the
 // quads / only the single blocks of a quad sweep (measurement); "quad_singles_first" = grid order
 int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_first = 0, ibh_quad_singles_iters = 1;
+int ibh_transport_blocks = 1;  // tuning key "transport_blocks" 0: the face-list transport kernel everywhere (A/B, tests)
 int ibh_rows_singles = getenv("IBH_ROWS_SINGLES") ? atoi(getenv("IBH_ROWS_SINGLES")) : -1;
 // measured (profiles/r3_final/rows_for_singles.json): 1 441 single blocks 5.96 -> 10.6 us, 5 937: 15.5 -> 19.0 us (a row wave
 // lives ~3 us whatever the load, and the second launch is serial), 47 272: 126.1 -> 119.0 us
@@ -1233,6 +1360,7 @@ int ibh_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "quad_singles_iters")) ibh_quad_singles_iters = value;
     else if (!strcmp(key, "rows")) ibh_rows = value;
     else if (!strcmp(key, "rows_singles")) ibh_rows_singles = value;
+    else if (!strcmp(key, "transport_blocks")) ibh_transport_blocks = value;
     else return ibh_fail(-1, "ibh_set_tuning: unknown key", __FILE__, __LINE__);
     return 0;
 }
@@ -1608,6 +1736,19 @@ static bool all_blocks3(const ibh_part* p) {
     return p->nd == 3 && p->bs == 8 && p->blocks3 && p->nblk > 0 && p->n_irr == 0 && (int64_t)p->nblk * 512 == p->nc &&
            p->info[6] == 0;
 }
+// ibh_scalar_transport on an all-block 3-D partition (dispatched from ibh_turb.hip; 0 = not applicable here)
+int ibh_scalar_transport_blocks(const ibh_part* p, const float* R, const float* nuR, float nu, const float* vel, int64_t ldv,
+                                const float* S, float* out, int* done) {
+    *done = 0;
+    if (!all_blocks3(p) || !ibh_transport_blocks) return 0;
+    const int32_t nwg = (p->nblk + 3) / 4;
+    hipLaunchKernelGGL(k_scalar_transport_blocks3, dim3(nwg), dim3(256), 0, ibh_stream, p->blocks3, p->htab3, p->ftab3,
+                       p->nblk, nwg, (uint32_t)p->nc, p->spacing, R, nuR, nu, vel, (uint32_t)ldv, S, out);
+    IBH_LAUNCH_CHECK();
+    *done = 1;
+    return 0;
+}
+
 // no block structure at all: the tuple cell_gradient is the face-list kernel there (ibh_cell_gradient_nd)
 static bool no_blocks(const ibh_part* p) {
     return !(p->bs == 8 && p->nblk > 0 && (p->nd == 2 ? p->blocks2 != nullptr : p->blocks3 != nullptr));

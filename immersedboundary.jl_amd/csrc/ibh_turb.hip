@@ -320,6 +320,11 @@ int ibh_scalar_transport(const ibh_part* p, const float* R, const float* nuR, fl
                          const float* S, float* out) {
     IBH_REQUIRE(p && R && nuR && vel && S && out && (p->nd == 2 || p->nd == 3), "ibh_scalar_transport: bad argument");
     if (p->nc == 0) return 0;
+    {
+        int done = 0;   // all-block 3-D partitions: the block kernel (ibh_fused.hip)
+        const int rc = ibh_scalar_transport_blocks(p, R, nuR, nu, vel, ldv, S, out, &done);
+        if (rc || done) return rc;
+    }
     TransportDims T;
     for (int d = 0; d < p->nd; ++d) {
         T.d[d] = p->dim[d];

@@ -185,3 +185,41 @@ def test_fused_closures_on_face_list_partitions_are_the_composition(nd):
     wa_c = T.Wray_Agarwal(R, S_comp, ibamd.cell_gradient_array(dpart, R), ibamd.cell_gradient_array(dpart, S_comp))
     for k in ("nut", "nuR", "S"):
         assert torch.equal(wa_f[k], wa_c[k]), k
+
+
+@pytest.mark.gpu
+def test_block_transport_kernel_against_the_face_list_kernel():
+    """``ibh_scalar_transport`` on a 3-D partition of complete blocks runs the block kernel (wave per 8^3 block, side fluxes
+    by the slot lanes): against the face-list kernel of the same entry (tuning key ``transport_blocks`` 0) -- the same
+    expressions in the same order, so equal bit for bit wherever a side has one face; behind a FINE side the four face
+    fluxes may be summed in another order (last-bit differences)."""
+    import torch
+    import ibamd
+    from ibamd import Ball, Mesh, _lib
+    from ibamd import turbulence as T
+    msh = Mesh(f32([-2, -2, -2]), f32([4, 4, 4]), block_size=8,
+               refinement_regions=[(Ball(np.array([1.2, 1.2, 1.2]), 0.1), f32(0.1))])
+    dom = ibamd.Domain(msh, max_partition_size=10 ** 9, boundaries=False)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    assert T.all_blocks(dpart) and dpart.info["sides_fine"] > 0 and dpart.info["sides_coarse"] > 0
+    nc = part.centers.shape[0]
+    X = part.centers
+    rng = np.random.default_rng(8)
+    R = ibamd.hip((4.5e-5 * (1 + 0.5 * rng.uniform(0, 1, nc))).astype(f32))
+    nuR = ibamd.hip((1e-5 * rng.uniform(0.5, 2, nc)).astype(f32))
+    S = ibamd.hip(rng.uniform(-1, 1, nc).astype(f32))
+    vel = ibamd.hip(np.stack([100 * (1 + 0.1 * np.sin(X[:, 1])), 10 * np.cos(X[:, 0] + X[:, 2]),
+                              5 * rng.uniform(-1, 1, nc)], axis=1).astype(f32))
+    got = T.scalar_transport(dpart, R, nuR, vel, 1.5e-5, S)
+    _lib.call("ibh_set_tuning", b"transport_blocks", 0)
+    try:
+        ref = T.scalar_transport(dpart, R, nuR, vel, 1.5e-5, S)
+    finally:
+        _lib.call("ibh_set_tuning", b"transport_blocks", 1)
+    same = (got == ref)
+    frac = float(same.float().mean())
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"block transport: {100 * frac:.2f} % of the cells bit-identical, max difference {err:.2e} of max |ref|")
+    assert frac > 0.97 and err <= 1e-6
+    assert float((ref - S).abs().max()) > 0
