@@ -304,6 +304,20 @@ __device__ __forceinline__ void sweep_adv(const BlockDesc2* __restrict__ blocks,
 // ------------------------------------------------------------------------------------------
 #define BLK2_SWEEP_EULER_LDS (4 * 128 + 128 + 8 * 128 + 4 * 64 + 80)
 
+// conserved state, pressure, normal velocity and speed of sound of one side of a face
+__device__ __forceinline__ void euler_state(const float* P, int dn, const Gas& gas, float* Q, float& p, float& un, float& a) {
+    p = P[0];
+    const float T = fmaxf(P[1], 10.0f);
+    const float k = 0.5f * (P[2] * P[2] + P[3] * P[3]);
+    const float rho = p * __builtin_amdgcn_rcpf(gas.R * T);
+    Q[0] = rho;
+    Q[1] = rho * (gas.R / (gas.gamma - 1.0f) * T + k);
+    Q[2] = rho * P[2];
+    Q[3] = rho * P[3];
+    un = dn ? P[3] : P[2];
+    a = __builtin_amdgcn_sqrtf(gas.gamma * gas.R * T);
+}
+
 // MUSCL states from undivided slopes (see flux_w), then the HLL flux of blk2::euler_flux
 __device__ __forceinline__ void euler_flux_w(const float* Pa, const float* Pb, const float* Sa, const float* Sb, float Da,
                                              float Db, float wa, int dn, const Gas& gas, float* F) {
@@ -321,14 +335,24 @@ __device__ __forceinline__ void euler_flux_w(const float* Pa, const float* Pb, c
         PL[v] = uf + Df * ((s - wa * d) - t16);   // (Pa + s) - uf
         PR[v] = uf + Df * ((wb * d - s) - t16);   // (Pb - s) - uf
     }
-    float QL[4], FL[4], QR[4], FR[4], uL, aL, uR, aR;
-    euler_side(PL, dn, gas, QL, FL, uL, aL);
-    euler_side(PR, dn, gas, QR, FR, uR, aR);
+    // HLL regrouped by state, operation for operation what quad2::euler_flux_w2 does on pairs (ibh_quad2d_euler.h): a block
+    // gives the same bits whether a quad wave or a single-block wave sweeps it
+    float QL[4], QR[4], pL, pR, uL, aL, uR, aR;
+    euler_state(PL, dn, gas, QL, pL, uL, aL);
+    euler_state(PR, dn, gas, QR, pR, uR, aR);
     const float SR = fminf(uR - aR, 0.0f);
     const float SL = fmaxf(uL + aL, 0.0f);
     const float rs = __builtin_amdgcn_rcpf(SL - SR);
+    const float wL = SL * rs, wR = SR * rs;
+    const float c = SL * wR;
+    const float cL = wL * uL - c, cR = c - wR * uR;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) F[v] = (SL * FL[v] - SR * FR[v] + SR * SL * (QR[v] - QL[v])) * rs;
+    for (int v = 0; v < 4; ++v) F[v] = QL[v] * cL + QR[v] * cR;
+    const float mL = wL * pL, mR = wR * pR;
+    const float m = mL - mR;
+    F[2] += dn ? 0.0f : m;
+    F[3] += dn ? m : 0.0f;
+    F[1] += mL * uL - mR * uR;
 }
 
 struct SweepPreE {
