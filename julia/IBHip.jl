@@ -572,6 +572,24 @@ function scalar_transport!(out::HipArray{Float32}, part::HipPartition, R::HipArr
     out
 end
 
+"`shear_rate([cell_gradient(part, vel[:, i]) for i in 1:nd])` (src/turbulence.jl:110-124) in one launch where the partition
+is made of complete 3-D blocks or has no block structure (an error otherwise: compose the operators)."
+function shear_rate_of_velocity!(S::HipArray{Float32}, part::HipPartition, vel::HipArray{Float32})
+    check(ccall((:ibh_shear_rate_of_velocity, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+        part.handle, vel.ptr, ld(vel), S.ptr))
+    S
+end
+
+"`Wray_Agarwal(R, S, cell_gradient(part, R), cell_gradient(part, S))` (src/turbulence.jl:222-241) in one launch; returns
+`(νt = nut, νR = nuR, S = Sout)` written into the three arrays."
+function wray_agarwal_of!(nut::HipArray{Float32}, nuR::HipArray{Float32}, Sout::HipArray{Float32}, part::HipPartition,
+                          R::HipArray{Float32}, S::HipArray{Float32}; σR = 0.72f0, C1 = 0.0829f0, κ = 0.41f0)
+    check(ccall((:ibh_wray_agarwal_of, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        part.handle, R.ptr, S.ptr, Float32(σR), Float32(C1), Float32(κ), nut.ptr, nuR.ptr, Sout.ptr))
+    (νt = nut, νR = nuR, S = Sout)
+end
+
 # flags of the fused sweeps (include/ibhip.h)
 const FORCE_GENERAL, IMAGE_ONLY, PASS_A_ONLY, PASS_B_ONLY, EXACT = 1, 2, 4, 8, 16
 const PHASE_INTERIOR, PHASE_BOUNDARY, NO_FUSE, NO_QUAD = 32, 64, 128, 1024
