@@ -703,7 +703,10 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
         const int32_t wgs = singles_first ? (int32_t)blockIdx.x : (int32_t)blockIdx.x - nwgq;
         if constexpr (RS) {
             const int32_t first8 = __builtin_amdgcn_readfirstlane((xcd_remap(wgs, nwgs) * WPB + wave) * 8);
-            if (first8 < ns) rows2::sweep_rows(blocks, etab, first8, ns, u, C, ldc, ud, lds + wave * ROWS_LDS, lane, singles);
+            if (first8 < ns) {
+                __builtin_amdgcn_s_setprio(3);  // a row wave is the longest-lived wave of the launch
+                rows2::sweep_rows(blocks, etab, first8, ns, u, C, ldc, ud, lds + wave * ROWS_LDS, lane, singles);
+            }
             return;
         }
         const int32_t first = __builtin_amdgcn_readfirstlane(xcd_remap(wgs, nwgs) * (WPB * siters) + wave);
@@ -1300,7 +1303,8 @@ const int ibh_quad = getenv("IBH_QUAD") ? atoi(getenv("IBH_QUAD")) : 1;
 int ibh_rows = getenv("IBH_ROWS") ? atoi(getenv("IBH_ROWS")) : 0;
 // ibh_set_tuning(key, v): "quad_variant" 4 = wave time stamps (scripts/wave_timeline.py); "quad_parts" 1 / 2 = only the
 // quads / only the single blocks of a quad sweep (measurement); "quad_singles_first" = grid order
-int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_first = 0, ibh_quad_singles_iters = 1;
+int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_iters = 1;
+int ibh_quad_singles_first = getenv("IBH_SINGLES_FIRST") ? atoi(getenv("IBH_SINGLES_FIRST")) : 0;
 int ibh_transport_blocks = 1;  // tuning key "transport_blocks" 0: the face-list transport kernel everywhere (A/B, tests)
 int ibh_rows_singles = getenv("IBH_ROWS_SINGLES") ? atoi(getenv("IBH_ROWS_SINGLES")) : -1;
 // measured (profiles/r3_final/rows_for_singles.json): 1 441 single blocks 5.96 -> 10.6 us, 5 937: 15.5 -> 19.0 us (a row wave

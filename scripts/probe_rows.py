@@ -58,6 +58,18 @@ for key, rows in (("quad_sweep_us", 0), ("row_sweep_us", 1)):
         ref = r
     else:
         out["maxdiff"] = float((r - ref).abs().max() / ref.abs().max())
+_lib.call("ibh_set_tuning", b"rows", 0)
+# the blocks outside quads: per-block body in the quad launch (0), second launch of the row sweep (1), row waves inside the
+# quad launch (2), the latter two with either grid order
+for rs in (0, 1, 2):
+    for sf in (0, 1):
+        if rs == 1 and sf:
+            continue
+        _lib.call("ibh_set_tuning", b"rows_singles", rs)
+        _lib.call("ibh_set_tuning", b"quad_singles_first", sf)
+        out["singles_form_%d_singles_first_%d_us" % (rs, sf)] = round(timed(lambda: ibamd.residual_advection(dpart, u, C, out=ud)), 3)
+_lib.call("ibh_set_tuning", b"rows_singles", -1)
+_lib.call("ibh_set_tuning", b"quad_singles_first", 0)
 for key in ("quad_sweep_us", "row_sweep_us"):
     out[key.replace("_us", "_frac")] = round(16.0 * dpart.nc / (out[key] * 1e-6) / 8e12, 4)
 print(json.dumps(out))
