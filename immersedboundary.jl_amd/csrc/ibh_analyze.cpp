@@ -464,4 +464,59 @@ void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<i
                 out.singles.push_back(b);
                 if (pass == 0) out.ns_int++;
             }
+    // ---- pairs among the blocks left over (only where no phase split exists: every block an interior-phase block)
+    if (nB1 != nb) {
+        out.singles2 = out.singles;
+        return;
+    }
+    std::vector<char> paired(nb, 0);
+    auto side_ok = [&](int32_t bi, int s) {
+        const BlockDesc2& b = blocks[bi];
+        const int ty = b.type[s];
+        bool ok = ty == SIDE_SAME || ty == SIDE_COARSE || ty == SIDE_FINE;
+        if (ok && s >= 2)
+            for (int t = 0; t < 8 && ok; ++t) {
+                const int32_t h0 = htab[(size_t)bi * 64 + (s * 8 + t) * 2], h1 = htab[(size_t)bi * 64 + (s * 8 + t) * 2 + 1];
+                const int32_t dl = s == 2 ? -8 : 8;
+                ok = h0 + 1 < nc && h0 + dl >= 0 && h0 + dl + 1 < nc && (ty != SIDE_FINE || h1 == h0 + 1);
+            }
+        return ok;
+    };
+    for (int32_t o : order) {
+        if (used[o] || paired[o] || !cand[o]) continue;
+        const BlockDesc2& b0 = blocks[o];
+        auto it = bybase.find(b0.base + 64);
+        if (it == bybase.end()) continue;
+        const int32_t i1 = it->second;
+        if (used[i1] || paired[i1] || !cand[i1]) continue;
+        const BlockDesc2& b1 = blocks[i1];
+        bool ok = same_to(b0, 1, b1.base) && same_to(b1, 0, b0.base) && b0.dt < 0 && b1.dt < 0 && b1.h[0] == b0.h[0] &&
+                  b1.h[1] == b0.h[1];
+        ok = ok && side_ok(o, 0) && side_ok(o, 2) && side_ok(o, 3) && side_ok(i1, 1) && side_ok(i1, 2) && side_ok(i1, 3);
+        if (!ok) continue;
+        paired[o] = paired[i1] = 1;
+        // lane rows g = 0..3 = sides left, bottom, top, right; half-sides (g, half): the block that holds them, or the
+        // half-side they repeat where a pair has none (left / right upper halves)
+        const int32_t blk_of_pair[4][2] = {{o, o}, {o, i1}, {o, i1}, {i1, i1}};
+        QuadDesc2 d;
+        d.base = b0.base;
+        d.rh[0] = b0.rh[0];
+        d.rh[1] = b0.rh[1];
+        d.cls = 0;
+        const size_t row = out.ptab.size();
+        out.ptab.resize(row + IBH_QROW);
+        for (int g = 0; g < 4; ++g)
+            for (int half = 0; half < 2; ++half) {
+                const int s = side_of_g[g], l = 2 * g + half;
+                const int32_t bi = blk_of_pair[g][half];
+                d.cls |= (uint32_t)blocks[bi].type[s] << (4 * l);
+                for (int t = 0; t < 8; ++t)
+                    for (int k = 0; k < 2; ++k)
+                        out.ptab[row + 2 * (16 * g + 8 * half + t) + k] = htab[(size_t)bi * 64 + (s * 8 + t) * 2 + k];
+                for (int e = 0; e < 4; ++e) out.ptab[row + 128 + 4 * l + e] = etab[(size_t)bi * 16 + s * 4 + e];
+            }
+        out.pd.push_back(d);
+    }
+    for (int32_t b : out.singles)
+        if (!paired[b]) out.singles2.push_back(b);
 }

@@ -285,8 +285,22 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
             p->nqs_int[k] = Q.ns_int;
             p->info[12 + 2 * k] = p->nq[k];
             p->info[13 + 2 * k] = p->nqs[k];
-            if ((rc = ibh_upload(&p->qd[k], Q.qd.data(), Q.qd.size()))) return rc;
-            if ((rc = ibh_upload(&p->qtab[k], Q.qtab.data(), Q.qtab.size()))) return rc;
+            if (k == 0 && !Q.pd.empty()) {
+                // pair tiles behind the quads, in the same arrays (the kernel tells them apart by index)
+                std::vector<QuadDesc2> qd(Q.qd);
+                qd.insert(qd.end(), Q.pd.begin(), Q.pd.end());
+                std::vector<int32_t> qt(Q.qtab);
+                qt.insert(qt.end(), Q.ptab.begin(), Q.ptab.end());
+                p->npair = (int32_t)Q.pd.size();
+                p->nqs2 = (int32_t)Q.singles2.size();
+                p->info[18] = p->npair;
+                if ((rc = ibh_upload(&p->qd[k], qd.data(), qd.size()))) return rc;
+                if ((rc = ibh_upload(&p->qtab[k], qt.data(), qt.size()))) return rc;
+                if ((rc = ibh_upload(&p->qsingles2, Q.singles2.data(), Q.singles2.size()))) return rc;
+            } else {
+                if ((rc = ibh_upload(&p->qd[k], Q.qd.data(), Q.qd.size()))) return rc;
+                if ((rc = ibh_upload(&p->qtab[k], Q.qtab.data(), Q.qtab.size()))) return rc;
+            }
             if ((rc = ibh_upload(&p->qsingles[k], Q.singles.data(), Q.singles.size()))) return rc;
         }
         p->nA1 = H.nph[0];
@@ -408,6 +422,9 @@ int ibh_host2d_get(const ibh_host2d* h, int what, int set, void* dst, int64_t ca
         case IBH_H2D_QUAD_DESC: src = Q.qd.data(); n = (int64_t)(Q.qd.size() * sizeof(QuadDesc2)); break;
         case IBH_H2D_QUAD_TAB: src = Q.qtab.data(); n = (int64_t)(Q.qtab.size() * 4); break;
         case IBH_H2D_SINGLES: src = Q.singles.data(); n = (int64_t)(Q.singles.size() * 4); break;
+        case IBH_H2D_PAIR_DESC: src = Q.pd.data(); n = (int64_t)(Q.pd.size() * sizeof(QuadDesc2)); break;
+        case IBH_H2D_PAIR_TAB: src = Q.ptab.data(); n = (int64_t)(Q.ptab.size() * 4); break;
+        case IBH_H2D_SINGLES2: src = Q.singles2.data(); n = (int64_t)(Q.singles2.size() * 4); break;
         case IBH_H2D_COUNTS: src = counts; n = (int64_t)sizeof(counts); break;
         case IBH_H2D_INFO: src = H.info; n = (int64_t)sizeof(H.info); break;
         default: return ibh_fail(-1, "ibh_host2d_get: unknown item", __FILE__, __LINE__);
@@ -446,6 +463,7 @@ int ibh_partition_destroy(ibh_part* p) {
         hipFree(p->qd[k]);
         hipFree(p->qtab[k]);
         hipFree(p->qsingles[k]);
+        if (k == 0) hipFree(p->qsingles2);
     }
     hipFree(p->fz_list);
     hipFree(p->ng_list);

@@ -53,6 +53,12 @@ struct QuadSet2 {
     std::vector<int32_t> qtab;     // [nq][IBH_QROW]
     std::vector<int32_t> singles;  // candidate blocks outside quads (block table indices), interior-phase ones first
     int32_t nq_int = 0, ns_int = 0;
+    // pairs: two blocks of `singles` side by side in x with consecutive bases (a 16 x 8 tile swept by one wave of the quad
+    // kernel in its HALF form); built only where every block is an interior-phase block (one partition, no skirt).
+    // Descriptors / rows in the quad format (unused half-sides repeat a used one); singles2 = singles without them.
+    std::vector<QuadDesc2> pd;
+    std::vector<int32_t> ptab;
+    std::vector<int32_t> singles2;
 };
 
 // 3-D: one full 8x8x8 block (512 consecutive local ids).  side s = 2*d + (0 low / 1 high); boundary cell of a
@@ -111,6 +117,8 @@ struct ibh_part {
     int32_t* qtab[2] = {nullptr, nullptr};
     int32_t* qsingles[2] = {nullptr, nullptr};
     int32_t nq[2] = {0, 0}, nq_int[2] = {0, 0}, nqs[2] = {0, 0}, nqs_int[2] = {0, 0};
+    int32_t npair = 0, nqs2 = 0;          // set 0 only: pair tiles (stored behind the quads in qd / qtab), blocks left over
+    int32_t* qsingles2 = nullptr;
     // mixed launches (fuse_all == 0): ascending block indices, interior-phase entries first
     int32_t* fz_list = nullptr;  // eligible blocks                       [n_fz], the first n_fz_int of them < nB1
     int32_t* ng_list = nullptr;  // blocks whose gradients somebody reads [n_ng], the first n_ng_int of them < nA1

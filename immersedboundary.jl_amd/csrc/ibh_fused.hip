@@ -682,7 +682,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
                                                          const int32_t* __restrict__ dtab,
                                                          const int32_t* __restrict__ singles, int32_t ns, int32_t nwgs,
                                                          int32_t singles_first, int32_t siters,
-                                                         const float* __restrict__ dtp = nullptr) {
+                                                         const float* __restrict__ dtp = nullptr, int32_t npair = 0) {
     __shared__ __attribute__((aligned(16))) float lds[RS && WPB * ROWS_LDS > QUAD_WG_LDS ? WPB * ROWS_LDS : QUAD_WG_LDS];
     float dt = 0.0f;
     if constexpr (STEP) dt = *dtp;  // (scalar load: the time step lives on the device, ibh_timestep_advection)
@@ -699,6 +699,9 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
         if (q < nq)
             quad2::sweep_quad<STAMP, GM, STEP>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane,
                                                STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr, dt);
+        else if (q < nq + npair)  // pair tiles: entries nq .. of the same arrays, the HALF form of the same wave code
+            quad2::sweep_quad<STAMP, GM, STEP, true>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane,
+                                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr, dt);
     } else {
         const int32_t wgs = singles_first ? (int32_t)blockIdx.x : (int32_t)blockIdx.x - nwgq;
         if constexpr (RS) {
@@ -1305,6 +1308,7 @@ int ibh_rows = getenv("IBH_ROWS") ? atoi(getenv("IBH_ROWS")) : 0;
 // quads / only the single blocks of a quad sweep (measurement); "quad_singles_first" = grid order
 int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_iters = 1;
 int ibh_quad_singles_first = getenv("IBH_SINGLES_FIRST") ? atoi(getenv("IBH_SINGLES_FIRST")) : 0;
+int ibh_pairs = getenv("IBH_PAIRS") ? atoi(getenv("IBH_PAIRS")) : 1;  // pair tiles for the blocks outside quads ("pairs")
 int ibh_transport_blocks = 1;  // tuning key "transport_blocks" 0: the face-list transport kernel everywhere (A/B, tests)
 int ibh_rows_singles = getenv("IBH_ROWS_SINGLES") ? atoi(getenv("IBH_ROWS_SINGLES")) : -1;
 // measured (profiles/r3_final/rows_for_singles.json): 1 441 single blocks 5.96 -> 10.6 us, 5 937: 15.5 -> 19.0 us (a row wave
@@ -1365,6 +1369,7 @@ int ibh_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "rows")) ibh_rows = value;
     else if (!strcmp(key, "rows_singles")) ibh_rows_singles = value;
     else if (!strcmp(key, "transport_blocks")) ibh_transport_blocks = value;
+    else if (!strcmp(key, "pairs")) ibh_pairs = value;
     else return ibh_fail(-1, "ibh_set_tuning: unknown key", __FILE__, __LINE__);
     return 0;
 }
@@ -1468,19 +1473,32 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         // The blocks outside quads as a SECOND launch of the row sweep (rows2::sweep_rows over the list: any eight complete
         // blocks per wave, 110 vector instructions per block against 365 in the per-block kernel) where a second launch
         // is cheap against the sweep ("rows_singles": -1 = by size, 0 / 1 = never / always)
+        // pair tiles (set 0, whole sweeps or the interior phase -- they exist only where every block is interior): the
+        // single blocks are then the ones outside quads AND pairs
+        const int32_t npair =
+            (k == 0 && ibh_pairs && p->npair > 0 && !ph2 && q0 == 0 && q1 == p->nq[k] && ibh_quad_parts == 3) ? p->npair : 0;
+        const int32_t* slist = p->qsingles[k];
+        if (npair) {
+            slist = p->qsingles2;
+            s0 = 0;
+            s1 = p->nqs2;
+        } else if (k == 0 && p->npair > 0 && ph2) {
+            s1 = s0;  // (all blocks are interior blocks there: nothing in the boundary phase)
+        }
         const bool rows_singles = k == 0 && p->rows_ok && p->n_dt == 0 && ibh_quad_variant == 0 && s1 > s0 &&
                                   (ibh_rows_singles < 0 ? s1 - s0 >= IBH_ROWS_SINGLES_MIN : ibh_rows_singles > 0);
         const int32_t rs0 = s0, rs1 = s1;
         const bool rows_inside = k == 0 && p->rows_ok && p->n_dt == 0 && ibh_quad_variant == 0 && s1 > s0 && ibh_rows_singles == 2;
         if (rows_singles && !rows_inside) s1 = s0;
         const int32_t siters = ibh_quad_singles_iters > 0 ? ibh_quad_singles_iters : 1;
-        const int32_t nwgq = (q1 - q0 + WPB - 1) / WPB,
+        const int32_t nwgq = (q1 - q0 + npair + WPB - 1) / WPB,
                       nwgs = rows_inside ? (s1 - s0 + WPB * 8 - 1) / (WPB * 8) : (s1 - s0 + WPB * siters - 1) / (WPB * siters);
         if (nwgq + nwgs == 0 && !rows_singles) return;
 #define QUAD_LAUNCH(DT, STAMP, ...)                                                                                    \
     hipLaunchKernelGGL((k_sweep_quad<DT, STAMP, ##__VA_ARGS__>), dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C,              \
                        (uint32_t)ldc, ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq,            \
-                       p->blocks2, p->htab, p->etab, p->dtab, p->qsingles[k] + s0, s1 - s0, nwgs, ibh_quad_singles_first, siters)
+                       p->blocks2, p->htab, p->etab, p->dtab, slist + s0, s1 - s0, nwgs, ibh_quad_singles_first, siters,          \
+                       (const float*)nullptr, npair)
         if (rows_inside) QUAD_LAUNCH(false, false, 127, false, true);
         else if (p->n_dt > 0) QUAD_LAUNCH(true, false);
         else if (ibh_quad_variant == 4) QUAD_LAUNCH(false, true);
@@ -1494,7 +1512,7 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
         if (rows_singles && !rows_inside) {
             const int32_t nw = (rs1 - rs0 + 7) / 8, nwgr = (nw + WPBR - 1) / WPBR;
             hipLaunchKernelGGL(k_sweep_rows, dim3(nwgr), dim3(64 * WPBR), 0, ibh_stream, u, C, (uint32_t)ldc, ud, p->blocks2,
-                               p->etab, 0, rs1 - rs0, nwgr, p->qsingles[k] + rs0);
+                               p->etab, 0, rs1 - rs0, nwgr, slist + rs0);
         }
     };
     if (tuned2 && (flags & IBH_IMAGE_ONLY) && p->img_all_fz && !p->fuse_all) {
@@ -1624,11 +1642,12 @@ int ibh_step_advection(ibh_part* p, const float* u, float* u_out, const float* C
     int rc = 0;
     if (p->nd == 2 && p->bs == 8 && p->nblk > 0 && p->fuse_all && ibh_quad && p->nq[0] > 0 && p->n_dt == 0) {
         // sweep and update in one launch: the quad sweep stores u + dt * residual (its cells of u are in registers)
-        const int32_t nq = p->nq[0], ns = p->nqs[0];
-        const int32_t nwgq = (nq + WPB - 1) / WPB, nwgs = (ns + WPB - 1) / WPB;
+        const int32_t npair = ibh_pairs ? p->npair : 0;
+        const int32_t nq = p->nq[0], ns = npair ? p->nqs2 : p->nqs[0];
+        const int32_t nwgq = (nq + npair + WPB - 1) / WPB, nwgs = (ns + WPB - 1) / WPB;
         hipLaunchKernelGGL((k_sweep_quad<false, false, 127, true>), dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C,
                            (uint32_t)ldc, u_out, p->qd[0], p->qtab[0], nq, nwgq, p->blocks2, p->htab, p->etab, p->dtab,
-                           p->qsingles[0], ns, nwgs, ibh_quad_singles_first, 1, dt_dev);
+                           npair ? p->qsingles2 : p->qsingles[0], ns, nwgs, ibh_quad_singles_first, 1, dt_dev, npair);
         IBH_LAUNCH_CHECK();
     } else {
         if ((rc = ibh_residual_advection(p, u, C, ldc, u_out, 0))) return rc;

@@ -113,13 +113,17 @@ __device__ __forceinline__ float jst_max2(float g1, float a1, float rh1, float g
 
 // Lane table of the quad sweep, built at compile time: per lane 8 words, LDS byte offsets packed two per word (see
 // sweep_quad for the meaning of the fields), the lane's cell offset inside the quad and its deeper-cell step.
+// HALF: the tile of a PAIR of blocks (16 x 8 cells: lower-left, lower-right), swept by the same wave code -- lanes t >= 8
+// own no cells (they still own the slots of bottom / top boundary cells x = t), the top side sits on row 7
+template <bool HALF>
 struct QuadLaneTab {
     uint32_t w[64][8];
     constexpr QuadLaneTab() : w() {
         for (int lane = 0; lane < 64; ++lane) {
             const int g = lane >> 4, t = lane & 15, tl = lane & 7, lhs = lane >> 3;
-            const bool g0 = g == 0, g3 = g == 3, lr = g0 || g3, t0 = t == 0, t15 = t == 15;
-            const int bx = g0 ? 0 : g3 ? 15 : t, by = lr ? t : g == 1 ? 0 : 15;
+            const int ytop = HALF ? 7 : 15;
+            const bool g0 = g == 0, g3 = g == 3, lr = g0 || g3, t0 = t == 0, t15 = t == ytop;
+            const int bx = g0 ? 0 : g3 ? 15 : t, by = lr ? t : g == 1 ? 0 : ytop;
             const int pos_b = by * QUAD_PITCH + bx;
             const int pos_b1 = lr ? (t ^ 1) * QUAD_PITCH + bx : by * QUAD_PITCH + (t ^ 1);
             const int pos_own = t * QUAD_PITCH + 4 * g;
@@ -140,7 +144,8 @@ struct QuadLaneTab {
         }
     }
 };
-__device__ const QuadLaneTab lane_tab = QuadLaneTab();
+__device__ const QuadLaneTab<false> lane_tab = QuadLaneTab<false>();
+__device__ const QuadLaneTab<true> lane_tab_half = QuadLaneTab<true>();
 
 // ---- the wave's lane-only state: LDS pointers from a compile-time table (two 16-byte loads; computing them costs
 // ~90 vector instructions per wave, a fifth of a quad's arithmetic), lane classes from the lane id
@@ -160,15 +165,18 @@ struct QuadLane {
     uint32_t a0off;  // this lane's first cell relative to the quad's
     int delta;       // deeper cell of a halo cell: -1, -8, +8, +1
     int lane, tl, lhs;
-    bool g0, g3, lr, dny, t15;
+    bool g0, g3, lr, dny, t15;   // t15: this lane's cells are the top row of the tile (t = 15; pair tiles: t = 7)
+    bool active;     // this lane owns cells (pair tiles: t < 8)
     float sgn;       // +1: the quad's cell is the owner of the edge face (top / right), -1 on left / bottom
 };
 
+template <bool HALF = false>
 __device__ __forceinline__ QuadLane quad_lane(float* lds, int lane) {
     QuadLane G;
     char* const L = (char*)lds;
-    const uint4 w0 = *(const uint4*)(lane_tab.w[lane]);
-    const uint4 w1 = *(const uint4*)(lane_tab.w[lane] + 4);
+    const uint32_t* const tab = HALF ? lane_tab_half.w[lane] : lane_tab.w[lane];
+    const uint4 w0 = *(const uint4*)(tab);
+    const uint4 w1 = *(const uint4*)(tab + 4);
 #define QL_LO(w) ((w) & 0xffffu)
 #define QL_HI(w) ((w) >> 16)
     G.p_own = (float*)(L + QL_LO(w0.x));
@@ -187,7 +195,8 @@ __device__ __forceinline__ QuadLane quad_lane(float* lds, int lane) {
 #undef QL_HI
     // from the lane id (the own-cell loads then wait for the descriptor only):
     // 64 ((g >> 1) + 2 (t >> 3)) + 4 (g & 1) + 8 (t & 7)
-    G.a0off = ((lane & 7) << 3) | ((lane & 8) << 4) | ((lane & 16) >> 2) | ((lane & 32) << 1);
+    // (pair tiles: lanes t >= 8 repeat the cells of t - 8 -- valid loads, nothing stored)
+    G.a0off = ((lane & 7) << 3) | (HALF ? 0 : ((lane & 8) << 4)) | ((lane & 16) >> 2) | ((lane & 32) << 1);
     G.delta = (int)w1.w;
     G.lane = lane;
     G.tl = lane & 7;
@@ -196,7 +205,8 @@ __device__ __forceinline__ QuadLane quad_lane(float* lds, int lane) {
     G.g3 = lane >= 48;
     G.lr = G.g0 || G.g3;
     G.dny = !G.lr;
-    G.t15 = (lane & 15) == 15;
+    G.t15 = (lane & 15) == (HALF ? 7 : 15);
+    G.active = !HALF || (lane & 8) == 0;
     G.sgn = lane >= 32 ? 1.0f : -1.0f;
     // neutral ring rows: u ring unused, sensor correction 0, weight 1/2 (read by lanes that are not on the y edges)
     ((float*)(L + 4 * (QUAD_OFF_RING + 64 + 32)))[lane & 15] = 0.0f;
@@ -295,7 +305,7 @@ __device__ __forceinline__ QuadHalo quad_load_halo_paired(const QuadLane& G, con
 
 // ---- the arithmetic of one quad.  STAMP: phase time stamps of the wave (100 MHz ticks) for scripts/wave_timeline.py
 // STEP: the explicit update u + dt * residual is stored instead of the residual (ibh_step_advection)
-template <bool STAMP, bool STEP = false>
+template <bool STAMP, bool STEP = false, bool HALF = false>
 __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T, const QuadOwn& O, const QuadHalo& H,
                                              float* __restrict__ ud, unsigned long long* stamps, float dt = 0.0f) {
     using blk2::wave_lds_sync;
@@ -356,6 +366,7 @@ __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T
         for (int c = 0; c < 4; ++c) {
             uB[c] = dpp_shr1(rM[c], U[c]);
             uT[c] = dpp_shl1(rM[c], U[c]);
+            if constexpr (HALF) uT[c] = t15 ? rM[c] : uT[c];  // (lane t = 8 exists: the top row takes the ring itself)
         }
         const v4f dT = uT - U, dB = U - uB;
         SY = qT * dT + qB * dB;
@@ -452,23 +463,23 @@ __device__ __forceinline__ void quad_compute(const QuadLane& G, const QuadTab& T
             FTf[c] = t15 ? ex[c] : FT[c];
         }
         const v4f res = -((FRf - FL) * rhx) - ((FTf - FB) * rhy);
-        *(v4f_g*)((char*)ud + ((size_t)O.a0 << 2)) = STEP ? U + dt * res : res;
+        if (!HALF || G.active) *(v4f_g*)((char*)ud + ((size_t)O.a0 << 2)) = STEP ? U + dt * res : res;
     }
 }
 
 // ---- one quad by one wave.  (Sweeping several quads per wave with the next quad's loads in flight was measured and
 // dropped: the prefetch registers cost a wave per SIMD -- 124 VGPRs against 89 -- and the sweep lives on wave-level
 // parallelism: 6.1 us against 5.5 us at 0.87 M cells, no gain at 3.47 M.)
-template <bool STAMP, int GM = 127, bool STEP = false>
+template <bool STAMP, int GM = 127, bool STEP = false, bool HALF = false>
 __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, const int32_t* __restrict__ qtab, int32_t q,
                                            const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
                                            float* __restrict__ ud, float* lds, int lane,
                                            unsigned long long* stamps = nullptr, float dt = 0.0f) {
-    const QuadLane G = quad_lane(lds, lane);
+    const QuadLane G = quad_lane<HALF>(lds, lane);
     const QuadTab T = quad_load_tab(qd, qtab, q, lane);  // everything that needs the quad's index only is in flight
     const QuadOwn O = quad_load_own(G, T, u, C, ldc);
     const QuadHalo H = GM == 127 ? quad_load_halo_paired(G, T, u, C, ldc) : quad_load_halo<GM == 126 ? 127 : GM>(G, T, u, C, ldc);
-    quad_compute<STAMP, STEP>(G, T, O, H, ud, stamps, dt);
+    quad_compute<STAMP, STEP, HALF>(G, T, O, H, ud, stamps, dt);
 }
 
 #pragma clang fp contract(off)

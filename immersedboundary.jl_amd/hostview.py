@@ -14,7 +14,7 @@ BLOCK_DTYPE = np.dtype([("base", "<i4"), ("type", "<i4", (4,)), ("nb", "<i4", (4
                         ("h", "<f4", (2,)), ("rh", "<f4", (2,)), ("q", "<f4", (4,)), ("rt", "<f4", (4,)),
                         ("dt", "<i4")])
 QUAD_DTYPE = np.dtype([("base", "<i4"), ("cls", "<u4"), ("rh", "<f4", (2,))])
-(BLOCKS, HTAB, ETAB, FUSABLE, QUAD_DESC, QUAD_TAB, SINGLES, COUNTS, INFO) = range(9)
+(BLOCKS, HTAB, ETAB, FUSABLE, QUAD_DESC, QUAD_TAB, SINGLES, COUNTS, INFO, PAIR_DESC, PAIR_TAB, SINGLES2) = range(12)
 SIDE_SAME, SIDE_MIRROR, SIDE_COARSE, SIDE_FINE, SIDE_GENERAL = range(5)
 
 
@@ -59,7 +59,11 @@ def analyze2(part):
             cnt = get(COUNTS, np.int64, k)
             out[f"quads_{name}"] = dict(desc=get(QUAD_DESC, QUAD_DTYPE, k), tab=get(QUAD_TAB, np.int32, k).reshape(-1, 160),
                                         singles=get(SINGLES, np.int32, k), n_interior=int(cnt[2]),
-                                        n_singles_interior=int(cnt[4]))
+                                        n_singles_interior=int(cnt[4]),
+                                        # pair tiles among the single blocks (set 0 of one-partition domains) and what is left
+                                        pair_desc=get(PAIR_DESC, QUAD_DTYPE, k),
+                                        pair_tab=get(PAIR_TAB, np.int32, k).reshape(-1, 160),
+                                        singles2=get(SINGLES2, np.int32, k))
             out.update(fuse_all=bool(cnt[5]), img_all_fz=bool(cnt[6]), nB1=int(cnt[7]))
     finally:
         call("ibh_host2d_destroy", h)

@@ -143,7 +143,10 @@ enum {
     IBH_H2D_QUAD_TAB = 5,  /* int32 [nq][160] */
     IBH_H2D_SINGLES = 6,   /* int32 block indices outside quads */
     IBH_H2D_COUNTS = 7,    /* int64 [8]: blocks, quads, interior quads, singles, interior singles, fuse_all, img_all_fz, nB1 */
-    IBH_H2D_INFO = 8       /* int64 [12] as ibh_partition_info */
+    IBH_H2D_INFO = 8,      /* int64 [12] as ibh_partition_info */
+    IBH_H2D_PAIR_DESC = 9, /* pair tiles (two blocks side by side, base and base + 64) in the quad format; set 0 only */
+    IBH_H2D_PAIR_TAB = 10, /* int32 [npair][160] */
+    IBH_H2D_SINGLES2 = 11  /* int32 block indices outside quads and pairs */
 };
 int ibh_analyze2_host(ibh_host2d** out, int32_t nc, const float* spacing, const int32_t* nf,
                       const int32_t* const* owners, const int32_t* const* neighbors,

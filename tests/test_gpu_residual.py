@@ -307,6 +307,7 @@ def test_quad_sweep(adv_mesh, rae_mesh_small, case, kind):
     (part,) = dom.partitions.values()
     dpart = ibamd.to_backend(part, ibamd.hip)
     assert dpart.info["quads"] > 0 and dpart.info["quads"] * 4 + dpart.info["quad_singles"] == dpart.info["full_blocks"]
+    assert dpart.info["quad_pairs"] * 2 <= dpart.info["quad_singles"]
     u = seeded_field(part.centers, kind=kind)
     C = np.stack([np.ones_like(u), f32(0.5) + seeded_field(part.centers, seed=3) * f32(0.1)], axis=1)
     exp = rc.CPart(part).residual_advection(u, C)

@@ -37,6 +37,16 @@ def test_quad_model_matches_oracle(adv_mesh, rae_mesh_small, case, kind):
             covered[bybase[int(d["base"]) + 64 * k]] += 1
     assert np.all(covered == 1)
     assert nq > 0.5 * len(blocks) / 4
+    # pair tiles: two single blocks side by side with consecutive bases, each single block in at most one pair; what is
+    # left is singles2
+    inpair = np.zeros(len(blocks), dtype=int)
+    for d in Q["pair_desc"]:
+        for k in range(2):
+            inpair[bybase[int(d["base"]) + 64 * k]] += 1
+    assert inpair.max() <= 1 and np.all(inpair[Q["singles"]] + np.isin(Q["singles"], Q["singles2"]) == 1)
+    assert len(Q["singles2"]) + 2 * len(Q["pair_desc"]) == len(Q["singles"])
+    pcls = np.array([[(int(c) >> (4 * l)) & 15 for l in range(8)] for c in Q["pair_desc"]["cls"]]).reshape(-1, 8)
+    assert np.all((pcls == 0) | (pcls == 2) | (pcls == 3))
     classes = np.array([[(int(c) >> (4 * l)) & 15 for l in range(8)] for c in Q["desc"]["cls"]])
     assert ({2, 3} if case == "rae" else {2}) <= set(np.unique(classes))  # coarse (and fine) half-sides are exercised
     u = seeded_field(part.centers, kind=kind)
