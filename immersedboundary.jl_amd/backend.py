@@ -235,6 +235,7 @@ class DevicePartition:
                          quads=info[12] if self.nd == 2 else 0, quad_singles=info[13], image_quads=info[14],
                          image_quad_singles=info[15], row_sweep=bool(info[16]), direct_sides=info[17],
                          quad_pairs=info[18] if self.nd == 2 else 0,   # pair tiles among the blocks outside quads
+                         quad_arith_half_sides=info[19] if self.nd == 2 else 0,   # of 8 per quad: halo ids computed, not read
                          # 3-D single-kernel sweeps: rim neighbours of halo cells that are four finer cells
                          rim4_rows=info[12] if self.nd == 3 else 0)
 

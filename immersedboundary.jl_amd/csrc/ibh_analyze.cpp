@@ -372,6 +372,28 @@ void ibh_analyze_blocks2(const HostPartView& v, std::vector<BlockDesc2>& blocks,
 // other and whose 8 outer half-sides are SAME / COARSE / FINE with arithmetic deeper cells (dt < 0).  89.6 % of the
 // blocks of the 0.87 M-cell RAE2822 mesh sit in such groups (the four leaf children of a quadtree node).
 // ------------------------------------------------------------------------------------------
+// companion row of a quad / pair row (IBH_QAUX): end ids + per half-side the origin of arithmetic halo ids or -1
+static void quad_aux_row(const int32_t* row, uint32_t cls, std::vector<int32_t>& aux) {
+    const size_t a0 = aux.size();
+    aux.resize(a0 + IBH_QAUX);
+    for (int e = 0; e < 32; ++e) aux[a0 + e] = row[128 + e];
+    for (int l = 0; l < 8; ++l) {
+        const int g = l >> 1, half = l & 1;
+        const uint32_t ty = (cls >> (4 * l)) & 15u;
+        const int stride = (g == 0 || g == 3) ? 8 : 1;
+        const int32_t* ids = row + 2 * (16 * g + 8 * half);
+        int32_t orig = -1;
+        if (ty == SIDE_SAME || ty == SIDE_COARSE) {
+            orig = ids[0];
+            for (int t = 0; t < 8 && orig >= 0; ++t) {
+                const int32_t want = ids[0] + stride * (ty == SIDE_COARSE ? (t >> 1) : t);
+                if (ids[2 * t] != want || ids[2 * t + 1] != want) orig = -1;
+            }
+        }
+        aux[a0 + 32 + l] = orig;
+    }
+}
+
 void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<int32_t>& htab,
                       const std::vector<int32_t>& etab, const std::vector<char>& cand, int32_t nB1, QuadSet2& out,
                       int32_t nc) {
@@ -456,6 +478,7 @@ void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<i
                     for (int e = 0; e < 4; ++e) out.qtab[row + 128 + 4 * l + e] = etab[(size_t)bi * 16 + s * 4 + e];
                 }
             out.qd.push_back(d);
+            quad_aux_row(out.qtab.data() + row, d.cls, out.qaux);
             if (pass == 0) out.nq_int++;
         }
     for (int pass = 0; pass < 2; ++pass)
@@ -516,6 +539,7 @@ void ibh_build_quads2(const std::vector<BlockDesc2>& blocks, const std::vector<i
                 for (int e = 0; e < 4; ++e) out.ptab[row + 128 + 4 * l + e] = etab[(size_t)bi * 16 + s * 4 + e];
             }
         out.pd.push_back(d);
+        quad_aux_row(out.ptab.data() + row, d.cls, out.paux);
     }
     for (int32_t b : out.singles)
         if (!paired[b]) out.singles2.push_back(b);

@@ -297,9 +297,19 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
                 if ((rc = ibh_upload(&p->qd[k], qd.data(), qd.size()))) return rc;
                 if ((rc = ibh_upload(&p->qtab[k], qt.data(), qt.size()))) return rc;
                 if ((rc = ibh_upload(&p->qsingles2, Q.singles2.data(), Q.singles2.size()))) return rc;
+                std::vector<int32_t> qa(Q.qaux);
+                qa.insert(qa.end(), Q.paux.begin(), Q.paux.end());
+                if ((rc = ibh_upload(&p->qaux[k], qa.data(), qa.size()))) return rc;
             } else {
                 if ((rc = ibh_upload(&p->qd[k], Q.qd.data(), Q.qd.size()))) return rc;
                 if ((rc = ibh_upload(&p->qtab[k], Q.qtab.data(), Q.qtab.size()))) return rc;
+                if ((rc = ibh_upload(&p->qaux[k], Q.qaux.data(), Q.qaux.size()))) return rc;
+            }
+            {
+                int64_t arith = 0;
+                for (size_t i = 0; i < Q.qaux.size(); i += IBH_QAUX)
+                    for (int l = 0; l < 8; ++l) arith += Q.qaux[i + 32 + l] >= 0;
+                if (k == 0) p->info[19] = arith;     // half-sides of the quads whose halo ids are arithmetic
             }
             if ((rc = ibh_upload(&p->qsingles[k], Q.singles.data(), Q.singles.size()))) return rc;
         }
@@ -462,6 +472,7 @@ int ibh_partition_destroy(ibh_part* p) {
     for (int k = 0; k < 2; ++k) {
         hipFree(p->qd[k]);
         hipFree(p->qtab[k]);
+        hipFree(p->qaux[k]);
         hipFree(p->qsingles[k]);
         if (k == 0) hipFree(p->qsingles2);
     }

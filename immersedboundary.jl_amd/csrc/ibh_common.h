@@ -48,9 +48,16 @@ struct QuadDesc2 {
 // sub-face k); [128,160) end ids, entry 4*l + e (e = 0,1 low end k = 0,1; 2,3 high end) -- the per-block halo / end
 // tables of ibh_analyze.cpp re-indexed for the quad's lanes.
 #define IBH_QROW 160
+// Compact companion row (IBH_QAUX ints per quad / pair): [0,32) the end ids of the row above, [32,40) per half-side l the
+// halo cell id of its boundary cell 0 where the ids of the half-side are ARITHMETIC -- SAME: id(t) = orig + stride t,
+// COARSE: id(t) = orig + stride (t >> 1), stride = 8 on left / right sides, 1 on bottom / top, both sub-face slots the same
+// cell (verified against the row by the builder) -- or -1: FINE half-sides and anything else read the 128 ids of the row.
+// A sweep that takes its ids from here touches 176 bytes of tables per quad instead of 656.
+#define IBH_QAUX 40
 struct QuadSet2 {
     std::vector<QuadDesc2> qd;     // interior-phase quads first (n_int of them)
     std::vector<int32_t> qtab;     // [nq][IBH_QROW]
+    std::vector<int32_t> qaux, paux;  // [nq][IBH_QAUX], [npair][IBH_QAUX]
     std::vector<int32_t> singles;  // candidate blocks outside quads (block table indices), interior-phase ones first
     int32_t nq_int = 0, ns_int = 0;
     // pairs: two blocks of `singles` side by side in x with consecutive bases (a 16 x 8 tile swept by one wave of the quad
@@ -115,6 +122,7 @@ struct ibh_part {
     // quad sweeps (ibh_quad2d.h): set 0 = all blocks (used when fuse_all), set 1 = image blocks (used when img_all_fz)
     QuadDesc2* qd[2] = {nullptr, nullptr};
     int32_t* qtab[2] = {nullptr, nullptr};
+    int32_t* qaux[2] = {nullptr, nullptr};
     int32_t* qsingles[2] = {nullptr, nullptr};
     int32_t nq[2] = {0, 0}, nq_int[2] = {0, 0}, nqs[2] = {0, 0}, nqs_int[2] = {0, 0};
     int32_t npair = 0, nqs2 = 0;          // set 0 only: pair tiles (stored behind the quads in qd / qtab), blocks left over

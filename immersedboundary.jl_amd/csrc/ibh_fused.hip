@@ -682,7 +682,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
                                                          const int32_t* __restrict__ dtab,
                                                          const int32_t* __restrict__ singles, int32_t ns, int32_t nwgs,
                                                          int32_t singles_first, int32_t siters,
-                                                         const float* __restrict__ dtp = nullptr, int32_t npair = 0) {
+                                                         const float* __restrict__ dtp = nullptr, int32_t npair = 0,
+                                                         const int32_t* __restrict__ qaux = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[RS && WPB * ROWS_LDS > QUAD_WG_LDS ? WPB * ROWS_LDS : QUAD_WG_LDS];
     float dt = 0.0f;
     if constexpr (STEP) dt = *dtp;  // (scalar load: the time step lives on the device, ibh_timestep_advection)
@@ -698,10 +699,10 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict
         const int32_t q = __builtin_amdgcn_readfirstlane(xcd_remap(wgq, nwgq) * WPB + wave);
         if (q < nq)
             quad2::sweep_quad<STAMP, GM, STEP>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane,
-                                               STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr, dt);
+                                               STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr, dt, qaux);
         else if (q < nq + npair)  // pair tiles: entries nq .. of the same arrays, the HALF form of the same wave code
             quad2::sweep_quad<STAMP, GM, STEP, true>(qd, qtab, q, u, C, ldc, ud, lds + wave * QUAD_LDS, lane,
-                                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr, dt);
+                                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)slot * 8 : nullptr, dt, qaux);
     } else {
         const int32_t wgs = singles_first ? (int32_t)blockIdx.x : (int32_t)blockIdx.x - nwgq;
         if constexpr (RS) {
@@ -1309,6 +1310,7 @@ int ibh_rows = getenv("IBH_ROWS") ? atoi(getenv("IBH_ROWS")) : 0;
 int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_iters = 1;
 int ibh_quad_singles_first = getenv("IBH_SINGLES_FIRST") ? atoi(getenv("IBH_SINGLES_FIRST")) : 0;
 int ibh_pairs = getenv("IBH_PAIRS") ? atoi(getenv("IBH_PAIRS")) : 1;  // pair tiles for the blocks outside quads ("pairs")
+int ibh_arith_ids = getenv("IBH_ARITH_IDS") ? atoi(getenv("IBH_ARITH_IDS")) : 1;  // quad sweep: halo ids from the companion rows
 int ibh_transport_blocks = 1;  // tuning key "transport_blocks" 0: the face-list transport kernel everywhere (A/B, tests)
 int ibh_rows_singles = getenv("IBH_ROWS_SINGLES") ? atoi(getenv("IBH_ROWS_SINGLES")) : -1;
 // measured (profiles/r3_final/rows_for_singles.json): 1 441 single blocks 5.96 -> 10.6 us, 5 937: 15.5 -> 19.0 us (a row wave
@@ -1370,6 +1372,7 @@ int ibh_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "rows_singles")) ibh_rows_singles = value;
     else if (!strcmp(key, "transport_blocks")) ibh_transport_blocks = value;
     else if (!strcmp(key, "pairs")) ibh_pairs = value;
+    else if (!strcmp(key, "arith_ids")) ibh_arith_ids = value;
     else return ibh_fail(-1, "ibh_set_tuning: unknown key", __FILE__, __LINE__);
     return 0;
 }
@@ -1498,7 +1501,7 @@ int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t 
     hipLaunchKernelGGL((k_sweep_quad<DT, STAMP, ##__VA_ARGS__>), dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C,              \
                        (uint32_t)ldc, ud, p->qd[k] + q0, p->qtab[k] + (size_t)q0 * IBH_QROW, q1 - q0, nwgq,            \
                        p->blocks2, p->htab, p->etab, p->dtab, slist + s0, s1 - s0, nwgs, ibh_quad_singles_first, siters,          \
-                       (const float*)nullptr, npair)
+                       (const float*)nullptr, npair, ibh_arith_ids ? p->qaux[k] + (size_t)q0 * IBH_QAUX : (const int32_t*)nullptr)
         if (rows_inside) QUAD_LAUNCH(false, false, 127, false, true);
         else if (p->n_dt > 0) QUAD_LAUNCH(true, false);
         else if (ibh_quad_variant == 4) QUAD_LAUNCH(false, true);
@@ -1647,7 +1650,8 @@ int ibh_step_advection(ibh_part* p, const float* u, float* u_out, const float* C
         const int32_t nwgq = (nq + npair + WPB - 1) / WPB, nwgs = (ns + WPB - 1) / WPB;
         hipLaunchKernelGGL((k_sweep_quad<false, false, 127, true>), dim3(nwgq + nwgs), dim3(64 * WPB), 0, ibh_stream, u, C,
                            (uint32_t)ldc, u_out, p->qd[0], p->qtab[0], nq, nwgq, p->blocks2, p->htab, p->etab, p->dtab,
-                           npair ? p->qsingles2 : p->qsingles[0], ns, nwgs, ibh_quad_singles_first, 1, dt_dev, npair);
+                           npair ? p->qsingles2 : p->qsingles[0], ns, nwgs, ibh_quad_singles_first, 1, dt_dev, npair,
+                           ibh_arith_ids ? p->qaux[0] : (const int32_t*)nullptr);
         IBH_LAUNCH_CHECK();
     } else {
         if ((rc = ibh_residual_advection(p, u, C, ldc, u_out, 0))) return rc;

@@ -228,11 +228,25 @@ struct QuadHalo {  // needs the table entries
     v2f hu, hd, hc;
     float eu;
 };
+// qaux (or null): the compact companion rows (IBH_QAUX, ibh_common.h) -- half-sides with arithmetic halo ids are computed
+// from one origin id, only FINE half-sides (and the rare others) read their part of the 640-byte row
 __device__ __forceinline__ QuadTab quad_load_tab(const QuadDesc2* __restrict__ qd, const int32_t* __restrict__ qtab,
-                                                 int32_t q, int lane) {
+                                                 int32_t q, int lane, const int32_t* __restrict__ qaux = nullptr) {
     QuadTab T;
     T.d = qd[q];
     const int32_t* row = qtab + (size_t)q * IBH_QROW;
+    if (qaux) {
+        const int32_t* aux = qaux + (size_t)q * IBH_QAUX;
+        const int lhs = lane >> 3, tl = lane & 7;
+        const int32_t orig = aux[32 + lhs];
+        T.eid = (uint32_t)aux[lane & 31];
+        const bool isC = ((T.d.cls >> (4 * lhs)) & 15u) == SIDE_COARSE;
+        const bool lr = lane < 16 || lane >= 48;
+        const int32_t id = orig + (lr ? 8 : 1) * (isC ? tl >> 1 : tl);
+        T.hid = v2i{id, id};
+        if (orig < 0) T.hid = *(const v2i*)(row + 2 * lane);
+        return T;
+    }
     T.hid = *(const v2i*)(row + 2 * lane);
     T.eid = (uint32_t)row[128 + (lane & 31)];
     return T;
@@ -474,9 +488,10 @@ template <bool STAMP, int GM = 127, bool STEP = false, bool HALF = false>
 __device__ __forceinline__ void sweep_quad(const QuadDesc2* __restrict__ qd, const int32_t* __restrict__ qtab, int32_t q,
                                            const float* __restrict__ u, const float* __restrict__ C, uint32_t ldc,
                                            float* __restrict__ ud, float* lds, int lane,
-                                           unsigned long long* stamps = nullptr, float dt = 0.0f) {
+                                           unsigned long long* stamps = nullptr, float dt = 0.0f,
+                                           const int32_t* __restrict__ qaux = nullptr) {
     const QuadLane G = quad_lane<HALF>(lds, lane);
-    const QuadTab T = quad_load_tab(qd, qtab, q, lane);  // everything that needs the quad's index only is in flight
+    const QuadTab T = quad_load_tab(qd, qtab, q, lane, qaux);  // everything that needs the quad's index only is in flight
     const QuadOwn O = quad_load_own(G, T, u, C, ldc);
     const QuadHalo H = GM == 127 ? quad_load_halo_paired(G, T, u, C, ldc) : quad_load_halo<GM == 126 ? 127 : GM>(G, T, u, C, ldc);
     quad_compute<STAMP, STEP, HALF>(G, T, O, H, ud, stamps, dt);
