@@ -672,7 +672,10 @@ __device__ __forceinline__ void dbg_stamp(int32_t slot, int k, unsigned long lon
 // RS: the blocks outside quads take the row sweep, EIGHT per wave (rows2::sweep_rows over the list), instead of the per-block
 // body -- `nwgs`, `siters` then count waves of eight
 template <bool DT, bool STAMP, int GM = 127, bool STEP = false, bool RS = false>
-__global__ __launch_bounds__(64 * WPB) void k_sweep_quad(const float* __restrict__ u, const float* __restrict__ C,
+#ifndef QS_WAVES
+#define QS_WAVES 5
+#endif
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(QS_WAVES, QS_WAVES))) void k_sweep_quad(const float* __restrict__ u, const float* __restrict__ C,
                                                          uint32_t ldc, float* __restrict__ ud,
                                                          const QuadDesc2* __restrict__ qd,
                                                          const int32_t* __restrict__ qtab, int32_t nq, int32_t nwgq,
