@@ -435,6 +435,8 @@ int ibh_host2d_get(const ibh_host2d* h, int what, int set, void* dst, int64_t ca
         case IBH_H2D_PAIR_DESC: src = Q.pd.data(); n = (int64_t)(Q.pd.size() * sizeof(QuadDesc2)); break;
         case IBH_H2D_PAIR_TAB: src = Q.ptab.data(); n = (int64_t)(Q.ptab.size() * 4); break;
         case IBH_H2D_SINGLES2: src = Q.singles2.data(); n = (int64_t)(Q.singles2.size() * 4); break;
+        case IBH_H2D_QUAD_AUX: src = Q.qaux.data(); n = (int64_t)(Q.qaux.size() * 4); break;
+        case IBH_H2D_PAIR_AUX: src = Q.paux.data(); n = (int64_t)(Q.paux.size() * 4); break;
         case IBH_H2D_COUNTS: src = counts; n = (int64_t)sizeof(counts); break;
         case IBH_H2D_INFO: src = H.info; n = (int64_t)sizeof(H.info); break;
         default: return ibh_fail(-1, "ibh_host2d_get: unknown item", __FILE__, __LINE__);

@@ -14,7 +14,8 @@ BLOCK_DTYPE = np.dtype([("base", "<i4"), ("type", "<i4", (4,)), ("nb", "<i4", (4
                         ("h", "<f4", (2,)), ("rh", "<f4", (2,)), ("q", "<f4", (4,)), ("rt", "<f4", (4,)),
                         ("dt", "<i4")])
 QUAD_DTYPE = np.dtype([("base", "<i4"), ("cls", "<u4"), ("rh", "<f4", (2,))])
-(BLOCKS, HTAB, ETAB, FUSABLE, QUAD_DESC, QUAD_TAB, SINGLES, COUNTS, INFO, PAIR_DESC, PAIR_TAB, SINGLES2) = range(12)
+(BLOCKS, HTAB, ETAB, FUSABLE, QUAD_DESC, QUAD_TAB, SINGLES, COUNTS, INFO, PAIR_DESC, PAIR_TAB, SINGLES2, QUAD_AUX,
+ PAIR_AUX) = range(14)
 SIDE_SAME, SIDE_MIRROR, SIDE_COARSE, SIDE_FINE, SIDE_GENERAL = range(5)
 
 
@@ -63,7 +64,10 @@ def analyze2(part):
                                         # pair tiles among the single blocks (set 0 of one-partition domains) and what is left
                                         pair_desc=get(PAIR_DESC, QUAD_DTYPE, k),
                                         pair_tab=get(PAIR_TAB, np.int32, k).reshape(-1, 160),
-                                        singles2=get(SINGLES2, np.int32, k))
+                                        singles2=get(SINGLES2, np.int32, k),
+                                        # companion rows: 32 end ids + per half-side the origin of arithmetic halo ids / -1
+                                        aux=get(QUAD_AUX, np.int32, k).reshape(-1, 40),
+                                        pair_aux=get(PAIR_AUX, np.int32, k).reshape(-1, 40))
             out.update(fuse_all=bool(cnt[5]), img_all_fz=bool(cnt[6]), nB1=int(cnt[7]))
     finally:
         call("ibh_host2d_destroy", h)

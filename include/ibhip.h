@@ -118,7 +118,11 @@ enum { IBH_EW_PUSH_ARRAY = 32, IBH_EW_PUSH_SCALAR = 33 };
 int ibh_ew_eval(int64_t n, int nv, int nprog, const int32_t* prog, int narr, const float* const* arrays,
                 const int32_t* arr_nv, int nscal, const float* scalars, float* out);
 
-/* Measurement switches of the kernels (A/B runs inside one process); key "quad_variant": variant of the quad sweep. */
+/* Measurement switches of the kernels (A/B runs inside one process, no effect on results beyond rounding):
+ *   "quad_variant"  variant of the quad / 3-D sweeps (4: wave time stamps; 512, 518: round-2 3-D kernels; ...)
+ *   "quad_parts" 1 / 2 only the quads / only the single blocks; "quad_singles_first" grid order; "quad_singles_iters"
+ *   "rows" 1: the row sweep instead of the quad sweep; "rows_singles" -1 by size / 0 / 1 second launch / 2 inside the launch
+ *   "pairs" 0: no pair tiles; "arith_ids" 0: halo ids from the table rows; "transport_blocks" 0: face-list transport kernel */
 int ibh_set_tuning(const char* key, int value);
 /* Wave timeline of the quad sweep (quad_variant 4): 8 x uint64 per wave {start, end (100 MHz ticks), HW_ID, is_quad, 4 phase stamps of a quad wave}. */
 int ibh_debug_buffer(void* device_buffer);
@@ -146,7 +150,9 @@ enum {
     IBH_H2D_INFO = 8,      /* int64 [12] as ibh_partition_info */
     IBH_H2D_PAIR_DESC = 9, /* pair tiles (two blocks side by side, base and base + 64) in the quad format; set 0 only */
     IBH_H2D_PAIR_TAB = 10, /* int32 [npair][160] */
-    IBH_H2D_SINGLES2 = 11  /* int32 block indices outside quads and pairs */
+    IBH_H2D_SINGLES2 = 11, /* int32 block indices outside quads and pairs */
+    IBH_H2D_QUAD_AUX = 12, /* int32 [nq][40] companion rows: 32 end ids + 8 origins of arithmetic halo ids (or -1) */
+    IBH_H2D_PAIR_AUX = 13  /* int32 [npair][40] */
 };
 int ibh_analyze2_host(ibh_host2d** out, int32_t nc, const float* spacing, const int32_t* nf,
                       const int32_t* const* owners, const int32_t* const* neighbors,

@@ -49,6 +49,24 @@ def test_quad_model_matches_oracle(adv_mesh, rae_mesh_small, case, kind):
     assert np.all((pcls == 0) | (pcls == 2) | (pcls == 3))
     classes = np.array([[(int(c) >> (4 * l)) & 15 for l in range(8)] for c in Q["desc"]["cls"]])
     assert ({2, 3} if case == "rae" else {2}) <= set(np.unique(classes))  # coarse (and fine) half-sides are exercised
+    # companion rows: where a half-side carries an origin, origin + stride * t (t >> 1 on COARSE half-sides) IS the row's
+    # halo id of both sub-face slots; FINE half-sides never do; the end ids are the row's
+    for tab, aux, cls in ((Q["tab"], Q["aux"], classes), (Q["pair_tab"], Q["pair_aux"], pcls)):
+        assert aux.shape[0] == tab.shape[0]
+        if not len(tab):
+            continue
+        assert np.array_equal(aux[:, :32], tab[:, 128:160])
+        ids = tab[:, :128].reshape(-1, 4, 2, 8, 2)                       # [quad][g][half][t][k]
+        orig = aux[:, 32:40].reshape(-1, 4, 2)
+        ty = cls.reshape(-1, 4, 2)
+        stride = np.array([8, 1, 1, 8])[None, :, None, None]
+        tt = np.arange(8)[None, None, None, :]
+        step = np.where((ty == 2)[..., None], tt >> 1, tt)
+        want = orig[..., None] + stride * step
+        ok = orig >= 0
+        assert np.all(ty[ok] != 3)
+        assert np.array_equal(ids[..., 0][ok], want[ok]) and np.array_equal(ids[..., 1][ok], want[ok])
+        assert ok.mean() > 0.5
     u = seeded_field(part.centers, kind=kind)
     C = np.stack([np.ones_like(u), f32(0.5) + seeded_field(part.centers, seed=3) * f32(0.1)], axis=1)
     exp = rc.CPart(part).residual_advection(u, C)
