@@ -189,6 +189,10 @@ def main():
                          "reproduces the rccl exchange bit for bit at start-up, else rccl")
     ap.add_argument("--graph-batch", type=int, default=20,
                     help="sweeps captured per HIP graph (launch-bound loop; 0 = eager launches)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "c-loop"],
+                    help="how the K sweeps of a timed block are launched (one GPU, scalar sweep): HIP graphs of --graph-batch "
+                         "sweeps, or one C call that launches them back to back (ibh_residual_advection_n: the step loop of "
+                         "a compiled host); auto = both timed on a few blocks, the faster one is used and both are recorded")
     ap.add_argument("--step", default="sweep", choices=["sweep", "march", "config4", "config5"],
                     help="config4 (3-D workloads, --residual euler): a step = impose_bc! with FlowBC closures on the "
                          "immersed sphere and the far field (ghost-layer interpolation) + the Euler residual sweep; one "
@@ -626,6 +630,31 @@ def main():
             for _ in range(nsteps % batch):  # (the exchange kernel keeps its buffer parity on the device: any mix works)
                 step()
 
+    # the plain scalar sweep on one GPU can also be looped by ONE C call (no interpreter between the launches, no graph)
+    plain = world == 1 and hx is None and not (euler or march or config4 or config5)
+    launch_forms = None
+    c_loop = False
+    if plain and args.launch != "graph":
+        def run_c(nsteps):
+            with torch.cuda.stream(side):
+                ibamd.residual_advection_repeat(dpart, u, C, ud, nsteps, flags=flags)
+
+        def block_us(fn, blocks=30):
+            ts = []
+            for _ in range(blocks):
+                barrier()
+                t0 = time.perf_counter()
+                fn(args.steps)
+                barrier()
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            return ts[len(ts) // 2] / args.steps * 1e6
+        run(args.warmup)
+        run_c(args.warmup)
+        launch_forms = {"hip-graph": round(block_us(run), 3), "c-loop": round(block_us(run_c), 3)}
+        c_loop = args.launch == "c-loop" or launch_forms["c-loop"] < launch_forms["hip-graph"]
+        if c_loop:
+            run = run_c
     run(args.warmup)
     # EXACTLY `steps` sweeps between barrier + synchronize on both sides, max over ranks -- and that block `repeats`
     # times: a block is a fraction of a millisecond, its wall time moves with launch jitter; the median is reported
@@ -827,7 +856,9 @@ def main():
                             "block-fast-path, single kernel" if (fused or fused_e or fused3) else
                             "block-fast-path, single kernel on %d of %d blocks" % (inf["fusable_blocks"], inf["full_blocks"])
                             if mixed else "block-fast-path, two kernels"),
-                   "launch": f"hip-graph x{batch}" if batch else "eager",
+                   "launch": (f"c-loop x{args.steps} (one C call launches the sweeps of a block back to back)" if c_loop else
+                              f"hip-graph x{batch}" if batch else "eager"),
+                   "launch_forms_us_per_step": launch_forms,
                    "halo": None if hx is None else {"backend": args.backend, "exchange": halo_kind,
                                                     "overlap": bool(step_form["overlap"]), "timeouts": halo_timeouts,
                                                     "auto_step_us": auto_step_us,

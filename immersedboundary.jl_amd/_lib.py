@@ -70,6 +70,7 @@ _SIGS = {
     "ibh_scatter_rows": [c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_copy_rows": [c_vp, c_vp, C.c_int32, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_residual_advection": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
+    "ibh_residual_advection_n": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_int],
     "ibh_shear_rate_of_velocity": [c_vp, c_vp, c_i64, c_vp],
     "ibh_wray_agarwal_of": [c_vp, c_vp, c_vp, C.c_float, C.c_float, C.c_float, c_vp, c_vp, c_vp],
     "ibh_scalar_transport": [c_vp, c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp],

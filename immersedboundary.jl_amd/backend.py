@@ -602,6 +602,20 @@ def residual_advection(part, u, C_, out=None, flags=0):
     return ud
 
 
+def residual_advection_repeat(part, u, C_, out, n, flags=0):
+    """``n`` sweeps of ``residual_advection`` launched back to back by one C call (``ibh_residual_advection_n``): the step
+    loop as a compiled host runs it.  ``out`` is written ``n`` times."""
+    part = _part(part)
+    u, nv, _ = _field(u, part.nc)
+    C_, nvc, ldc = _field(C_, part.nc)
+    ud, nvo, _ = _field_inplace(out, part.nc, "out")
+    if nv != 1 or nvc != part.nd or nvo != 1:
+        raise ValueError("u (nc,), C (nc, nd), out (nc,)")
+    _stream()
+    call("ibh_residual_advection_n", part.handle, _ptr(u), _ptr(C_), ldc, _ptr(ud), flags, int(n))
+    return ud
+
+
 # ---------------------------------------------------------------------------
 # an explicit solver step, device resident (test/advection.jl:30-89)
 # ---------------------------------------------------------------------------

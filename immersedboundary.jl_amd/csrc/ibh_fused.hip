@@ -1380,6 +1380,17 @@ int ibh_set_tuning(const char* key, int value) {
     return 0;
 }
 
+int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t ldc, float* ud, int flags);
+// n sweeps launched back to back from ONE call: the step loop of a compiled host (a Julia `for` around the ccall costs tens
+// of nanoseconds per iteration; from Python the interpreter and ctypes would be ten times the 6 us sweep)
+int ibh_residual_advection_n(ibh_part* p, const float* u, const float* C, int64_t ldc, float* ud, int flags, int n) {
+    for (int i = 0; i < n; ++i) {
+        const int rc = ibh_residual_advection(p, u, C, ldc, ud, flags);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int ibh_residual_advection(ibh_part* p, const float* u, const float* C, int64_t ldc, float* ud, int flags) {
     IBH_REQUIRE(p && u && C && ud, "ibh_residual_advection: null argument");
     if (p->nc == 0) return 0;

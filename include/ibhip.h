@@ -258,6 +258,8 @@ int ibh_copy_rows(const int32_t* dst_rows, const int32_t* src_rows, int32_t n,
 #define IBH_NO_QUAD 1024      /* A/B: per-block single kernel where the quad sweep (2x2 block groups per wavefront) would run */
 #define IBH_EXACT 16      /* block fast path with the literal IEEE arithmetic (bit-comparable with the face-list path) */
 int ibh_residual_advection(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags);
+/* n such sweeps launched back to back by one call (the step loop of a compiled host) */
+int ibh_residual_advection_n(ibh_part*, const float* u, const float* C, int64_t ldc, float* ud, int flags, int n);
 int ibh_residual_euler_hll(ibh_part*, const float* P, int64_t ldp, float* R, int64_t ldr,
                            const ibh_fluid* fluid, int flags);
 
