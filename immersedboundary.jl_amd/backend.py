@@ -649,6 +649,12 @@ class BCSet:
         self.n_ghost, self.n_levels = int(ng.value), int(nl.value) & 0xffff
         self.n_direct_levels = int(nl.value) >> 16      # levels blended straight into the field (one launch each)
 
+    def healthy(self):
+        """False if a barrier of the one-launch form ever gave up (its bound is far beyond anything a healthy launch needs)."""
+        ng, nl = C.c_int32(0), C.c_int32(0)
+        call("ibh_bcset_info", self.handle, C.byref(ng), C.byref(nl))
+        return ng.value >= 0
+
     def apply(self, u):
         """The boundary conditions on the device field ``u`` (in place)."""
         from .hiparray import HipArray

@@ -184,6 +184,7 @@ struct ibh_bcset {
     int32_t ng = 0;                 // ghost cells of all boundaries, ordered by level
     int32_t seg[IBH_MAX_BC + 1] = {0};  // ghost ranges of the levels
     bool direct[IBH_MAX_BC] = {false};  // no ghost cell of the level is a donor of the level: blended straight into the field
+    unsigned int* sync = nullptr;       // [4] one-launch form: barrier counter, finished workgroups, status, spare
     int32_t *ghost = nullptr, *off = nullptr, *donor = nullptr, *bidx = nullptr;
     float *eta = nullptr, *w = nullptr, *gval = nullptr, *value = nullptr;
     int32_t* mode = nullptr;

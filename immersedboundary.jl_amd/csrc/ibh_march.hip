@@ -9,6 +9,7 @@
 // The step itself (sweep + u += dt ud in one launch) is ibh_step_advection in ibh_fused.hip.
 // Arithmetic: the operator kernels' (ibh_ops.hip): -ffp-contract=off, the reference's evaluation order.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "ibh_common.h"
@@ -49,6 +50,71 @@ __global__ void k_bcset_interp(int32_t g0, int32_t g1, const float* __restrict__
 __global__ void k_bcset_scatter(int32_t g0, int32_t g1, const int32_t* __restrict__ ghost, const float* __restrict__ gval,
                                 float* __restrict__ a) {
     for (int32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += gridDim.x * blockDim.x) a[ghost[g]] = gval[g];
+}
+
+// ---- every level of the set in ONE launch: at most 256 workgroups, all resident at once (a launch starts when the stream's
+// previous kernel has ended), so a grid-wide barrier on a counter cannot dead-lock; it is bounded all the same -- a wave that
+// gives up sets sync[2] and goes on (ibh_bcset_info reports it).  The last workgroup to leave resets the counters.
+struct BcsetSeg {
+    int32_t seg[IBH_MAX_BC + 1];
+    int32_t direct[IBH_MAX_BC];
+};
+__device__ __forceinline__ void bcset_grid_barrier(unsigned int* sync, unsigned int target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                   // this workgroup's stores before its arrival
+        atomicAdd(&sync[0], 1u);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) {
+                atomicOr(&sync[2], 1u);
+                break;
+            }
+        }
+        __threadfence();                                   // the others' stores after the barrier
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(MARCH_BLOCK) void k_bcset_all(int nlev, BcsetSeg S, const float* __restrict__ eta,
+                                                           const int32_t* __restrict__ off, const int32_t* __restrict__ donor,
+                                                           const float* __restrict__ w, const int32_t* __restrict__ bidx,
+                                                           const int32_t* __restrict__ mode, const float* __restrict__ value,
+                                                           const int32_t* __restrict__ ghost, float* a, float* gval,
+                                                           unsigned int* sync) {
+    unsigned int nbar = 0;
+    for (int lv = 0; lv < nlev; ++lv) {
+        const int32_t g0 = S.seg[lv], g1 = S.seg[lv + 1];
+        for (int32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += gridDim.x * blockDim.x) {
+            const int32_t b = off[g], e = off[g + 1];
+            float s = 0.0f;
+            for (int32_t k = b; k < e; ++k) {   // (plain loads: `a` changes between the levels of this launch)
+                const float t = a[donor[k]] * w[k];
+                s = (k == b) ? t : s + t;
+            }
+            const int32_t kb = bidx[g];
+            const float et = eta[g];
+            const float bv = mode[kb] ? s : value[kb];
+            const float v = et * s + (1.0f - et) * bv;
+            if (S.direct[lv]) a[ghost[g]] = v;
+            else gval[g] = v;
+        }
+        if (!S.direct[lv]) {
+            bcset_grid_barrier(sync, ++nbar * gridDim.x);
+            for (int32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += gridDim.x * blockDim.x)
+                a[ghost[g]] = gval[g];
+        }
+        if (lv + 1 < nlev) bcset_grid_barrier(sync, ++nbar * gridDim.x);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&sync[1], 1u) == gridDim.x - 1) {    // last one out: counters back to zero for the next launch
+            __threadfence();
+            sync[0] = 0u;
+            sync[1] = 0u;
+        }
+    }
 }
 
 // out = u + dt * r with dt in device memory (the update of advection.jl:87 for partitions without the fused step kernel)
@@ -136,6 +202,8 @@ int ibh_bcset_create(ibh_bcset** out, int nbc, const ibh_bc* const* bcs, const i
     if ((rc = ibh_upload(&s->mode, mode.data(), mode.size()))) return rc;
     if ((rc = ibh_upload(&s->value, value.data(), value.size()))) return rc;
     IBH_HIP(hipMalloc((void**)&s->gval, sizeof(float) * std::max<size_t>(ghost.size(), 1)));
+    IBH_HIP(hipMalloc((void**)&s->sync, 4 * sizeof(unsigned int)));
+    IBH_HIP(hipMemset(s->sync, 0, 4 * sizeof(unsigned int)));
     *out = s;
     return 0;
 }
@@ -143,7 +211,7 @@ int ibh_bcset_create(ibh_bcset** out, int nbc, const ibh_bc* const* bcs, const i
 int ibh_bcset_destroy(ibh_bcset* s) {
     if (!s) return 0;
     hipFree(s->ghost); hipFree(s->eta); hipFree(s->off); hipFree(s->donor); hipFree(s->w); hipFree(s->bidx);
-    hipFree(s->mode); hipFree(s->value); hipFree(s->gval);
+    hipFree(s->mode); hipFree(s->value); hipFree(s->gval); hipFree(s->sync);
     delete s;
     return 0;
 }
@@ -156,11 +224,34 @@ int ibh_bcset_info(const ibh_bcset* s, int32_t* n_ghost, int32_t* n_levels) {
         for (int lv = 0; lv < s->nlev; ++lv) nd += s->direct[lv];
         *n_levels = s->nlev | (nd << 16);  // low half: levels; high half: how many of them are blended in one launch
     }
+    if (n_ghost && s->sync) {   // a barrier of the one-launch form gave up (never seen): report it as a negative ghost count
+        unsigned int st[4] = {0, 0, 0, 0};
+        IBH_HIP(hipMemcpy(st, s->sync, sizeof(st), hipMemcpyDeviceToHost));
+        if (st[2]) *n_ghost = -s->ng;
+    }
     return 0;
 }
 
+// 0 (default): interpolate / scatter launches per level; 1: all levels in one launch with an in-kernel barrier -- measured
+// SLOWER (march step 34.5 against 16.8 us with 182 workgroups: the arrivals at one counter serialise at ~100 ns each across
+// the XCDs, a grid barrier costs several launches' worth), kept as an opt-in for the record
+static int ibh_bcset_one_launch = getenv("IBH_BCSET_ONE_LAUNCH") ? atoi(getenv("IBH_BCSET_ONE_LAUNCH")) : 0;
+
 int ibh_bcset_apply(const ibh_bcset* s, float* a) {
     IBH_REQUIRE(s && a, "ibh_bcset_apply: null argument");
+    if (s->ng == 0) return 0;
+    if (ibh_bcset_one_launch) {
+        BcsetSeg S;
+        int32_t widest = 0;
+        for (int lv = 0; lv <= IBH_MAX_BC; ++lv) S.seg[lv] = lv <= s->nlev ? s->seg[lv] : s->seg[s->nlev];
+        for (int lv = 0; lv < IBH_MAX_BC; ++lv) S.direct[lv] = lv < s->nlev && s->direct[lv];
+        for (int lv = 0; lv < s->nlev; ++lv) widest = std::max(widest, s->seg[lv + 1] - s->seg[lv]);
+        const int nwg = std::max(1, std::min(ibh_grid(widest, MARCH_BLOCK), 256));   // all resident at once
+        hipLaunchKernelGGL(k_bcset_all, dim3(nwg), dim3(MARCH_BLOCK), 0, ibh_stream, s->nlev, S, s->eta, s->off, s->donor,
+                           s->w, s->bidx, s->mode, s->value, s->ghost, a, s->gval, s->sync);
+        IBH_LAUNCH_CHECK();
+        return 0;
+    }
     for (int lv = 0; lv < s->nlev; ++lv) {
         const int32_t g0 = s->seg[lv], g1 = s->seg[lv + 1];
         if (g1 == g0) continue;

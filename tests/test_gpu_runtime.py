@@ -334,6 +334,7 @@ def test_advection_march_through_the_fused_step(adv_mesh):
     ibamd.impose_bc(lambda b, ui: 0.0, dp, "lower", a2)
     ibamd.impose_bc(lambda b, ui: ui.clone(), dp, "outlet", a2)
     assert torch.equal(a1, a2)
+    assert bcs.healthy()
     # the march
     uo = u0.copy()
     ua, ub = ibamd.hip(u0), torch.empty(n, dtype=torch.float32, device="cuda")
@@ -358,3 +359,4 @@ def test_advection_march_through_the_fused_step(adv_mesh):
     bcs.apply(w)
     f = ibamd.step_advection(dpart, ibamd.hip(u0), C, dt, bcs)
     assert rel_inf(ibamd.to_host(f), ibamd.to_host(w)) <= 1e-6
+    assert bcs.healthy() and bcs.n_levels >= 1
