@@ -199,7 +199,9 @@ int ibh_acc_create(ibh_acc** out, int32_t n_output, int32_t n_input,
 int ibh_acc_destroy(ibh_acc*);
 int ibh_accumulate(const ibh_acc*, const float* v, int nv, int64_t ldv, float* out, int64_t ldo);
 /* out .+= acc(v .- v2) in one launch (the prolongation step of FAS!, solver.jl:76: Q .+= prolong(Qc .- Qcold)); same
- * arithmetic as the three separate operations */
+ * arithmetic as the three separate operations.  For 2..8 fields on a many-rows-per-donor operator (a prolongation) the donors'
+ * differences are first packed side by side into a scratch buffer the accumulator allocates on its first such call (so: not
+ * inside a stream capture the first time, and not from two host threads at once on the same accumulator). */
 int ibh_accumulate_diff_add(const ibh_acc*, const float* v, const float* v2, int nv, int64_t ldv, float* out, int64_t ldo);
 
 /* ---- ghost-cell BC: impose_bc! (ImmersedBoundary.jl:1197-1247) ----------------
