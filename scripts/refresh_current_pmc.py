@@ -31,7 +31,21 @@ E = [entry("headline", "rae2822_0.87M", "k_sweep_quad", "k_sweep_quad<"),
      entry("3.47M", "rae2822_3.47M", "k_sweep_quad", "k_sweep_quad<"),
      entry("3d_4.6M", "sphere3d_4.6M", "k_sweep3_cols", "k_sweep3_cols"),
      entry("3d_euler_4.6M", "sphere3d_4.6M", "k_sweep3_euler_cols", "k_sweep3_euler_cols")]
+# large lines: traffic passes only (no SQ groups, no kernel trace)
+for tag, workload, kernel, match in (("28M", "rae2822_28M", "k_sweep_quad", "k_sweep_quad<"),
+                                     ("3d_33M", "sphere3d_33M", "k_sweep3_cols", "k_sweep3_cols"),
+                                     ("3d_euler_33M", "sphere3d_33M", "k_sweep3_euler_cols", "k_sweep3_euler_cols")):
+    f = P + "pmc_summary_%s.json" % tag
+    if os.path.exists(f):
+        d = json.load(open(f))
+        k = [x for x in d if x.startswith(match)][0]
+        E.append({"workload": workload, "kernel": kernel, "fetch_kb": d[k]["FETCH_SIZE"], "write_kb": d[k]["WRITE_SIZE"],
+                  "source": "%spmc_summary_%s.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, per-launch "
+                            "averages, KB; FETCH_SIZE x2 on gfx950)" % (P, tag)})
 for e in E:
+    if "kernel_trace_avg_us" not in e:
+        print(e["workload"], e["kernel"], round((2 * e["fetch_kb"] + e["write_kb"]) / 1024, 1), "MB")
+        continue
     print(e["workload"], e["kernel"], e["kernel_trace_avg_us"], "us", round((2 * e["fetch_kb"] + e["write_kb"]) / 1024, 1), "MB",
           e["valu_insts_per_wave"], e["valu_busy_frac"], e["wave_wait_frac"])
 json.dump({"entries": E}, open(os.path.join(ROOT, "profiles", "current_pmc.json"), "w"), indent=1)
