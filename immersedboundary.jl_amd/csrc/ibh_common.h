@@ -153,7 +153,7 @@ struct ibh_part {
     int64_t info[24] = {0};
     // workspace for per-cell gradients + sensor (pass A output)
     float* G = nullptr;
-    float* march_tmp = nullptr;  // two words of ibh_timestep_advection's reduction (maximum, finished workgroups)
+    float* march_tmp = nullptr;  // workgroup maxima of ibh_timestep_advection's reduction
     size_t march_tmp_n = 0;
     size_t G_bytes = 0;
 };

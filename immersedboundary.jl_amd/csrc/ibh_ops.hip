@@ -147,13 +147,13 @@ __global__ void k_cell_gradient_all(int32_t nc, GradDims G, const float* __restr
 
 // dt of an explicit advection step (test/advection.jl:52-59, :65): max over cells and dimensions of
 // unsigned_green_gauss(at_faces(C_d, d), d) -- the same expressions as k_at_faces + k_green_gauss(unsigned), a face value
-// evaluated by both of its cells instead of being written and read back -- reduced in ONE launch: wave and workgroup
-// maxima, one atomicMax per workgroup (non-negative floats order like their bit patterns), and the last workgroup to
-// finish writes dt = (0.5 / max) * scale and resets the two words for the next call.
+// evaluated by both of its cells instead of being written and read back.  Two launches and NO atomics: workgroup maxima into
+// an array, then one workgroup reduces them and writes dt = (0.5 / max) * scale.  (A single launch whose workgroups meet at
+// one counter -- atomicMax + last-workgroup-out -- took 39 us for 1 024 workgroups: arrivals at one address serialise at
+// ~35 ns each across the XCDs; this form takes ~8.)
 template <int ND>
 __global__ __launch_bounds__(OPS_BLOCK) void k_timestep_advection(int32_t nc, GradDims G, const float* __restrict__ C,
-                                                                  int64_t ldc, float scale, unsigned int* __restrict__ words,
-                                                                  float* __restrict__ dt) {
+                                                                  int64_t ldc, float* __restrict__ partial) {
     float m = 0.0f;
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         int32_t sd[2 * ND];
@@ -176,21 +176,26 @@ __global__ __launch_bounds__(OPS_BLOCK) void k_timestep_advection(int32_t nc, Gr
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     __shared__ float wm[OPS_BLOCK / 64];
-    __shared__ bool last;
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         float b = wm[0];
         for (int w = 1; w < OPS_BLOCK / 64; ++w) b = fmaxf(b, wm[w]);
-        atomicMax(&words[0], __float_as_uint(b));
-        __threadfence();
-        last = atomicAdd(&words[1], 1u) == gridDim.x - 1;
-        if (last) {
-            __threadfence();
-            const unsigned int w = atomicExch(&words[0], 0u);
-            words[1] = 0u;
-            *dt = (0.5f / __uint_as_float(w)) * scale;  // advection.jl:53 and :65
-        }
+        partial[blockIdx.x] = b;
+    }
+}
+__global__ __launch_bounds__(OPS_BLOCK) void k_dt_from_partials(int n, const float* __restrict__ partial, float scale,
+                                                                float* __restrict__ dt) {
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += OPS_BLOCK) m = fmaxf(m, partial[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[OPS_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = wm[0];
+        for (int w = 1; w < OPS_BLOCK / 64; ++w) b = fmaxf(b, wm[w]);
+        *dt = (0.5f / b) * scale;  // advection.jl:53 and :65
     }
 }
 
@@ -531,6 +536,27 @@ __global__ void k_axpy(int64_t n, float a, const float* __restrict__ x, float* _
         y[i] = a * x[i] + y[i];
 }
 
+// final step of the two-stage reductions below: one workgroup adds the workgroup sums (in index order: a fixed order for a
+// fixed grid) -- no atomics: 1 024 - 2 048 arrivals at ONE address cost 20 - 40 us on this part (they serialise across the XCDs)
+__global__ __launch_bounds__(OPS_BLOCK) void k_sum_partials(int n, const double* __restrict__ part, double* __restrict__ out) {
+    __shared__ double sh[OPS_BLOCK];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += OPS_BLOCK) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = OPS_BLOCK / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+// scratch of the two-stage reductions (per host thread: one stream of reductions at a time)
+static double* red_scratch() {
+    static thread_local double* buf = nullptr;
+    if (!buf && hipMalloc((void**)&buf, 4096 * sizeof(double)) != hipSuccess) buf = nullptr;
+    return buf;
+}
+
 __global__ void k_sumsq(int64_t n, const float* __restrict__ x, double* __restrict__ out) {
     double s = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -545,7 +571,7 @@ __global__ void k_sumsq(int64_t n, const float* __restrict__ x, double* __restri
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < OPS_BLOCK / 64; ++i) t += part[i];
-        atomicAdd(out, t);
+        out[blockIdx.x] = t;    // (workgroup sums: k_sum_partials adds them)
     }
 }
 
@@ -567,7 +593,7 @@ __global__ void k_axpy_clamped_sumsq(int64_t n, float omega, const float* __rest
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < OPS_BLOCK / 64; ++i) t += part[i];
-        atomicAdd(out, t);
+        out[blockIdx.x] = t;    // (workgroup sums: k_sum_partials adds them)
     }
 }
 
@@ -707,24 +733,17 @@ int ibh_wray_agarwal_of_cells(const ibh_part* p, const float* R, const float* S,
 
 int ibh_timestep_advection(ibh_part* p, const float* C, int64_t ldc, float scale, float* dt_dev) {
     IBH_REQUIRE(p && C && dt_dev && (p->nd == 2 || p->nd == 3) && p->nc > 0, "ibh_timestep_advection: bad argument");
-    if (!p->march_tmp) {  // two words: running maximum, finished workgroups (both left at zero by every call)
-        IBH_HIP(hipMalloc((void**)&p->march_tmp, 2 * sizeof(unsigned int)));
-        IBH_HIP(hipMemset(p->march_tmp, 0, 2 * sizeof(unsigned int)));
-        p->march_tmp_n = 2;
+    if (!p->march_tmp) {  // workgroup maxima
+        IBH_HIP(hipMalloc((void**)&p->march_tmp, 1024 * sizeof(float)));
+        p->march_tmp_n = 1024;
     }
-    GradDims G;
-    for (int d = 0; d < p->nd; ++d) {
-        G.d[d] = p->dim[d];
-        G.h[d] = p->spacing + (int64_t)d * p->nc;
-    }
-    G.side = p->side;
+    const GradDims G = grad_dims(p);
     const int nwg = std::min(ibh_grid(p->nc, OPS_BLOCK), 1024);
     if (p->nd == 2)
-        hipLaunchKernelGGL(k_timestep_advection<2>, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, C, ldc, scale,
-                           (unsigned int*)p->march_tmp, dt_dev);
+        hipLaunchKernelGGL(k_timestep_advection<2>, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, C, ldc, p->march_tmp);
     else
-        hipLaunchKernelGGL(k_timestep_advection<3>, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, C, ldc, scale,
-                           (unsigned int*)p->march_tmp, dt_dev);
+        hipLaunchKernelGGL(k_timestep_advection<3>, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, C, ldc, p->march_tmp);
+    hipLaunchKernelGGL(k_dt_from_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg, p->march_tmp, scale, dt_dev);
     IBH_LAUNCH_CHECK();
     return 0;
 }
@@ -882,10 +901,15 @@ int ibh_axpy_clamped(int64_t n, float omega, const float* r, float* q) {
 }
 int ibh_axpy_clamped_sumsq(int64_t n, float omega, const float* r, float* q, double* out) {
     IBH_REQUIRE(out, "ibh_axpy_clamped_sumsq: null argument");
-    IBH_HIP(hipMemsetAsync(out, 0, sizeof(double), ibh_stream));
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_axpy_clamped_sumsq, dim3(ibh_grid(n, OPS_BLOCK) > 2048 ? 2048 : ibh_grid(n, OPS_BLOCK)),
-                       dim3(OPS_BLOCK), 0, ibh_stream, n, omega, r, q, out);
+    double* part = red_scratch();
+    IBH_REQUIRE(part, "ibh_axpy_clamped_sumsq: no scratch");
+    if (n <= 0) {
+        IBH_HIP(hipMemsetAsync(out, 0, sizeof(double), ibh_stream));
+        return 0;
+    }
+    const int nwg = ibh_grid(n, OPS_BLOCK) > 2048 ? 2048 : ibh_grid(n, OPS_BLOCK);
+    hipLaunchKernelGGL(k_axpy_clamped_sumsq, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, n, omega, r, q, part);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg, part, out);
     IBH_LAUNCH_CHECK();
     return 0;
 }
@@ -897,10 +921,15 @@ int ibh_axpy(int64_t n, float a, const float* x, float* y) {
     return 0;
 }
 int ibh_sumsq(int64_t n, const float* x, double* out) {
-    IBH_HIP(hipMemsetAsync(out, 0, sizeof(double), ibh_stream));
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_sumsq, dim3(ibh_grid(n, OPS_BLOCK) > 1024 ? 1024 : ibh_grid(n, OPS_BLOCK)), dim3(OPS_BLOCK), 0,
-                       ibh_stream, n, x, out);
+    double* part = red_scratch();
+    IBH_REQUIRE(out && part, "ibh_sumsq: null argument or no scratch");
+    if (n <= 0) {
+        IBH_HIP(hipMemsetAsync(out, 0, sizeof(double), ibh_stream));
+        return 0;
+    }
+    const int nwg = ibh_grid(n, OPS_BLOCK) > 1024 ? 1024 : ibh_grid(n, OPS_BLOCK);
+    hipLaunchKernelGGL(k_sumsq, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, n, x, part + 2048);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg, part + 2048, out);
     IBH_LAUNCH_CHECK();
     return 0;
 }
