@@ -107,16 +107,22 @@ __device__ __forceinline__ float block_reduce(float v, float* sm) {
     }
     return v;
 }
-// one launch: every block reduces its stride of the array, the last block to finish combines the partials
+// every block reduces its stride of the array; with ONE block the result is written at once, with more (`two_stage`) only
+// the partials are -- a second one-block launch over them finishes (many blocks meeting at one counter serialise: ~20 ns
+// per arrival across the XCDs, 20 us for 1 024 blocks; a launch costs a tenth of that)
 template <int OP>
 __global__ __launch_bounds__(256) void k_ew_reduce(int64_t total, const float* __restrict__ a, float* part,
-                                                   unsigned int* counter, float* out) {
+                                                   unsigned int* counter, float* out, int two_stage) {
     __shared__ float sm[4];
     __shared__ bool last;
     float v = red_identity<OP>();
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
         v = red2<OP>(v, a[t]);
     v = block_reduce<OP>(v, sm);
+    if (two_stage) {
+        if (threadIdx.x == 0) part[blockIdx.x] = v;
+        return;
+    }
     if (threadIdx.x == 0) {
         part[blockIdx.x] = v;
         __threadfence();
@@ -144,7 +150,7 @@ thread_local RedScratch red_scratch;
 
 int ensure_scratch() {
     if (red_scratch.part) return 0;
-    IBH_HIP(hipMalloc((void**)&red_scratch.part, 1024 * sizeof(float)));
+    IBH_HIP(hipMalloc((void**)&red_scratch.part, 1032 * sizeof(float)));
     IBH_HIP(hipMalloc((void**)&red_scratch.counter, sizeof(unsigned int)));
     IBH_HIP(hipMemset(red_scratch.counter, 0, sizeof(unsigned int)));
     return 0;
@@ -246,12 +252,19 @@ int ibh_ew_reduce(int op, int64_t total, const float* a, float* out_device) {
     const dim3 grid(std::min(1024, ibh_grid(total, 256 * 8))), blk(256);
     float* part = red_scratch.part;
     unsigned int* cnt = red_scratch.counter;
+    const int two = grid.x > 8;
+    const int64_t nparts = (int64_t)grid.x;
+    // (the second stage reads the first `nparts` partials and writes its own one partial behind them)
+#define EW_REDUCE(OP)                                                                                                  \
+    hipLaunchKernelGGL(k_ew_reduce<OP>, grid, blk, 0, ibh_stream, total, a, part, cnt, out_device, two);               \
+    if (two) hipLaunchKernelGGL(k_ew_reduce<OP>, dim3(1), blk, 0, ibh_stream, nparts, (const float*)part, part + 1024, cnt, out_device, 0)
     switch (op) {
-        case IBH_EW_SUM: hipLaunchKernelGGL(k_ew_reduce<IBH_EW_SUM>, grid, blk, 0, ibh_stream, total, a, part, cnt, out_device); break;
-        case IBH_EW_MAX: hipLaunchKernelGGL(k_ew_reduce<IBH_EW_MAX>, grid, blk, 0, ibh_stream, total, a, part, cnt, out_device); break;
-        case IBH_EW_MIN: hipLaunchKernelGGL(k_ew_reduce<IBH_EW_MIN>, grid, blk, 0, ibh_stream, total, a, part, cnt, out_device); break;
+        case IBH_EW_SUM: EW_REDUCE(IBH_EW_SUM); break;
+        case IBH_EW_MAX: EW_REDUCE(IBH_EW_MAX); break;
+        case IBH_EW_MIN: EW_REDUCE(IBH_EW_MIN); break;
         default: return ibh_fail(-1, "ibh_ew_reduce: unknown operation", __FILE__, __LINE__);
     }
+#undef EW_REDUCE
     IBH_LAUNCH_CHECK();
     return 0;
 }
