@@ -985,25 +985,62 @@ __global__ __launch_bounds__(64 * WPB3C) __attribute__((amdgpu_waves_per_eu(WAVE
                           TAB ? dtab : nullptr);
 }
 
-// Column form of the 3-D Euler sweep (strip3e::sweep_euler_cols): one wavefront per block.  (A persistent form -- a
-// chain of blocks per wave, the first loads of the next block in flight during the z fluxes of the one in hand -- was
-// measured slower: 143 against 107 us at 4.56 M cells; the 26 registers of the prefetch and the second descriptor spill.)
+// Column form of the 3-D Euler sweep (strip3e::sweep_block): one wavefront per 8^3 block.
+// Round 4: PERSISTENT waves -- the grid is the 2 048 wave slots of the chip at two waves per SIMD (8 per CU), and each wave
+// works through a chain of blocks with the first loads of its next block in flight during the z fluxes of the one in hand
+// (strip3e::sweep_euler_chain).  Every XCD gets one contiguous chunk of the block list (depth-first order: a compact patch
+// of the mesh), and the waves of an XCD walk their chunk side by side (wave i: blocks c0 + i, c0 + i + W, ...), so the
+// blocks in flight on an XCD at any time are W consecutive ones.
+// PERSIST = false: one block per wave (grid = blocks), the A/B reference ("quad_variant" 513).
+// (Round 3 measured a persistent form slower, 143 against 107 us at 4.56 M cells: at 256 VGPRs the registers of the
+// prefetch spilled.  Round 4 first freed the registers -- nothing of a later pass is held through a flux loop, lane-only
+// integers and the block descriptor are derived / read again per pass: 190 VGPRs -- and tried them as a third wave per
+// SIMD: 168 VGPRs with 17 spilled words, 11 waves per CU resident (wave timeline), and slower: 755 against 695 us at 33.6 M
+// cells on the same box.  As prefetch registers they pay: see profiles/r4_*/README.md.)
 #ifndef WPB3E
-#define WPB3E 2
+#define WPB3E 1
 #endif
-template <int WAVES, bool STAMP = false, bool TAB = false>
+#define S3E_SLOTS_PER_CU 8
+template <int WAVES, bool STAMP = false, bool TAB = false, bool PERSIST = true>
 __global__ __launch_bounds__(64 * WPB3E) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_sweep3_euler_cols(
     const float* __restrict__ P, uint32_t ldp, float* __restrict__ R, uint32_t ldr, float Rgas, float gamma,
     const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab, const int32_t* __restrict__ ftab,
     const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg,
     const int32_t* __restrict__ dtab = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[WPB3E * S3E_LDS];
+    __shared__ __attribute__((aligned(16))) float nextbuf[WPB3E * S3E_NEXT];  // (an array of its own: the LDS-DMA rows)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3E + wave);
-    if (blk >= n) return;
-    strip3e::sweep_euler_cols<STAMP>(blocks, htab, ftab, rtab, r4tab, blk, P, ldp, R, ldr, blk3::Gas3{Rgas, gamma},
-                                     lds + wave * S3E_LDS, lane,
-                                     STAMP && ibh_dbg_buf ? ibh_dbg_buf + (size_t)blk * 8 : nullptr, TAB ? dtab : nullptr);
+    int32_t first, stride, end;
+    if constexpr (PERSIST) {
+        // nwg = workgroups of the launch, a multiple of 8; workgroup w belongs to XCD w & 7 (placement affects speed only)
+        const int32_t xcd = blockIdx.x & 7, idx = (blockIdx.x >> 3) * WPB3E + wave;
+        const int32_t q = n >> 3, r = n & 7;
+        const int32_t c0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        first = __builtin_amdgcn_readfirstlane(c0 + idx);
+        stride = (nwg >> 3) * WPB3E;
+        end = c0 + q + (xcd < r ? 1 : 0);
+    } else {
+        first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * WPB3E + wave);
+        stride = n;
+        end = n;
+    }
+    strip3e::sweep_euler_chain<STAMP>(blocks, htab, ftab, rtab, r4tab, first, stride, end, P, ldp, R, ldr,
+                                      blk3::Gas3{Rgas, gamma}, lds + wave * S3E_LDS, nextbuf + wave * S3E_NEXT, lane,
+                                      STAMP ? ibh_dbg_buf : nullptr,
+                                      TAB ? dtab : nullptr);
+}
+// workgroups of the persistent launch: the chip's wave slots (or fewer, for few blocks), a multiple of 8
+static int32_t s3e_persistent_wgs(int32_t nblk) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int32_t slots = cus * S3E_SLOTS_PER_CU / WPB3E;
+    const int32_t want = ((nblk + WPB3E - 1) / WPB3E + 7) & ~7;
+    return want < slots ? want : slots;
 }
 
 // wave-per-block form of the 3-D scalar pass A (blk3::passA_wave): 4 blocks per 256-thread workgroup
@@ -1310,7 +1347,8 @@ const int ibh_quad = getenv("IBH_QUAD") ? atoi(getenv("IBH_QUAD")) : 1;
 int ibh_rows = getenv("IBH_ROWS") ? atoi(getenv("IBH_ROWS")) : 0;
 // ibh_set_tuning(key, v): "quad_variant" 4 = wave time stamps (scripts/wave_timeline.py); "quad_parts" 1 / 2 = only the
 // quads / only the single blocks of a quad sweep (measurement); "quad_singles_first" = grid order
-int ibh_quad_variant = 0, ibh_quad_parts = 3, ibh_quad_singles_iters = 1;
+int ibh_quad_variant = getenv("IBH_QUAD_VARIANT") ? atoi(getenv("IBH_QUAD_VARIANT")) : 0;  // (profiling a variant under bench.py)
+int ibh_quad_parts = 3, ibh_quad_singles_iters = 1;
 int ibh_quad_singles_first = getenv("IBH_SINGLES_FIRST") ? atoi(getenv("IBH_SINGLES_FIRST")) : 0;
 int ibh_pairs = getenv("IBH_PAIRS") ? atoi(getenv("IBH_PAIRS")) : 1;  // pair tiles for the blocks outside quads ("pairs")
 int ibh_arith_ids = getenv("IBH_ARITH_IDS") ? atoi(getenv("IBH_ARITH_IDS")) : 1;  // quad sweep: halo ids from the companion rows
@@ -1866,7 +1904,7 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
                    IBH_PHASE_BOUNDARY))) {
         // image blocks of a partition with skirt fragments: one launch, nothing through the workspace
         const int32_t nwg = (p->n_img3 + WPB3E - 1) / WPB3E;
-        hipLaunchKernelGGL((k_sweep3_euler_cols<2, false, true>), dim3(nwg), dim3(64 * WPB3E), 0, ibh_stream, P,
+        hipLaunchKernelGGL((k_sweep3_euler_cols<2, false, true, false>), dim3(nwg), dim3(64 * WPB3E), 0, ibh_stream, P,
                            (uint32_t)ldp, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->iblocks3, p->ihtab3, p->iftab3,
                            p->irtab3, p->ir4tab3, p->n_img3, nwg, p->idtab3);
         IBH_LAUNCH_CHECK();
@@ -1877,14 +1915,15 @@ int ibh_residual_euler_hll(ibh_part* p, const float* P, int64_t ldp, float* R, i
                    IBH_PHASE_INTERIOR | IBH_PHASE_BOUNDARY))) {
         // 3-D, every block qualifies for the single-kernel sweep: one launch, nothing through the workspace
         if (ibh_quad_variant != 512) {
-            const int32_t nwg = (p->nblk + WPB3E - 1) / WPB3E;
-#define S3E_LAUNCH(W, ST)                                                                                            \
-    hipLaunchKernelGGL((k_sweep3_euler_cols<W, ST>), dim3(nwg), dim3(64 * WPB3E), 0, ibh_stream, P, (uint32_t)ldp, R, \
-                       (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks3, p->htab3, p->ftab3, p->rtab3, p->r4tab3,    \
-                       p->nblk, nwg)
-            if (ibh_quad_variant == 513) S3E_LAUNCH(3, false);
-            else if (ibh_quad_variant == 4) S3E_LAUNCH(2, true);  // wave time stamps (scripts/wave_timeline_3d.py)
-            else S3E_LAUNCH(2, false);
+            const bool persist = ibh_quad_variant == 514;  // A/B: persistent waves (measured slower, see above)
+            const int32_t nwg = persist ? s3e_persistent_wgs(p->nblk) : (p->nblk + WPB3E - 1) / WPB3E;
+#define S3E_LAUNCH(W, ST, PE)                                                                                         \
+    hipLaunchKernelGGL((k_sweep3_euler_cols<W, ST, false, PE>), dim3(nwg), dim3(64 * WPB3E), 0, ibh_stream, P,         \
+                       (uint32_t)ldp, R, (uint32_t)ldr, fluid->R, fluid->gamma, p->blocks3, p->htab3, p->ftab3,        \
+                       p->rtab3, p->r4tab3, p->nblk, nwg)
+            if (persist) S3E_LAUNCH(2, false, true);
+            else if (ibh_quad_variant == 4) S3E_LAUNCH(2, true, false);  // wave time stamps (scripts/wave_timeline_3d.py)
+            else S3E_LAUNCH(2, false, false);
 #undef S3E_LAUNCH
         } else  // A/B: thread-per-cell form
         hipLaunchKernelGGL(k_sweep3_euler, dim3(p->nblk), dim3(512), 0, ibh_stream, P, (uint32_t)ldp, R, (uint32_t)ldr,

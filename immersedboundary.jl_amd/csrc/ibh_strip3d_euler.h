@@ -39,12 +39,14 @@ using strip3::jst_max3;
 using strip3::lane_geo;
 using strip3::LaneGeo;
 
-// LDS per wave (floats)
+// LDS per wave (floats).  The plane of side_eval lives in the transposition buffer: the two are used in different phases
+// and a wavefront's LDS operations execute in order.
 #define S3E_BUF 0                       // transposition buffer (8 x 72)
-#define S3E_PLANE 576                   // [18 x 18] pressure of the halo cells of one side + rim
+#define S3E_PLANE 0                     // [18 x 18] pressure of the halo cells of one side + rim
 #define S3E_PLANEA (S3E_PLANE + 324)    // [64] rim: mean |difference| to the halo cell next to it
-#define S3E_R (S3E_PLANEA + 64)         // [5][576] residual
-#define S3E_LDS (S3E_R + 5 * 576)       // 3 844 floats = 15.0 KB per wave
+#define S3E_R 576                       // [5][576] residual
+#define S3E_LDS (S3E_R + 5 * 576)       // 3 456 floats = 13.5 KB per wave (+ 5 KB for the first loads of the next block)
+
 
 struct Col {
     v2f e[5];
@@ -163,11 +165,28 @@ __device__ __forceinline__ void euler_state(const T* P, const Gas3& gas, T* Q, T
     a = sqrtT((gas.gamma * gas.R) * Tt);
 }
 
+// density, energy per mass, pressure, normal velocity and speed of sound of one side of a face
+template <class T, int DN>
+__device__ __forceinline__ void euler_side_pm(const T* P, const Gas3& gas, T& rho, T& e, T& p, T& un, T& a) {
+    p = P[0];
+    const T Tt = maxT(P[1], bc<T>(10.0f));
+    const T q = P[2] * P[2] + P[3] * P[3] + P[4] * P[4];
+    rho = p * rcpT(gas.R * Tt);
+    e = (gas.R / (gas.gamma - 1.0f)) * Tt + 0.5f * q;
+    un = P[2 + DN];
+    a = sqrtT((gas.gamma * gas.R) * Tt);
+}
+
 // MUSCL states from undivided slopes, then HLL (blk3::euler_flux_w3); a = owner (towards -), b = neighbour,
 // wa = h_a / (h_a + h_b)
 template <class T, int DN>
 __device__ __forceinline__ void euler_flux(const T* Pa, const T* Pb, const T* Sa, const T* Sb, T Da, T Db, T wa,
                                            const Gas3& gas, T* F) {
+#ifdef S3E_ABLATE_FLUX  // (timing diagnostic, wrong results: the flux arithmetic removed, everything else in place)
+#pragma unroll
+    for (int v = 0; v < 5; ++v) F[v] = (Pa[v] + Pb[v]) * wa + (Sa[v] - Sb[v]) * (Da + Db);
+    return;
+#endif
     T PL[5], PR[5];
     const T Df = maxT(maxT(Da, Db), bc<T>(1e-7f));
     const T wb = 1.0f - wa;
@@ -180,22 +199,26 @@ __device__ __forceinline__ void euler_flux(const T* Pa, const T* Pb, const T* Sa
         const T t16 = (Sa[v] - Sb[v]) * 0.0625f;
         const T uf = (Pa[v] + wa * d) + t16;
         PL[v] = uf + Df * ((s - wa * d) - t16);
-        PR[v] = uf + Df * ((wb * d - s) - t16);
+        // PR = uf + Df ((wb d - s) - t16) = PL + Df (d - 2 s)   (wa + wb = 1)
+        PR[v] = PL[v] + Df * (d - 2.0f * s);
     }
     // HLL: F = (SL FL - SR FR + SL SR (QR - QL)) / (SL - SR) with FL = QL unL + pressure terms regrouped by state:
-    // F = QL (aL unL - c) + QR (c - aR unR) + pressure terms, aL = SL / (SL - SR), aR = SR / (SL - SR), c = SL aR
-    T QL[5], QR[5], pL, pR, uL, aL, uR, aR;
-    euler_state<T, DN>(PL, gas, QL, pL, uL, aL);
-    euler_state<T, DN>(PR, gas, QR, pR, uR, aR);
+    // F = QL (wL unL - c) + QR (c - wR unR) + pressure terms, wL = SL / (SL - SR), wR = SR / (SL - SR), c = SL wR; with
+    // Q = rho (1, e, u, v, w) the conserved states are never formed: F = AL (1, eL, uL..) + AR (1, eR, uR..), A = rho c
+    T rL, eL, pL, uL, aL, rR, eR, pR, uR, aR;
+    euler_side_pm<T, DN>(PL, gas, rL, eL, pL, uL, aL);
+    euler_side_pm<T, DN>(PR, gas, rR, eR, pR, uR, aR);
     const T z = bc<T>(0.0f);
     const T SR = minT(uR - aR, z);
     const T SL = maxT(uL + aL, z);
     const T rs = rcpT(SL - SR);
     const T wL = SL * rs, wR = SR * rs;
     const T c = SL * wR;
-    const T cL = wL * uL - c, cR = c - wR * uR;
+    const T AL = rL * (wL * uL - c), AR = rR * (c - wR * uR);
+    F[0] = AL + AR;
+    F[1] = AL * eL + AR * eR;
 #pragma unroll
-    for (int v = 0; v < 5; ++v) F[v] = QL[v] * cL + QR[v] * cR;
+    for (int v = 2; v < 5; ++v) F[v] = AL * PL[v] + AR * PR[v];
     // (the form (QL - QR) cL + QR (cL + cR), exact in the difference of the states, was measured: the same error against
     // the Float64 combine of the reference -- 9.6e-6 of max |R| on tests/test_config5.py either way -- at five more
     // instructions per face: the error is the Float32 rounding of the fluxes themselves)
@@ -251,6 +274,9 @@ __device__ __forceinline__ Slot slot_of(const BlockDesc3& bb, const int32_t* __r
     constexpr int sd = d == 0 ? 1 : d == 1 ? 8 : 64;
     Slot s;
     s.hid = halo_cell3s<S>(bb, htab, blk, lane);
+#ifdef S3E_ABLATE_HALO  // (timing diagnostic, wrong results: every halo gather becomes a coalesced read of the block's own cells)
+    s.hid = (uint32_t)bb.base + 64u * S + (uint32_t)lane;
+#endif
     s.dd = bb.type[S] == SIDE_MIRROR ? 0 : ((S & 1) ? sd : -sd);
     s.drow = dtab ? dtab + (size_t)blk * 1536 : nullptr;
     return s;
@@ -260,6 +286,9 @@ template <int S>
 __device__ __forceinline__ uint32_t deeper_of(const BlockDesc3& bb, const Slot& sl, int lane, int k, uint32_t c) {
     if (sl.drow && bb.nb[S] < 0 && bb.type[S] != SIDE_MIRROR)  // wave-uniform
         return (uint32_t)sl.drow[(S * 64 + lane) * 4 + k];
+#ifdef S3E_ABLATE_HALO
+    return c;
+#endif
     return (uint32_t)((int)c + sl.dd);
 }
 
@@ -463,14 +492,20 @@ constexpr int rstride() {
 
 // ---- flux pass along D: the lane's column with its two halo ends; R -= (F_high - F_low) / h for its 8 cells.
 // MODE 0: first pass (R = ...), 1: R += ..., 2: last pass (R + ... goes to global memory: z-columns, coalesced dwords).
-// The halo registers of this pass were loaded by the caller; `prefetch` requests what comes next, before the flux loop.
-template <int D, int MODE, class Prefetch>
-__device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const LaneGeo& LG, const int32_t* __restrict__ ftab,
+// The halo registers of this pass were loaded by the caller -- after the flux loop of the pass before, so that nothing of
+// a later pass is held in registers while the flux loop runs (168 VGPRs = three waves per SIMD).  Order: face 4 (needs no
+// halo value: covers the halo loads), the two sides, then the packed faces.  The mean flux through a FINE side goes
+// straight into the residual of its boundary cell in LDS (the packed evaluation of that face is zeroed).
+template <int D, int MODE, class Hook>
+__device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const int32_t* __restrict__ ftab,
                                           const int32_t* __restrict__ r4tab, const float* __restrict__ P, uint32_t ldp,
-                                          float* lds, int lane, const Gas3& gas, Col* Pc, Col& Dc, const Slot* slots,
-                                          const int32_t* rids, const HaloRegs& h0, const HaloRegs& h1, Prefetch&& prefetch,
-                                          float* __restrict__ Rr, uint32_t ldr) {
+                                          float* lds, int lane, const Gas3& gas, Col* Pc, Col& Dc, const Slot& sl0,
+                                          const Slot& sl1, int32_t rid0, int32_t rid1, const HaloRegs& h0,
+                                          const HaloRegs& h1, float* __restrict__ Rr, uint32_t ldr, Hook&& hook) {
     constexpr int S0 = 2 * D, S1 = 2 * D + 1;
+    // lane-only integers (plane positions, LDS and store addresses) are derived again in every pass instead of living in
+    // registers -- or in scratch -- across the flux loops: the asm hides that `lane` is the same value as before
+    asm volatile("" : "+v"(lane));
     const float rh = bb.rh[D];
     const float qlo = bb.q[S0], qhi = bb.q[S1];
 #ifdef S3E_COUNT_SAME_ONLY
@@ -478,6 +513,46 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const LaneGeo& L
 #else
     const bool isF0 = bb.type[S0] == SIDE_FINE, isF1 = bb.type[S1] == SIDE_FINE;
 #endif
+    float* const Rl = lds + S3E_R + rbase<D>(lane & 7, lane >> 3);
+    // cell I of the column: R (op) -(Fhi - Flo) / h; `pre`: the cell already holds the flux of a FINE side (MODE 0)
+    auto put = [&](int v, int i, float dF, bool pre = false) {
+        float* r = Rl + v * 576 + rstride<D>() * i;
+        if constexpr (MODE == 0) {
+            if (pre) *r = *r - dF * rh;  // wave-uniform
+            else *r = -(dF * rh);
+        } else if constexpr (MODE == 1) *r = *r - dF * rh;
+        else Rr[(size_t)v * ldr + (uint32_t)bb.base + lane + 64 * i] = *r - dF * rh;
+    };
+    // ---- face 4 (between cells 3 and 4) first, straight into the residual of its two cells (nothing of it is held
+    // through the flux loop)
+    {
+        float Pa[5], Pbb[5], Sa[5], Sbb[5], F4[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const Col& p = Pc[v];
+            const float d4 = p.e[0].y - p.e[4].x;
+            Pa[v] = p.e[4].x;
+            Pbb[v] = p.e[0].y;
+            Sa[v] = 0.5f * d4 + 0.5f * (p.e[4].x - p.e[3].x);
+            Sbb[v] = 0.5f * (p.e[1].y - p.e[0].y) + 0.5f * d4;
+        }
+        euler_flux<float, D>(Pa, Pbb, Sa, Sbb, Dc.e[4].x, Dc.e[0].y, 0.5f, gas, F4);
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            float* r3 = Rl + v * 576 + rstride<D>() * 3;
+            float* r4 = Rl + v * 576 + rstride<D>() * 4;
+            const float f = F4[v] * rh;
+            if constexpr (MODE == 0) {
+                *r3 = -f;
+                *r4 = f;
+            } else {
+                *r3 = *r3 - f;
+                *r4 = *r4 + f;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const LaneGeo LG = lane_geo(lane);
     // mean halo value behind the boundary cells (own slopes)
     float hm0[5], hm1[5];
 #pragma unroll
@@ -502,98 +577,108 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const LaneGeo& L
         }
     }
     // ---- undivided slopes of the two boundary cells (0 and 7); halo cells: slopes along the normal, pressure sensor
-    // (FINE sides: the finished face flux)
-    float Sh0[5], Sh1[5], Dh0, Dh1;
-    float Ff0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, Ff1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    // (FINE sides: the finished face flux, added to the residual of the boundary cell here).  The mean halo values go to
+    // the two free ends of the column registers: pairs e[0] = (c[-1], c[4]) and e[4] = (c[3], c[8]) are then register
+    // aligned like the others, and nothing else of the halo is held through the flux loop.  (Behind a FINE side the mean
+    // stands in for the halo cell in the packed evaluation of that face, whose result is not used.)
+    float Sh0[5], Dh0, Dh1;
+    float* const park = lds + S3E_BUF + lane;  // slopes of the high halo cell: not needed before the last pair
     {
-        float Pb[5], Sb[5];
+        float Pb[5], Sb[5], Ff[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
             const Col& p = Pc[v];
             Pb[v] = p.e[1].x;
             Sb[v] = 0.5f * (p.e[2].x - p.e[1].x) + qlo * (p.e[1].x - hm0[v]);
         }
-        side_eval<S0>(bb, LG, ftab, r4tab, P, ldp, lds, lane, slots[S0], h0.hu, h0.hd, rids[S0], h0.rv, Pb, Sb, Dc.e[1].x,
-                      gas, Sh0, Dh0, Ff0);
+        side_eval<S0>(bb, LG, ftab, r4tab, P, ldp, lds, lane, sl0, h0.hu, h0.hd, rid0, h0.rv, Pb, Sb, Dc.e[1].x, gas, Sh0,
+                      Dh0, Ff);
+        if (isF0) {  // cell 0: R -= (F1 - Ff) / h
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                float* r = Rl + v * 576;
+                if constexpr (MODE == 0) *r = Ff[v] * rh;
+                else *r = *r + Ff[v] * rh;
+            }
+        }
+        float Sh1[5];
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
             const Col& p = Pc[v];
             Pb[v] = p.e[3].y;
             Sb[v] = qhi * (hm1[v] - p.e[3].y) + 0.5f * (p.e[3].y - p.e[2].y);
         }
-        side_eval<S1>(bb, LG, ftab, r4tab, P, ldp, lds, lane, slots[S1], h1.hu, h1.hd, rids[S1], h1.rv, Pb, Sb, Dc.e[3].y,
-                      gas, Sh1, Dh1, Ff1);
+        side_eval<S1>(bb, LG, ftab, r4tab, P, ldp, lds, lane, sl1, h1.hu, h1.hd, rid1, h1.rv, Pb, Sb, Dc.e[3].y, gas, Sh1,
+                      Dh1, Ff);
+        if (isF1) {  // cell 7: R -= (Ff - F7) / h
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                float* r = Rl + v * 576 + rstride<D>() * 7;
+                if constexpr (MODE == 0) *r = -(Ff[v] * rh);
+                else *r = *r - Ff[v] * rh;
+            }
+        }
+        wave_lds_sync();  // (the plane of the side is read by other lanes)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) park[64 * v] = Sh1[v];
     }
-    // ---- loads of what comes next (the halo registers of the next pass)
     __builtin_amdgcn_sched_barrier(0);
-    prefetch();
+    hook();  // (the halo registers are free from here on: the first loads of the wave's next block go out in the last pass)
     __builtin_amdgcn_sched_barrier(0);
-    // column ends: mean halo values for the slopes of cells 0 / 7, the halo cells themselves for the faces
+    // column ends
     Dc.e[0].x = Dh0;
     Dc.e[4].y = Dh1;
-    // slopes of cells (j - 1, j + 4) from the column with the MEAN halo values at its ends
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        Pc[v].e[0].x = hm0[v];
+        Pc[v].e[4].y = hm1[v];
+    }
+    // slopes of cells (j - 1, j + 4)
     auto slope = [&](int v, int j) -> v2f {
         const Col& p = Pc[v];
-        const v2f lo = j == 1 ? v2f{hm0[v], p.e[0].y} : p.e[j - 1];
-        const v2f hi = j == 3 ? v2f{p.e[4].x, hm1[v]} : p.e[j + 1];
         const v2f wl = j == 1 ? v2f{qlo, 0.5f} : v2f{0.5f, 0.5f}, wr = j == 3 ? v2f{0.5f, qhi} : v2f{0.5f, 0.5f};
-        return wr * (hi - p.e[j]) + wl * (p.e[j] - lo);
+        return wr * (p.e[j + 1] - p.e[j]) + wl * (p.e[j] - p.e[j - 1]);
     };
-    float* const Rl = lds + S3E_R + rbase<D>(lane & 7, lane >> 3);
-    // cell I of the column: R (op) -(Fhi - Flo) / h
-    auto put = [&](int v, int i, float dF) {
-        float* r = Rl + v * 576 + rstride<D>() * i;
-        if constexpr (MODE == 0) *r = -(dF * rh);
-        else if constexpr (MODE == 1) *r = *r - dF * rh;
-        else Rr[(size_t)v * ldr + (uint32_t)bb.base + lane + 64 * i] = *r - dF * rh;
-    };
-    // ---- face 4 (between cells 3 and 4) first: its two cells close at the first and the last pair
-    float F4[5];
     v2f Sc[5];  // slopes e[j] of the pair in hand: starts as e[0] = (Sh0, S4)
-    {
-        float Pa[5], Pbb[5], Sa[5], Sbb[5];
 #pragma unroll
-        for (int v = 0; v < 5; ++v) {
-            const Col& p = Pc[v];
-            const float d4 = p.e[0].y - p.e[4].x;
-            Pa[v] = p.e[4].x;
-            Pbb[v] = p.e[0].y;
-            Sa[v] = 0.5f * d4 + 0.5f * (p.e[4].x - p.e[3].x);
-            Sbb[v] = 0.5f * (p.e[1].y - p.e[0].y) + 0.5f * d4;
-            Sc[v] = v2f{Sh0[v], Sbb[v]};
-        }
-        euler_flux<float, D>(Pa, Pbb, Sa, Sbb, Dc.e[4].x, Dc.e[0].y, 0.5f, gas, F4);
+    for (int v = 0; v < 5; ++v) {
+        const Col& p = Pc[v];
+        Sc[v] = v2f{Sh0[v], 0.5f * (p.e[1].y - p.e[0].y) + 0.5f * (p.e[0].y - p.e[4].x)};
     }
     // ---- faces (j, j + 5), two at a time
     v2f Fp[5];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        v2f Pa[5], Pbb[5], Sn[5], F[5];
+        v2f Sn[5], F[5];
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
             const Col& p = Pc[v];
-            Pa[v] = j == 0 ? v2f{h0.hu[v], p.e[0].y} : p.e[j];
-            Pbb[v] = j == 3 ? v2f{p.e[4].x, h1.hu[v]} : p.e[j + 1];
             if (j < 3) Sn[v] = slope(v, j + 1);
             else {
                 const float d4 = p.e[0].y - p.e[4].x;
-                Sn[v] = v2f{0.5f * d4 + 0.5f * (p.e[4].x - p.e[3].x), Sh1[v]};
+                Sn[v] = v2f{0.5f * d4 + 0.5f * (p.e[4].x - p.e[3].x), park[64 * v]};
             }
+        }
+        v2f Pa[5], Pbb[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            Pa[v] = Pc[v].e[j];
+            Pbb[v] = Pc[v].e[j + 1];
         }
         const v2f wa = j == 0 ? v2f{1.0f - qlo, 0.5f} : j == 3 ? v2f{0.5f, qhi} : v2f{0.5f, 0.5f};
         euler_flux<v2f, D>(Pa, Pbb, Sc, Sn, Dc.e[j], Dc.e[j + 1], wa, gas, F);
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
-            if (j == 0 && isF0) F[v].x = Ff0[v];
-            if (j == 3 && isF1) F[v].y = Ff1[v];
+            if (j == 0 && isF0) F[v].x = 0.0f;
+            if (j == 3 && isF1) F[v].y = 0.0f;
             if (j == 0) {
-                put(v, 4, F[v].y - F4[v]);  // cell 4: faces 4 and 5
-            } else {                        // cells (j - 1, j + 4)
+                put(v, 4, F[v].y, true);  // cell 4: faces 4 (in R already) and 5
+            } else {                      // cells (j - 1, j + 4)
                 const v2f dF = F[v] - Fp[v];
-                put(v, j - 1, dF.x);
-                put(v, j + 4, dF.y);
+                put(v, j - 1, dF.x, j == 1 && isF0);
+                put(v, j + 4, dF.y, j == 3 && isF1);
             }
-            if (j == 3) put(v, 3, F4[v] - F[v].x);  // cell 3: faces 3 and 4
+            if (j == 3) put(v, 3, -F[v].x, true);  // cell 3: faces 3 and 4 (in R already)
             Fp[v] = F[v];
             Sc[v] = Sn[v];
         }
@@ -608,44 +693,55 @@ __device__ __forceinline__ void load_zcol(const float* __restrict__ p, Col& c) {
     }
 }
 
-// the first loads of a block, those of the sensor: halo cell ids, rim ids, the pressure as z-columns, the halo pressures
-struct Pre {
-    Slot slots[6];
-    int32_t rids[6];
-    Col p;
-    float hp[6];
-};
-__device__ __forceinline__ void load_pre(const BlockDesc3& bn, const int32_t* __restrict__ htab,
-                                         const int32_t* __restrict__ rtab, const int32_t* __restrict__ dtab,
-                                         const float* __restrict__ P, int32_t blk, int lane, Pre& q) {
-    // halo cell ids first: where a side is FINE (a table load) the compiler waits for every load in flight before it
-    // uses the ids
-    q.slots[0] = slot_of<0>(bn, htab, blk, lane, dtab);
-    q.slots[1] = slot_of<1>(bn, htab, blk, lane, dtab);
-    q.slots[2] = slot_of<2>(bn, htab, blk, lane, dtab);
-    q.slots[3] = slot_of<3>(bn, htab, blk, lane, dtab);
-    q.slots[4] = slot_of<4>(bn, htab, blk, lane, dtab);
-    q.slots[5] = slot_of<5>(bn, htab, blk, lane, dtab);
-    __builtin_amdgcn_sched_barrier(0);
+// ---- the first loads of a block -- those its sensor needs, and the rim ids: the pressure as z-columns (8 rows of 64), the
+// halo pressures (6), the rim ids of the six sides (6) -- go to a wave-private LDS buffer by LDS-DMA (global_load_lds_dword:
+// a per-lane global address, row base + 4 * lane in LDS, no VGPR for the data).  In a chain of blocks they are requested
+// during the z fluxes of the block before and cost that block neither registers nor a wait.
+#define S3E_NEXT_ROWS 20
+#define S3E_NEXT (64 * S3E_NEXT_ROWS)  // floats per wave
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// row[lane] = base[idx] (4-byte elements; uniform base + 32-bit lane offset: the SGPR-base form of the instruction)
+__device__ __forceinline__ void dma_row(const void* base, uint32_t idx, float* row) {
+    __builtin_amdgcn_global_load_lds((gptr_t)((const char*)base + (size_t)(idx << 2)), (lptr_t)row, 4, 0, 0);
+}
+__device__ __forceinline__ void request_first(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                              const int32_t* __restrict__ rtab, const float* __restrict__ P, int32_t blk,
+                                              int lane, float* nextbuf) {
+    const BlockDesc3 bn = blocks[blk];
+    // halo cell ids first (a table load where a side is FINE or faces a fragment)
+    uint32_t hid[6];
+    hid[0] = halo_cell3s<0>(bn, htab, blk, lane);
+    hid[1] = halo_cell3s<1>(bn, htab, blk, lane);
+    hid[2] = halo_cell3s<2>(bn, htab, blk, lane);
+    hid[3] = halo_cell3s<3>(bn, htab, blk, lane);
+    hid[4] = halo_cell3s<4>(bn, htab, blk, lane);
+    hid[5] = halo_cell3s<5>(bn, htab, blk, lane);
+#ifdef S3E_ABLATE_HALO
 #pragma unroll
-    for (int s = 0; s < 6; ++s) q.rids[s] = rtab[(size_t)blk * 384 + s * 64 + lane];
-    load_zcol(P + (uint32_t)bn.base + lane, q.p);
+    for (int s = 0; s < 6; ++s) hid[s] = (uint32_t)bn.base + 64u * s + (uint32_t)lane;
+#endif
+    const uint32_t c0 = (uint32_t)bn.base + (uint32_t)lane;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) q.hp[s] = ldg(P, q.slots[s].hid);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 8; ++i) dma_row(P, c0 + 64u * i, nextbuf + 64 * i);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) dma_row(P, hid[s], nextbuf + 64 * (8 + s));
+    const int32_t* rt = rtab + (size_t)blk * 384;  // (uniform)
+#pragma unroll
+    for (int s = 0; s < 6; ++s) dma_row(rt, (uint32_t)(64 * s + lane), nextbuf + 64 * (14 + s));
 }
 
-// One block.
+// One block whose first loads are in (or on their way to) `nextbuf`; `next` requests those of the wave's next block
+// (called in the z pass, when the buffer has long been read).
 // STAMP: phase time stamps of the wave (100 MHz ticks) for scripts/wave_timeline_3d.py: 0 start, 1 first loads landed,
 // 2 sensor done, 3 x fluxes, 4 transposed, 5 y fluxes, 6 transposed, 7 end
-template <bool STAMP = false>
-__device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
-                                                 const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
-                                                 const int32_t* __restrict__ r4tab, int32_t blk,
-                                                 const float* __restrict__ P, uint32_t ldp, float* __restrict__ Rr,
-                                                 uint32_t ldr, Gas3 gas, float* lds, int lane,
-                                                 unsigned long long* stamps = nullptr,
-                                                 const int32_t* __restrict__ dtab = nullptr) {
+template <bool STAMP, class Next>
+__device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                            const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
+                                            const int32_t* __restrict__ r4tab, int32_t blk, const float* __restrict__ P,
+                                            uint32_t ldp, float* __restrict__ Rr, uint32_t ldr, const Gas3& gas, float* lds,
+                                            int lane, unsigned long long* stamps, const int32_t* __restrict__ dtab,
+                                            const float* nextbuf, Next&& next) {
     auto stamp = [&](int k) {
         if constexpr (STAMP) {
             __builtin_amdgcn_sched_barrier(0);
@@ -658,22 +754,12 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
     const BlockDesc3 bb = blocks[blk];
     const int ta = lane & 7, tb = lane >> 3;
     float* buf = lds + S3E_BUF;
-    // ---- every load that does not depend on another one, up front, in the order of their use: those of the sensor, then
-    // the loads of the x fluxes:
-    Pre pre;
-    load_pre(bb, htab, rtab, dtab, P, blk, lane, pre);
-    // ---- the halo registers of the x sides, the five primitives
-    // as x-columns (two float4 per field)
-    Slot slots[6];
-    int32_t rids[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        slots[s] = pre.slots[s];
-        rids[s] = pre.rids[s];
-    }
-    HaloRegs hA0, hA1, hB0, hB1;
-    halo_load_values<0>(bb, lane, P, ldp, slots[0], hA0);
-    halo_load_values<1>(bb, lane, P, ldp, slots[1], hA1);
+    // ---- the halo values of the x sides and the five primitives as x-columns (two float4 per field): requested now, in
+    // flight during the sensor
+    HaloRegs h0, h1;
+    Slot sl0 = slot_of<0>(bb, htab, blk, lane, dtab), sl1 = slot_of<1>(bb, htab, blk, lane, dtab);
+    halo_load_values<0>(bb, lane, P, ldp, sl0, h0);
+    halo_load_values<1>(bb, lane, P, ldp, sl1, h1);
     __builtin_amdgcn_sched_barrier(0);
     Col Pc[5];
     {
@@ -687,23 +773,37 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    hA0.rv = ldg(P, (uint32_t)(rids[0] >= 0 ? rids[0] : bb.base));  // (the only loads here that depend on another one)
-    hA1.rv = ldg(P, (uint32_t)(rids[1] >= 0 ? rids[1] : bb.base));
+    // ---- the buffer of the first loads: the DMA rows are older than the 30 loads just issued (vector memory operations
+    // complete in order)
+    asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+    const int32_t* nrid = (const int32_t*)(nextbuf + 64 * 14) + lane;
+    int32_t rid0 = nrid[0], rid1 = nrid[64];
+    Col pz;
+    float hp[6];
+    {
+        const float* np_ = nextbuf + lane;
+        set_cell<0>(pz, np_[0]); set_cell<1>(pz, np_[64]); set_cell<2>(pz, np_[128]); set_cell<3>(pz, np_[192]);
+        set_cell<4>(pz, np_[256]); set_cell<5>(pz, np_[320]); set_cell<6>(pz, np_[384]); set_cell<7>(pz, np_[448]);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) hp[s] = np_[64 * (8 + s)];
+    }
+    h0.rv = ldg(P, (uint32_t)(rid0 >= 0 ? rid0 : bb.base));
+    h1.rv = ldg(P, (uint32_t)(rid1 >= 0 ? rid1 : bb.base));
     __builtin_amdgcn_sched_barrier(0);
     stamp(1);
     // ---- pressure sensor of the block's cells: z, y, x
     Col Dc;
     {
-        Col p = pre.p, N, Dn;
-        sensor_pass<2, true>(bb, ftab, P, lane, pre.hp[4], pre.hp[5], p, N, Dn);
+        Col p = pz, N, Dn;
+        sensor_pass<2, true>(bb, ftab, P, lane, hp[4], hp[5], p, N, Dn);
         transpose<2, 1>(buf, ta, tb, p);
         transpose<2, 1>(buf, ta, tb, N);
         transpose<2, 1>(buf, ta, tb, Dn);
-        sensor_pass<1, false>(bb, ftab, P, lane, pre.hp[2], pre.hp[3], p, N, Dn);
+        sensor_pass<1, false>(bb, ftab, P, lane, hp[2], hp[3], p, N, Dn);
         transpose<1, 0>(buf, ta, tb, p);
         transpose<1, 0>(buf, ta, tb, N);
         transpose<1, 0>(buf, ta, tb, Dn);
-        sensor_pass<0, false>(bb, ftab, P, lane, pre.hp[0], pre.hp[1], p, N, Dn);
+        sensor_pass<0, false>(bb, ftab, P, lane, hp[0], hp[1], p, N, Dn);
 #pragma unroll
         for (int j = 1; j < 4; ++j)
             Dc.e[j] = v2f{fmaxf(N.e[j].x * __builtin_amdgcn_rcpf(Dn.e[j].x), 1e-7f),
@@ -712,28 +812,71 @@ __device__ __forceinline__ void sweep_euler_cols(const BlockDesc3* __restrict__ 
         Dc.e[0].y = fmaxf(N.e[0].y * __builtin_amdgcn_rcpf(Dn.e[0].y), 1e-7f);
     }
     stamp(2);
-    // ---- fluxes: x, y, z
-    const LaneGeo LG = lane_geo(lane);
-    flux_pass<0, 0>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hA0, hA1, [&]() {
-        halo_load<2>(bb, lane, P, ldp, slots[2], rids[2], hB0);
-        halo_load<3>(bb, lane, P, ldp, slots[3], rids[3], hB1);
-    }, Rr, ldr);
+    // ---- fluxes: x, y, z.  The halo values of a pass are requested before the flux loop of the pass before (after its
+    // side evaluations, when its own halo registers are free).
+    // (The block descriptor is read again for every pass -- scalar loads -- instead of holding its 38 words in SGPRs
+    // throughout: with it the kernel ran out of SGPRs and kept the five field pointers in VGPRs.)
+    asm volatile("" : "+s"(blk));
+    const BlockDesc3 bx = blocks[blk];
+    HaloRegs g0, g1;  // the halo registers of the next pass: requested before the flux loop of the pass in hand
+    Slot tl0, tl1;
+    int32_t tid0, tid1;
+    flux_pass<0, 0>(bx, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, sl0, sl1, rid0, rid1, h0, h1, Rr, ldr, [&]() {
+        tid0 = ((const int32_t*)(nextbuf + 64 * 16))[lane];
+        tid1 = ((const int32_t*)(nextbuf + 64 * 17))[lane];
+        tl0 = slot_of<2>(bx, htab, blk, lane, dtab);
+        tl1 = slot_of<3>(bx, htab, blk, lane, dtab);
+        halo_load<2>(bx, lane, P, ldp, tl0, tid0, g0);
+        halo_load<3>(bx, lane, P, ldp, tl1, tid1, g1);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+s"(blk));
+    const BlockDesc3 by = blocks[blk];
     stamp(3);
 #pragma unroll
     for (int v = 0; v < 5; ++v) transpose<0, 1>(buf, ta, tb, Pc[v]);
     transpose<0, 1>(buf, ta, tb, Dc);
     stamp(4);
-    flux_pass<1, 1>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hB0, hB1, [&]() {
-        halo_load<4>(bb, lane, P, ldp, slots[4], rids[4], hA0);
-        halo_load<5>(bb, lane, P, ldp, slots[5], rids[5], hA1);
-    }, Rr, ldr);
+    flux_pass<1, 1>(by, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, tl0, tl1, tid0, tid1, g0, g1, Rr, ldr, [&]() {
+        rid0 = ((const int32_t*)(nextbuf + 64 * 18))[lane];
+        rid1 = ((const int32_t*)(nextbuf + 64 * 19))[lane];
+        sl0 = slot_of<4>(by, htab, blk, lane, dtab);
+        sl1 = slot_of<5>(by, htab, blk, lane, dtab);
+        halo_load<4>(by, lane, P, ldp, sl0, rid0, h0);
+        halo_load<5>(by, lane, P, ldp, sl1, rid1, h1);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+s"(blk));
+    const BlockDesc3 bz = blocks[blk];
     stamp(5);
 #pragma unroll
     for (int v = 0; v < 5; ++v) transpose<1, 2>(buf, ta, tb, Pc[v]);
     transpose<1, 2>(buf, ta, tb, Dc);
     stamp(6);
-    flux_pass<2, 2>(bb, LG, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, slots, rids, hA0, hA1, []() {}, Rr, ldr);
+    flux_pass<2, 2>(bz, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, sl0, sl1, rid0, rid1, h0, h1, Rr, ldr, next);
     stamp(7);
+}
+
+// A chain of blocks first, first + stride, ... < end for one wave: the first loads of a block are requested while the z
+// fluxes of the block before are computed.
+template <bool STAMP = false>
+__device__ __forceinline__ void sweep_euler_chain(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
+                                                  const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
+                                                  const int32_t* __restrict__ r4tab, int32_t first, int32_t stride,
+                                                  int32_t end, const float* __restrict__ P, uint32_t ldp,
+                                                  float* __restrict__ Rr, uint32_t ldr, Gas3 gas, float* lds,
+                                                  float* nextbuf, int lane, unsigned long long* stamps = nullptr,
+                                                  const int32_t* __restrict__ dtab = nullptr) {
+    if (first >= end) return;
+    request_first(blocks, htab, rtab, P, first, lane, nextbuf);
+#pragma unroll 1
+    for (int32_t blk = first; blk < end; blk += stride) {
+        const int32_t nb = blk + stride;
+        sweep_block<STAMP>(blocks, htab, ftab, rtab, r4tab, blk, P, ldp, Rr, ldr, gas, lds, lane,
+                           STAMP && stamps ? stamps + (size_t)blk * 8 : nullptr, dtab, nextbuf, [&]() {
+                               if (nb < end) request_first(blocks, htab, rtab, P, nb, lane, nextbuf);  // wave-uniform
+                           });
+    }
 }
 
 #pragma clang fp contract(off)

@@ -52,7 +52,9 @@ def pct(a):
     return [round(float(np.percentile(a, p)), 2) for p in (10, 50, 90)]
 
 
-out = {"workload": name, "waves": int(len(b)), "kernel_span_us": round(float(us[:, 7].max()), 2),
+# residency: waves alive at a few instants
+alive = {str(t): int(((us[:, 0] <= t) & (us[:, 7] > t)).sum()) for t in (2, 5, 10, 20, 30, 50, 70, 90)}
+out = {"workload": name, "waves": int(len(b)), "kernel_span_us": round(float(us[:, 7].max()), 2), "alive_at_us": alive,
        "wave_life_us_p10_50_90": pct(us[:, 7] - us[:, 0]),
        "phase_us_p10_50_90": {nm: pct(dur[:, k]) for k, nm in enumerate(names)},
        "start_us_p10_50_90": pct(us[:, 0])}
