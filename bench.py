@@ -275,12 +275,13 @@ def main():
         raise SystemExit("--step march: the explicit step of test/advection.jl on a 2-D workload, one GPU")
     if (config4 or config5) and (msh.ndims != 3 or args.residual != "euler"):
         raise SystemExit("--step config4 / config5 need a sphere3d workload and --residual euler")
-    if config5:
-        msh.distance_fields = {}  # the V-cycle line builds no ghost cells (config4 does)
+    if config5 and world > 1:
+        msh.distance_fields = {}  # (the multi-rank V-cycle line still runs without ghost cells: Euler + Wray-Agarwal only)
     fam4 = [("farfield", [(d, s_) for d in (1, 2, 3) for s_ in (False, True)])]
     fam2 = [("farfield", [(1, False), (1, True), (2, False), (2, True)])]
-    dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=config4 or march, only=[rank + 1],
-                       hypercube_families=fam4 if config4 else fam2 if march else ())
+    bc5 = config5 and world == 1       # configs[4] with its boundary conditions on every level (one GPU)
+    dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=config4 or march or bc5, only=[rank + 1],
+                       hypercube_families=fam4 if (config4 or bc5) else fam2 if march else ())
     part = dom.partitions[rank + 1]
     n_image = int(part.image.size)
     u_h, C_h = synthetic_fields(part.centers)
@@ -458,18 +459,30 @@ def main():
                  "extra_rows": [int(lv5.nrows[l_] - ncs5[l_]) for l_ in range(3)],
                  "recv_cells": [int(pl.n_recv) for pl in lv5.plans]}
     elif config5:
-        from ibamd.closures import euler_wray_agarwal_residual
+        # one GPU: the level closure of configs[4] as a solver script would write it -- impose_bc! on the level's own
+        # Boundary structs (FlowBC free stream; slip wall with wall_function), then Euler HLL + viscous_fluxes(mu + mu_t) +
+        # Wray-Agarwal transport (closures.py; tests/test_config5.py runs the same closure against the oracle)
+        from ibamd.closures import config5_boundary_conditions, navier_stokes_wray_agarwal_residual
         cds5, prol5, coar5 = ibamd.multigrid(dom, max_levels=2)
+        doms5 = [dom] + list(cds5)
         levels5 = [dpart] + [ibamd.to_backend(d.partitions[1], ibamd.hip) for d in cds5]
         for a5 in list(prol5) + list(coar5):
             ibamd.to_backend(a5)                       # transfer operators on the device before the timed region
+        ghosts5 = []
+        for d5 in doms5:                               # device-resident Boundary structs, built before the timed region
+            ghosts5.append({k: int(sum(b.ghost_indices.size for b in v.values())) for k, v in d5.boundaries.items()})
+            for v5 in d5.boundaries.values():
+                for b5 in v5.values():
+                    ibamd.to_backend(b5, ibamd.hip)
         Q5 = ibamd.colmajor_empty(dpart.nc, nvp + 1)
         Q5[:, :nvp] = P
         Q5[:, nvp] = 4.5e-5
         Q5_0 = Q5.clone()
+        FAR5 = [1.0e5, 288.15, 100.0, 0.0, 0.0]
 
         def f5(level, Q):
-            return euler_wray_agarwal_residual(levels5[level], Q), 2e-7
+            config5_boundary_conditions(doms5[level], Q, FAR5)
+            return navier_stokes_wray_agarwal_residual(levels5[level], Q), 2e-7
 
     step_form = {"fused": fused_step, "overlap": comm_stream is not None}
 
@@ -873,6 +886,34 @@ def main():
                          "exchange, Euler HLL residual sweep on the image blocks), 3D sphere")
         out["config"]["step"] = dict(dist4, what="distributed.LocalDomain: local boundary chunks, donor cells beyond the "
                                                  "skirt as extra rows; two exchanges per step")
+        # the point-implicit smoother across the ranks (point_implicit.py with distributed.RankOps): every residual sweep of
+        # the Hutchinson estimate and of the Jacobian-vector products behind a skirt exchange, dots / norms / max all-reduced
+        from ibamd import point_implicit as pi
+        from ibamd.distributed import RankOps
+        ops4 = RankOps(part.image_in_domain, bdom4.n_rows, hx4.exchange, device=u.device)
+        P40 = P4.clone()
+        dtp = 1e-5
+
+        def f_pi_local(X):
+            r_ = ibamd.colmajor_empty(X.shape[0], nvp)
+            r_[dpart.nc:] = 0.0
+            r_[:dpart.nc] = (X[:dpart.nc] - P40[:dpart.nc]) / dtp - ibamd.residual_euler_hll(dpart, X[:dpart.nc], flags=flags)
+            return r_
+        f_pi = ops4.closure(f_pi_local)
+        barrier()
+        t0 = time.perf_counter()
+        lin, bb, prec = pi.linearize(f_pi, P4, 1, h=1e-2, seed=1 + rank)
+        barrier()
+        t1 = time.perf_counter()
+        _, ratio = pi.solve(lin, bb, prec, n_iter=1, rtol=1e-9, reduce=ops4)
+        barrier()
+        t2 = time.perf_counter()
+        out["config"]["step"]["point_implicit"] = {
+            "linearize_ms": round((t1 - t0) * 1e3, 2), "solve_1_iteration_ms": round((t2 - t1) * 1e3, 2),
+            "residual_ratio": round(float(ratio), 4),
+            "what": "pseudo-time step (P - P0)/dt - R(P) across the ranks: Hutchinson block estimate with 1 sample per "
+                    "variable (6 exchanges + sweeps), one two-direction relaxation (2 exchanges + sweeps, 2 x 2 all-reduced "
+                    "dot products, max |r| and the norm all-reduced)"}
     if config4 and world == 1:
         from ibamd import point_implicit as pi
         P0 = P.clone()
@@ -906,16 +947,23 @@ def main():
                                          "10 steps, ibh_step_advection (k_sweep_quad storing u + dt ud, then the BC set) "
                                          "ping-pong between two arrays; boundaries: wall = 0, far field = copy(u)"}
     if config5:
-        out["metric"] = ("Mcells*V-cycles/s, config-5 step (FAS! V-cycle, 3 levels x 2 smoothing iterations, Euler HLL + "
-                         "Wray-Agarwal scalar residual), 3D sphere")
+        out["metric"] = ("Mcells*V-cycles/s, config-5 step (FAS! V-cycle, 3 levels x 2 smoothing iterations, " +
+                         ("impose_bc! on every level + Euler HLL + viscous fluxes with eddy viscosity + Wray-Agarwal scalar"
+                          if world == 1 else "Euler HLL + Wray-Agarwal scalar residual, no ghost cells") + "), 3D sphere")
         if dist5 is not None:
             out["config"]["distributed"] = dist5
         out["config"]["step"] = {"levels_cells": [int(l.nc) for l in levels5],
                                  "residual_evaluations_per_step": 9,
-                                 "what": "solver.jl:39-91 over multigrid() (ImmersedBoundary.jl:1355-1407); residual = fused "
-                                         "3-D Euler sweep (face-list kernels on the coarse levels) + operator-granularity "
-                                         "Wray-Agarwal transport (closures.euler_wray_agarwal_residual); one host sync per "
-                                         "iteration for the convergence test"}
+                                 "what": "solver.jl:39-91 over multigrid() (ImmersedBoundary.jl:1355-1407); level closure = "
+                                         "impose_bc! on the level's own boundaries (FlowBC free stream, slip wall with "
+                                         "wall_function: cfd.jl:243-300, turbulence.jl:27-98), fused 3-D Euler sweep "
+                                         "(face-list kernels on the coarse levels), viscous_fluxes(mu + mu_t) at operator "
+                                         "granularity (cfd.jl:664-736), Wray-Agarwal transport (closures.py); one host sync "
+                                         "per iteration for the convergence test" if world == 1 else
+                                         "solver.jl:39-91 over multigrid(); residual = fused 3-D Euler sweep + Wray-Agarwal "
+                                         "transport (closures.euler_wray_agarwal_residual), no ghost cells on this line"}
+        if world == 1:
+            out["config"]["step"]["ghost_cells"] = ghosts5
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler and not is3d:
         cb = cpu_baseline(part, u_h, C_h)
         out["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "Mcells*iters/s", "cores": cb["threads"],

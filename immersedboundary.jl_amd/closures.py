@@ -32,3 +32,60 @@ def euler_wray_agarwal_residual(part, Q, nu=1.5e-5, out=None):
     # S + sum_d green_gauss(at_faces(nu + nuR) .* face_gradient(R) .- at_faces(u_d .* R)) in one launch, straight into r
     T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"], out=r[:, nvp])
     return r
+
+
+def config5_boundary_conditions(dom, Q, far, wall_name="sphere", far_name="farfield", fluid=None, R_inf=None):
+    """The boundary conditions of a level of BASELINE.json configs[4], ``impose_bc!`` on THAT level's own ``Boundary``
+    structs (``multigrid`` builds every coarse ``Domain`` with its boundaries, ImmersedBoundary.jl:1381-1382), in the order a
+    solver script would write them:
+
+    * far field (hypercube family): ``FlowBC(fluid, [p, T, u, v, w])`` on the primitives (cfd.jl:243-300), the free-stream
+      value on the turbulence scalar;
+    * immersed wall: slip wall ``FlowBC(fluid, [p, T, 0]; normal_flow = true)`` with ``du!dn`` from
+      ``wall_function(y, u, nu)`` (turbulence.jl:72-98) at the image points -- ``y`` = image distance, ``u`` = tangential
+      speed at the image point, ``nu = mu(T) / rho`` -- and the wall function's ``nu_t`` as the value of the scalar.
+
+    ``Q = [p T u v w R]`` (global device array of the level, updated in place)."""
+    from . import cfd
+    fluid = fluid or cfd.Fluid()
+    nd = dom.ndims
+    P, R = Q[:, :nd + 2], Q[:, nd + 2]
+    free = cfd.FlowBC(fluid, far)
+    wall = cfd.FlowBC(fluid, [far[0], far[1], 0.0], normal_flow=True)
+    R_inf = float(R_inf if R_inf is not None else 3 * 1.5e-5)
+    B.impose_bc(lambda b, Pi, Ri: (free(Pi, b.normals), R_inf), dom, far_name, P, R)
+
+    def wall_bc(b, Pi, Ri):
+        rho = Pi[:, 0] / (fluid.R * Pi[:, 1])
+        nu = cfd.dynamic_viscosity(fluid, Pi[:, 1].contiguous()) / rho
+        un = (Pi[:, 2:] * b.normals).sum(dim=1)
+        ut = torch.sqrt(((Pi[:, 2:] - un[:, None] * b.normals) ** 2).sum(dim=1))
+        wf = T.wall_function(b.image_distances, ut.contiguous(), nu.contiguous())
+        return wall(Pi, b.normals, du_dn=wf["du_dn"], image_distances=b.image_distances), wf["nut"]
+    B.impose_bc(wall_bc, dom, wall_name, P, R)
+
+
+def navier_stokes_wray_agarwal_residual(part, Q, nu=1.5e-5, fluid=None, out=None):
+    """``Q = [p T u v (w) R]`` -> residual: Euler HLL sweep (``ibh_residual_euler_hll``) + the viscous fluxes with the eddy
+    viscosity, ``sum_d green_gauss(viscous_fluxes(fluid, at_faces(P), face_gradient(P, grad P, d), d; mu_t = at_faces(rho nu_t)), d)``
+    (cfd.jl:664-736 over ImmersedBoundary.jl:899-1069) + the Wray-Agarwal transport equation of ``euler_wray_agarwal_residual``."""
+    from . import cfd
+    fluid = fluid or cfd.Fluid()
+    nd = part.nd
+    nvp = nd + 2
+    if Q.shape[1] != nvp + 1:
+        raise ValueError(f"Q must be (nc, {nvp + 1}) = [p T u v (w) R]")
+    r = out if out is not None else B.colmajor_empty(Q.shape[0], nvp + 1)
+    P = Q[:, :nvp]
+    B.residual_euler_hll(part, P, out=r[:, :nvp])
+    R = Q[:, nvp].contiguous()
+    S = T.shear_rate_of_velocity(part, Q[:, 2:2 + nd])
+    wa = T.Wray_Agarwal_of(part, R, S)
+    T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"], out=r[:, nvp])
+    mut = (Q[:, 0] / (fluid.R * Q[:, 1])) * wa["nut"]                 # mu_t = rho nu_t
+    gP = B.cell_gradient(part, P)                                     # tuple over the dimensions of (nc, nd + 2)
+    for d in range(1, nd + 1):
+        Fv = cfd.viscous_fluxes(fluid, B.at_faces(part, P, d), B.face_gradient(part, P, gP, d), d,
+                                mu_t=B.at_faces(part, mut.contiguous(), d))
+        r[:, :nvp] += B.green_gauss(part, Fv, d)
+    return r

@@ -151,6 +151,58 @@ class Reductions:
         return float(self._allreduce(t, self.dist.ReduceOp.MIN).item())
 
 
+class RankOps(Reductions):
+    """What the point-implicit smoother (point_implicit.py; /root/reference/src/point_implicit.jl:65-114, 221-236, 250-329)
+    needs of a rank beyond ``Reductions``:
+
+    * ``closure(f_local)``: the residual closure of the rank -- refreshes the skirt (and donor) rows of its argument with
+      ``exchange`` (every Hutchinson sample and every Jacobian-vector product is a residual sweep, and needs them), calls
+      ``f_local`` and zeroes the rows the rank does not own, so that every vector the smoother forms vanishes there;
+    * ``sum(t)`` / ``max(t)``: all-reduce of a small device (or numpy) array in place -- the two dot products of
+      ``proj_along``, the norm and ``max |r|`` of ``solve``;
+    * ``own(a)``: the rows of a local array that this rank owns, zero elsewhere (for ``b`` and initial vectors).
+
+    ``n_rows``: rows of the local arrays (domain + extras); ``exchange(X)``: in-place halo exchange of a local array."""
+
+    def __init__(self, image_in_domain, n_rows, exchange, group=None, device="cpu"):
+        super().__init__(image_in_domain, group=group, device=device)
+        self.n_rows = int(n_rows)
+        self.exchange = exchange
+        m = np.zeros(self.n_rows, dtype=np.float32)
+        m[np.asarray(image_in_domain, dtype=np.int64)] = 1.0
+        self.mask_np = m
+        self.mask = self.torch.from_numpy(m).to(self.device)
+
+    def own(self, a):
+        if isinstance(a, np.ndarray):
+            return a * (self.mask_np if a.ndim == 1 else self.mask_np[:, None])
+        a *= (self.mask if a.ndim == 1 else self.mask[:, None])
+        return a
+
+    def closure(self, f_local):
+        def f(X):
+            self.exchange(X)
+            return self.own(f_local(X))
+        return f
+
+    def _reduce_inplace(self, t, op):
+        if isinstance(t, np.ndarray):
+            c = self.torch.from_numpy(t)
+            if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
+                self.dist.all_reduce(c, op=op, group=self.group)
+            return t
+        r = self._allreduce(t, op)
+        if r is not t:
+            t.copy_(r)
+        return t
+
+    def sum(self, t):
+        return self._reduce_inplace(t, self.dist.ReduceOp.SUM)
+
+    def max(self, t):
+        return self._reduce_inplace(t, self.dist.ReduceOp.MAX)
+
+
 # ---------------------------------------------------------------------------
 # FAS! across ranks: the levels of multigrid(dom) with one partition of every level per rank
 # ---------------------------------------------------------------------------

@@ -6,6 +6,14 @@ and only the convergence test reads a scalar back, once per inner iteration like
 
 ``f`` is the user's residual closure on device arrays, e.g. ``lambda P: ibamd.residual_euler_hll(dpart, P)``.
 Arrays are ``(n,)`` or column-major ``(n, nv)`` device arrays (``ibamd.hip``).  There is no CPU path.
+
+Across ranks (one partition per GPU): the arrays are the rank's local arrays (image + skirt rows [+ donor extras]) and
+``f`` is ``distributed.RankOps.closure(f_local)`` -- it refreshes the skirt rows of its argument (the halo exchange) before
+the residual sweep and returns zeros on the rows the rank does not own -- so that every vector the smoother forms
+(``b``, the Hutchinson sums, ``A v``, ``r``, the search directions) vanishes outside the owned rows; what is left to do here
+is to sum the dot products and norms and to take the maximum over the ranks: ``reduce=RankOps`` (``.sum(t)`` / ``.max(t)``
+all-reduce a small device tensor in place).  The +-1 sample of a skirt row never matters: the exchange overwrites the
+perturbed skirt rows with their owners' values.
 """
 from __future__ import annotations
 
@@ -166,7 +174,7 @@ class _Scalars:
         self.nr = torch.zeros(1, dtype=torch.float64, device=dev)
 
 
-def proj_along(A, v, b):
+def proj_along(A, v, b, reduce=None):
     """:221-236 -- ``(alpha, Av)`` with ``alpha = (Av . b) / (Av . Av + eps)``; alpha is read back (host float)."""
     Av = A(v)
     b = _dense(b)
@@ -174,31 +182,39 @@ def proj_along(A, v, b):
     n = _numel(b)
     call("ibh_dot", n, _p(Av), _p(b), c_vp(dots.data_ptr()))
     call("ibh_dot", n, _p(Av), _p(Av), c_vp(dots.data_ptr() + 8))
+    if reduce is not None:
+        reduce.sum(dots)
     d = dots.cpu().numpy()
     return float(np.float32(d[0]) / (np.float32(d[1]) + np.float32(EPS32))), Av
 
 
-def _relax(A, s, r, x, sc):
+def _relax(A, s, r, x, sc, reduce=None):
     """One minimal-residual step along ``s`` without leaving the device (:291-294 / :301-304)."""
     As = A(s)
     n = _numel(r)
     call("ibh_dot", n, _p(As), _p(r), c_vp(sc.dots.data_ptr()))
     call("ibh_dot", n, _p(As), _p(As), c_vp(sc.dots.data_ptr() + 8))
+    if reduce is not None:
+        reduce.sum(sc.dots)                      # (Av . b, Av . Av) over the owned rows of all ranks
     call("ibh_pi_update", n, _p(sc.dots), EPS32, _p(s), _p(As), _p(x), _p(r))
 
 
-def solve(A, b, prec, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=None, verbose=False, check_every=1):
+def solve(A, b, prec, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=None, verbose=False, check_every=1,
+          reduce=None):
     """:250-329 -- block-preconditioned two-direction minimal-residual relaxation; returns ``(x, |r|/|r0|)``.
     ``multigrid``: object with ``coarseners`` / ``prolongators`` (callables on device arrays, e.g. the
     ``DeviceAccumulator``s of ``ibamd.multigrid``), cycled from the coarsest level to none like the reference.
     ``check_every``: the residual norm is read back (the one host round trip of a step) every that many inner steps and
-    after the last one; 1 = the reference's loop."""
+    after the last one; 1 = the reference's loop.
+    ``reduce``: across ranks (module docstring) -- dot products, norms and ``max |r|`` are all-reduced over the ranks."""
     b = _dense(b)
     n = _numel(b)
     sc = _Scalars(b.device)
 
     def norm(t):
         call("ibh_sumsq", n, _p(t), _p(sc.nr))
+        if reduce is not None:
+            reduce.sum(sc.nr)
         return float(np.sqrt(sc.nr.item()))
     nr0 = norm(b)
     nr = nr0
@@ -214,11 +230,13 @@ def solve(A, b, prec, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=Non
             s = prec(r)
             if n_mgrid > 0:
                 s = _dense(multigrid.prolongators[n_mgrid - 1](multigrid.coarseners[n_mgrid - 1](s)))
-            _relax(A, s, r, x, sc)
+            _relax(A, s, r, x, sc, reduce)
             # second direction: the residual itself
             call("ibh_maxabs", n, _p(r), _p(sc.mx))
+            if reduce is not None:
+                reduce.max(sc.mx)
             call("ibh_pi_normalize", n, _p(r), _p(sc.mx), EPS32, _p(s))
-            _relax(A, s, r, x, sc)
+            _relax(A, s, r, x, sc, reduce)
             step = (nit - 1) * n_inner + nin
             if step % max(1, int(check_every)) == 0 or step == n_iter * n_inner:
                 nr = norm(r)

@@ -75,14 +75,29 @@ def linearize(f, x, samples, pre_evaluated_fx=None, h=1e-6):
     return Linearization(f, x, fx, h), -fx, D
 
 
-def proj_along(A, v, b):
+def _dots(Av, b, reduce):
+    """(Av . b, Av . Av) in Float64 like the device kernels; across ranks (``reduce``: tests of the distributed smoother,
+    ibamd.distributed.RankOps) the two partial sums are all-reduced."""
+    d = np.array([np.vdot(Av.astype(np.float64), b.astype(np.float64)), np.vdot(Av.astype(np.float64), Av.astype(np.float64))])
+    if reduce is not None:
+        reduce.sum(d)
+    return d
+
+
+def proj_along(A, v, b, reduce=None):
     """:221-236"""
     Av = A(v)
-    return f32(np.vdot(Av, b)) / (f32(np.vdot(Av, Av)) + EPS), Av
+    if reduce is None:
+        return f32(np.vdot(Av, b)) / (f32(np.vdot(Av, Av)) + EPS), Av
+    d = _dots(Av, b, reduce)
+    return f32(d[0]) / (f32(d[1]) + EPS), Av
 
 
-def solve(A, b, invD, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=None):
-    """:250-329"""
+def solve(A, b, invD, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=None, reduce=None):
+    """:250-329.  ``reduce``: the hooks of a rank of a distributed run (sums and maxima all-reduced, Float64 partial sums);
+    None = the reference's loop."""
+    if reduce is not None:
+        return _solve_ranks(A, b, invD, n_iter, n_inner, rtol, atol, reduce)
     nr0 = f32(np.linalg.norm(b))
     nr = nr0
     x = np.zeros_like(b)
@@ -105,4 +120,35 @@ def solve(A, b, invD, n_iter=100, n_inner=1, rtol=1e-2, atol=1e-7, multigrid=Non
             if nr < nr0 * f32(rtol) + f32(atol):
                 return x, nr / (nr0 + EPS)
         n_mgrid = n_levels if n_mgrid == 0 else n_mgrid - 1
+    return x, nr / (nr0 + EPS)
+
+
+def _solve_ranks(A, b, invD, n_iter, n_inner, rtol, atol, reduce):
+    """``solve`` with the scalars of a step all-reduced over the ranks (vectors vanish outside the owned rows)."""
+    def norm(t):
+        d = np.array([np.sum(t.astype(np.float64) ** 2)])
+        reduce.sum(d)
+        return f32(np.sqrt(d[0]))
+
+    def maxabs(t):
+        d = np.array([np.max(np.abs(t))], dtype=np.float32)
+        reduce.max(d)
+        return d[0]
+    nr0 = norm(b)
+    nr = nr0
+    x = np.zeros_like(b)
+    r = b.copy()
+    for _ in range(n_iter):
+        for _ in range(n_inner):
+            s = apply_prec(invD, r)
+            a, As = proj_along(A, s, r, reduce)
+            x = x + s * a
+            r = r - As * a
+            s = r / (EPS + maxabs(r))
+            a, As = proj_along(A, s, r, reduce)
+            x = x + s * a
+            r = r - As * a
+            nr = norm(r)
+            if nr < nr0 * f32(rtol) + f32(atol):
+                return x, nr / (nr0 + EPS)
     return x, nr / (nr0 + EPS)

@@ -4,7 +4,13 @@ one-equation turbulence scalar in the residual -- the closure the reference real
 (src/turbulence.jl:222-241; F2 of SURVEY.md: there is no Spalart-Allmaras in the reference):
 
     Q = [p T u v w R];   d/dt [p T u v w] <- Euler HLL residual (JST + MUSCL + CFD.inviscid_fluxes + green_gauss)
+                                               + div of CFD.viscous_fluxes with mu(T) + rho nu_t  (src/cfd.jl:664-736)
     R_t = -div(u R) + div[(nu + nu_R) grad R] + S,   (nu_t, nu_R, S) = Wray_Agarwal(R, shear_rate(grad u), grad R, grad S)
+
+with the boundary conditions a solver script would impose before every residual evaluation, on every level's OWN
+`Boundary` structs (`multigrid` builds each coarse `Domain` with its boundaries, src/ImmersedBoundary.jl:1381-1382):
+`FlowBC` free stream on the box (src/cfd.jl:243-300), on the immersed sphere a slip wall whose `du!dn` and turbulence
+scalar come from `wall_function(y, u, nu)` at the image points (src/turbulence.jl:72-98).
 
 Device-resident loop (fused 3-D Euler sweep on the fine level, face-list kernels on the coarse ones, operator kernels
 and the turbulence kernels for the scalar, Accumulator SpMV for the transfers) against the oracle's numpy loop."""
@@ -43,13 +49,19 @@ def test_config5_fas_vcycle_with_turbulence_scalar():
     from oracle.solver import FAS as oFAS
     from test_gpu_residual import oracle_euler_residual
     msh = Mesh(f32([-4, -4, -4]), f32([8, 8, 8]), ("sphere", bench.icosphere(subdiv=2), f32(0.2)), block_size=8)
-    msh.distance_fields = {}                       # the V-cycle test builds no ghost cells (tests/test_config4.py does)
-    dom = ibamd.Domain(msh, max_partition_size=10 ** 9)
+    fam = [("farfield", [(d, sd) for d in (1, 2, 3) for sd in (False, True)])]
+    dom = ibamd.Domain(msh, hypercube_families=fam, max_partition_size=10 ** 9)
     cds, prol, coar = ibamd.multigrid(dom, max_levels=2)
     levels = [dom] + cds
     sizes = [len(d) for d in levels]
     assert dom.ndims == 3 and sizes[0] >= 100_000 and sizes[0] == 8 * sizes[1] == 64 * sizes[2]
+    from conftest import oracle_boundaries_view
+    ghosts = [{k: sum(b.ghost_indices.size for b in v.values()) for k, v in d.boundaries.items()} for d in levels]
+    print("config-5 ghost cells per level:", ghosts)
+    assert all(g["sphere"] > 0 and g["farfield"] > 0 for g in ghosts)       # every level has its own boundaries
+    views = [oracle_boundaries_view(d) for d in levels]
     parts = [d.partitions[1] for d in levels]
+    assert all(np.array_equal(p.domain, np.arange(len(d))) for p, d in zip(parts, levels))   # local order = global order
     oparts = [oracle_view(p) for p in parts]
     dparts = [ibamd.to_backend(p, ibamd.hip) for p in parts]
     assert dparts[0].info["full_blocks"] * 512 == sizes[0]         # fine level: the 3-D block kernels
@@ -65,8 +77,28 @@ def test_config5_fas_vcycle_with_turbulence_scalar():
     Q0[:, 5] = 3 * NU * (1 + 0.5 * rng.uniform(0, 1, n))          # R_inf = 3 nu (turbulence.jl:205)
     omega = f32(2e-7)                                             # pseudo-time step, the same on every level
 
+    FAR = [1.0e5, 288.15, 100.0, 0.0, 0.0]
+    R_INF = f32(3) * NU
+    ofluid = ocfd.Fluid()
+    o_free = ocfd.FlowBC(ofluid, f32(FAR))
+    o_wall = ocfd.FlowBC(ofluid, f32([FAR[0], FAR[1], 0.0]), normal_flow=True)
+
+    def o_bcs(l, Q):
+        P, R = Q[:, :5], Q[:, 5]          # (views: impose_bc writes through)
+        od.impose_bc(lambda b, Pi, Ri: (o_free(Pi, b.normals), R_INF), views[l], "farfield", P, R)
+
+        def wall_bc(b, Pi, Ri):
+            rho = Pi[:, 0] / (ofluid.R * Pi[:, 1])
+            nu = ocfd.dynamic_viscosity(ofluid, Pi[:, 1]) / rho
+            un = (Pi[:, 2:] * b.normals).sum(axis=1)
+            ut = np.sqrt(((Pi[:, 2:] - un[:, None] * b.normals) ** 2).sum(axis=1))
+            wf = ot.wall_function(b.image_distances, ut, nu)
+            return o_wall(Pi, b.normals, dudn=wf["du_dn"], image_distances=b.image_distances), wf["nut"]
+        od.impose_bc(wall_bc, views[l], "sphere", P, R)
+
     def o_f(l, Q):
         part = oparts[l]
+        o_bcs(l, Q)
         r = np.zeros_like(Q)
         r[:, :5] = oracle_euler_residual(part, np.ascontiguousarray(Q[:, :5]), ocfd.Fluid())
         R = np.ascontiguousarray(Q[:, 5])
@@ -81,11 +113,20 @@ def test_config5_fas_vcycle_with_turbulence_scalar():
             diff = od.at_faces(part, NU + wa["nuR"], d + 1) * od.face_gradient(part, R, d + 1)
             rt += od.green_gauss(part, diff - conv, d + 1)
         r[:, 5] = rt
+        # viscous fluxes with the eddy viscosity
+        P = np.ascontiguousarray(Q[:, :5])
+        mut = (Q[:, 0] / (ofluid.R * Q[:, 1])) * wa["nut"]
+        gP = tuple(od.cell_gradient(part, P, d + 1) for d in range(3))
+        for d in (1, 2, 3):
+            Fv = ocfd.viscous_fluxes(ofluid, od.at_faces(part, P, d), od.face_gradient(part, P, gP, d), d,
+                                     mu_t=od.at_faces(part, mut, d))
+            r[:, :5] += od.green_gauss(part, Fv, d)
         return r, omega
 
     def g_f(l, Q):
-        from ibamd.closures import euler_wray_agarwal_residual
-        return euler_wray_agarwal_residual(dparts[l], Q, nu=NU), omega
+        from ibamd.closures import config5_boundary_conditions, navier_stokes_wray_agarwal_residual
+        config5_boundary_conditions(levels[l], Q, FAR, R_inf=float(R_INF))
+        return navier_stokes_wray_agarwal_residual(dparts[l], Q, nu=NU), omega
 
     # one evaluation of the residual on every level first (coarse levels through the transfer operators)
     ocoar, oprol = [_oracle_acc(a) for a in coar], [_oracle_acc(a) for a in prol]
