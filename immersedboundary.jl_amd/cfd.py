@@ -160,6 +160,32 @@ def viscous_fluxes(fluid, P, Pgrad, dim, mu_t=0.0):
     return F
 
 
+def viscous_residual(part, fluid, P, Pgrad, mu_t, R):
+    """``R[:, 1:] .+= sum_d green_gauss(part, viscous_fluxes(fluid, at_faces(part, P, d), face_gradient(part, P, Pgrad, d), d;
+    mu_t = at_faces(part, mu_t, d)), d)`` in ONE launch (``ibh_viscous_residual``), bit-identical to that composition
+    (cfd.jl:664-736 over ImmersedBoundary.jl:899-926, 1039-1069).  ``Pgrad`` = the tuple ``cell_gradient(part, P)``,
+    ``mu_t`` a cell array, ``R`` the (nc, nd + 2) residual updated in place."""
+    part = B._part(part)
+    P, _, ldp = B._field(P, part.nc)
+    nd = _nd(P)
+    grads = [B._field(g, part.nc)[0] for g in Pgrad]
+    if len(grads) != nd:
+        raise ValueError("Pgrad needs one array per dimension")
+    ldg = {g.stride(1) for g in grads}
+    if len(ldg) != 1:
+        grads = [g.T.contiguous().T for g in grads]
+        ldg = {part.nc}
+    ptrs = (B.c_vp * nd)(*[g.data_ptr() for g in grads])
+    mt = B._field(mu_t, part.nc)[0]
+    R, nvr, ldr = B._field_inplace(R, part.nc, "R")
+    if nvr != nd + 2:
+        raise ValueError("R must be (nc, nd + 2)")
+    f = fluid._c()
+    B._stream()
+    B.call("ibh_viscous_residual", part.handle, C.byref(f), B._ptr(P), ldp, ptrs, int(ldg.pop()), B._ptr(mt), B._ptr(R), ldr)
+    return R
+
+
 class FlowBC:
     """cfd.jl:160-300 -- generic flow boundary condition, called on device arrays inside ``impose_bc`` closures:
     ``bc(P, bdry.normals)``, ``bc(P, bdry.normals, du_dn=..., image_distances=bdry.image_distances, transpiration=...)``.

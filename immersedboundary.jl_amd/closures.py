@@ -65,10 +65,11 @@ def config5_boundary_conditions(dom, Q, far, wall_name="sphere", far_name="farfi
     B.impose_bc(wall_bc, dom, wall_name, P, R)
 
 
-def navier_stokes_wray_agarwal_residual(part, Q, nu=1.5e-5, fluid=None, out=None):
+def navier_stokes_wray_agarwal_residual(part, Q, nu=1.5e-5, fluid=None, out=None, fused_viscous=True):
     """``Q = [p T u v (w) R]`` -> residual: Euler HLL sweep (``ibh_residual_euler_hll``) + the viscous fluxes with the eddy
     viscosity, ``sum_d green_gauss(viscous_fluxes(fluid, at_faces(P), face_gradient(P, grad P, d), d; mu_t = at_faces(rho nu_t)), d)``
-    (cfd.jl:664-736 over ImmersedBoundary.jl:899-1069) + the Wray-Agarwal transport equation of ``euler_wray_agarwal_residual``."""
+    (cfd.jl:664-736 over ImmersedBoundary.jl:899-1069) + the Wray-Agarwal transport equation of ``euler_wray_agarwal_residual``.
+    ``fused_viscous``: the viscous sum in one launch (``ibh_viscous_residual``, bit-identical); False = operator by operator."""
     from . import cfd
     fluid = fluid or cfd.Fluid()
     nd = part.nd
@@ -84,6 +85,10 @@ def navier_stokes_wray_agarwal_residual(part, Q, nu=1.5e-5, fluid=None, out=None
     T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"], out=r[:, nvp])
     mut = (Q[:, 0] / (fluid.R * Q[:, 1])) * wa["nut"]                 # mu_t = rho nu_t
     gP = B.cell_gradient(part, P)                                     # tuple over the dimensions of (nc, nd + 2)
+    if fused_viscous:
+        # sum_d green_gauss(viscous_fluxes(at_faces(P), face_gradient(P, gP, d), d; mu_t = at_faces(mu_t)), d) in one launch
+        cfd.viscous_residual(part, fluid, P, gP, mut.contiguous(), r[:, :nvp])
+        return r
     for d in range(1, nd + 1):
         Fv = cfd.viscous_fluxes(fluid, B.at_faces(part, P, d), B.face_gradient(part, P, gP, d), d,
                                 mu_t=B.at_faces(part, mut.contiguous(), d))

@@ -159,6 +159,113 @@ __global__ void k_viscous(ibh_fluid f, int dim0, int64_t n, const float* __restr
     }
 }
 
+// ---- the viscous part of a Navier-Stokes residual, all dimensions in one launch (thread per cell, side table / face lists):
+//   R[:, v] += sum_d green_gauss(viscous_fluxes(fluid, at_faces(P, d), face_gradient(P, grad P, d), d; mu_t = at_faces(mu_t, d)), d)
+// (cfd.jl:664-736 over ImmersedBoundary.jl:899-926, 1039-1069) -- the composition of closures.navier_stokes_wray_agarwal_residual
+// operation by operation: same expressions, same order as k_at_faces / k_face_gradient / k_viscous / k_green_gauss and the
+// three `R .+= ...` (-ffp-contract=off), so the result is theirs bit for bit; a face's flux is evaluated by both of its cells
+// instead of nine face arrays per dimension being written and read back.
+template <int ND>
+struct ViscDims {
+    DimData d[ND];
+    const float* h[ND];
+    const float* g[ND];       // cell gradients of P along each axis, (nc, ND + 2) column-major, leading dimension ldg
+    const int32_t* side;
+};
+__device__ __forceinline__ float v_face_avg(float uo, float un, float ho, float hn) { return (uo * hn + un * ho) / (hn + ho); }
+// flux through the face between owner o and neighbour n normal to D0: F[0] = energy, F[1 + j] = momentum j
+template <int ND, int D0>
+__device__ __forceinline__ void visc_flux_on(const ibh_fluid& f, const ViscDims<ND>& V, int32_t o, int32_t n,
+                                             const float* __restrict__ P, int64_t ldp, int64_t ldg,
+                                             const float* __restrict__ mut, float* F) {
+    const float ho = V.h[D0][o], hn = V.h[D0][n];
+    const float fd = (ho + hn) / 2.0f;                                   // face_distance
+    const float T = v_face_avg(P[o + ldp], P[n + ldp], ho, hn);         // at_faces(P)[:, 2]
+    float u[ND], vg[ND][ND];
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+        const float uo = P[o + (2 + a) * ldp], un = P[n + (2 + a) * ldp];
+        u[a] = v_face_avg(uo, un, ho, hn);
+#pragma unroll
+        for (int b = 0; b < ND; ++b)                                     // vel_grad(a, b) = Pgrad[b][:, 2 + a]
+            vg[a][b] = b == D0 ? (un - uo) / fd                          // face_gradient(part, P, dim)
+                               : v_face_avg(V.g[b][o + (2 + a) * ldg], V.g[b][n + (2 + a) * ldg], ho, hn);  // at_faces(grad_b P)
+    }
+    const float gT = (P[n + ldp] - P[o + ldp]) / fd;                     // Pgrad[dim][:, 2]
+    const float mu = sutherland(f, T) + v_face_avg(mut[o], mut[n], ho, hn);
+    const float k = conductivity(f, T);
+    float divu = 0.f;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) divu = (a == 0) ? 0.f + vg[0][0] : divu + vg[a][a];
+    float Fe = 0.0f + gT * k;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const float tau = ((vg[D0][j] + vg[j][D0]) - (D0 == j ? 2.0f / 3.0f : 0.0f) * divu) * mu;
+        Fe = Fe + tau * u[j];
+        F[1 + j] = 0.0f + tau;
+    }
+    F[0] = Fe;
+}
+template <int ND, int D0>
+__device__ __forceinline__ void visc_mean(const ibh_fluid& f, const ViscDims<ND>& V, const int32_t* __restrict__ off,
+                                          const int32_t* __restrict__ idx, int32_t c, const float* __restrict__ P,
+                                          int64_t ldp, int64_t ldg, const float* __restrict__ mut, float* A) {
+    const int32_t b = off[c], e = off[c + 1];
+#pragma unroll
+    for (int v = 0; v <= ND; ++v) A[v] = 0.0f;
+    if (e == b) return;
+    const float w = 1.0f / (float)(e - b);
+    for (int32_t k = b; k < e; ++k) {
+        const int32_t fc = idx[k];
+        float F[ND + 1];
+        visc_flux_on<ND, D0>(f, V, V.d[D0].owners[fc], V.d[D0].neighbors[fc], P, ldp, ldg, mut, F);
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) A[v] = (k == b) ? F[v] * w : A[v] + F[v] * w;
+    }
+}
+template <int ND, int D0>
+__device__ __forceinline__ void visc_dim(const ibh_fluid& f, const ViscDims<ND>& V, int32_t nc, int32_t c,
+                                         const float* __restrict__ P, int64_t ldp, int64_t ldg,
+                                         const float* __restrict__ mut, float* acc) {
+    const int32_t l = V.side[(int64_t)(2 * D0) * nc + c], r = V.side[(int64_t)(2 * D0 + 1) * nc + c];
+    float ar[ND + 1], al[ND + 1];
+    if (r >= 0) {
+        visc_flux_on<ND, D0>(f, V, c, r, P, ldp, ldg, mut, ar);
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) ar[v] = ar[v] * 1.0f;
+    } else if (r == -2) {
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) ar[v] = 0.0f;
+    } else visc_mean<ND, D0>(f, V, V.d[D0].roff, V.d[D0].ridx, c, P, ldp, ldg, mut, ar);
+    if (l >= 0) {
+        visc_flux_on<ND, D0>(f, V, l, c, P, ldp, ldg, mut, al);
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) al[v] = al[v] * 1.0f;
+    } else if (l == -2) {
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) al[v] = 0.0f;
+    } else visc_mean<ND, D0>(f, V, V.d[D0].loff, V.d[D0].lidx, c, P, ldp, ldg, mut, al);
+    const float hc = V.h[D0][c];
+#pragma unroll
+    for (int v = 0; v <= ND; ++v) acc[v] = acc[v] + (ar[v] - al[v]) / hc;   // R .+= green_gauss(...), one dimension after the other
+}
+template <int ND>
+__global__ __launch_bounds__(CFD_BLOCK) void k_viscous_residual(ibh_fluid f, int32_t nc, ViscDims<ND> V,
+                                                                const float* __restrict__ P, int64_t ldp, int64_t ldg,
+                                                                const float* __restrict__ mut, float* __restrict__ R,
+                                                                int64_t ldr) {
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        float acc[ND + 1];
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) acc[v] = R[c + (1 + v) * ldr];
+        visc_dim<ND, 0>(f, V, nc, (int32_t)c, P, ldp, ldg, mut, acc);
+        visc_dim<ND, 1>(f, V, nc, (int32_t)c, P, ldp, ldg, mut, acc);
+        if constexpr (ND == 3) visc_dim<ND, 2>(f, V, nc, (int32_t)c, P, ldp, ldg, mut, acc);
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) R[c + (1 + v) * ldr] = acc[v];
+    }
+}
+
 inline dim3 grid1(int64_t n) { int g = ibh_grid(n, CFD_BLOCK); return dim3(g > 4096 ? 4096 : g); }
 
 // FlowBC call, cfd.jl:243-300: characteristic-style boundary state from the image-point primitives
@@ -323,6 +430,39 @@ int ibh_cfd_viscous_fluxes(const ibh_fluid* f, int nd, int dim, int64_t n, const
         GradPtrs<3> g{{Pgrad[0], Pgrad[1], Pgrad[2]}};
         hipLaunchKernelGGL(k_viscous<3>, grid1(n), dim3(CFD_BLOCK), 0, ibh_stream, *f, dim - 1, n, P, ldp, g, ldg, mu_t,
                            mu_t_const, F, ldf);
+    }
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+int ibh_viscous_residual(const ibh_part* p, const ibh_fluid* f, const float* P, int64_t ldp, const float* const* Pgrad,
+                         int64_t ldg, const float* mu_t, float* R, int64_t ldr) {
+    IBH_REQUIRE(p && f && P && Pgrad && mu_t && R && (p->nd == 2 || p->nd == 3), "ibh_viscous_residual: bad argument");
+    IBH_REQUIRE(f->nk >= 0 && f->nk <= 4, "ibh_cfd: nk out of range");
+    IBH_REQUIRE(p->side, "ibh_viscous_residual: the partition has no side table");
+    if (p->nc == 0) return 0;
+    if (p->nd == 2) {
+        ViscDims<2> V;
+        for (int d = 0; d < 2; ++d) {
+            IBH_REQUIRE(Pgrad[d], "ibh_viscous_residual: null gradient array");
+            V.d[d] = p->dim[d];
+            V.h[d] = p->spacing + (int64_t)d * p->nc;
+            V.g[d] = Pgrad[d];
+        }
+        V.side = p->side;
+        hipLaunchKernelGGL(k_viscous_residual<2>, grid1(p->nc), dim3(CFD_BLOCK), 0, ibh_stream, *f, p->nc, V, P, ldp, ldg,
+                           mu_t, R, ldr);
+    } else {
+        ViscDims<3> V;
+        for (int d = 0; d < 3; ++d) {
+            IBH_REQUIRE(Pgrad[d], "ibh_viscous_residual: null gradient array");
+            V.d[d] = p->dim[d];
+            V.h[d] = p->spacing + (int64_t)d * p->nc;
+            V.g[d] = Pgrad[d];
+        }
+        V.side = p->side;
+        hipLaunchKernelGGL(k_viscous_residual<3>, grid1(p->nc), dim3(CFD_BLOCK), 0, ibh_stream, *f, p->nc, V, P, ldp, ldg,
+                           mu_t, R, ldr);
     }
     IBH_LAUNCH_CHECK();
     return 0;

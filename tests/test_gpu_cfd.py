@@ -117,3 +117,40 @@ def test_three_point_jst_and_shock_sensor(nd):
     got = ibamd.to_host(gcfd.shock_sensor([[ibamd.hip(x) for x in row] for row in g]))
     exp = ocfd.shock_sensor(g)
     assert np.allclose(got, exp, rtol=2e-6, atol=0) and (exp > 0).all() and (exp <= 1).all()
+
+
+@pytest.mark.gpu
+def test_viscous_residual_is_the_operator_composition(rae_domains):
+    """``ibh_viscous_residual`` -- R .+= sum_d green_gauss(viscous_fluxes(fluid, at_faces(P, d), face_gradient(P, grad P, d), d;
+    mu_t = at_faces(mu_t, d)), d) in one launch -- against the same expression composed from the operator kernels, on 2-D
+    partitions with skirts (single faces through the side table, coarse-fine sides through the face lists) and on a 3-D
+    octree partition: bit for bit."""
+    import torch
+    import bench
+    from ibamd import cfd as gcfd
+    from ibamd.mesher import Mesh
+    from conftest import euler_field
+    dp, _ = rae_domains
+    cases = [(dp.partitions[k], 2) for k in (1, 3)]
+    msh3 = Mesh(f32([-4, -4, -4]), f32([8, 8, 8]), ("sphere", bench.icosphere(subdiv=2), f32(0.4)), block_size=8)
+    msh3.distance_fields = {}
+    dom3 = ibamd.Domain(msh3, max_partition_size=10 ** 9)
+    cases.append((dom3.partitions[1], 3))
+    fluid = gcfd.Fluid()
+    rng = np.random.default_rng(8)
+    for part, nd in cases:
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        nc = part.centers.shape[0]
+        P = ibamd.hip(euler_field(part.centers, seed=3))
+        mut = ibamd.hip((1e-4 * rng.uniform(0, 1, nc)).astype(f32))
+        R0 = ibamd.hip(rng.uniform(-1, 1, (nc, nd + 2)).astype(f32))
+        gP = ibamd.cell_gradient(dpart, P)
+        ref = R0.clone()
+        for d in range(1, nd + 1):
+            Fv = gcfd.viscous_fluxes(fluid, ibamd.at_faces(dpart, P, d), ibamd.face_gradient(dpart, P, gP, d), d,
+                                     mu_t=ibamd.at_faces(dpart, mut, d))
+            ref += ibamd.green_gauss(dpart, Fv, d)
+        got = R0.clone()
+        gcfd.viscous_residual(dpart, fluid, P, gP, mut, got)
+        assert not torch.equal(got, R0)
+        assert torch.equal(got, ref), float((got - ref).abs().max())
