@@ -508,7 +508,7 @@ def main():
                       exchange=lambda l_, Q_: hx5[l_].exchange(Q_),
                       level_norm=lambda l_, r_: red5[l_].norm(r_[:ncs5[l_]]))
         elif config5:
-            Q5.copy_(Q5_0)
+            # (no reset of Q between the steps: a solver's V-cycles follow one another; n_iter is fixed, rtol unreachable)
             ibamd.FAS(f5, Q5, coarseners=coar5, prolongators=prol5, n_iter=2, rtol=1e-9)
         elif config4 and world > 1:
             hx4.exchange(P4)                              # skirt and donor rows as the owners have them
@@ -897,7 +897,9 @@ def main():
         def f_pi_local(X):
             r_ = ibamd.colmajor_empty(X.shape[0], nvp)
             r_[dpart.nc:] = 0.0
-            r_[:dpart.nc] = (X[:dpart.nc] - P40[:dpart.nc]) / dtp - ibamd.residual_euler_hll(dpart, X[:dpart.nc], flags=flags)
+            H = ibamd.HipArray
+            r_[:dpart.nc] = ((H(X[:dpart.nc]) - H(P40[:dpart.nc])) / dtp
+                             - H(ibamd.residual_euler_hll(dpart, X[:dpart.nc], flags=flags))).t
             return r_
         f_pi = ops4.closure(f_pi_local)
         barrier()
@@ -919,8 +921,9 @@ def main():
         P0 = P.clone()
         dtp = 1e-5
 
-        def f_pi(X):
-            return (X - P0) / dtp - ibamd.residual_euler_hll(dpart, X)
+        def f_pi(X):   # (X - P0) / dt - R(X) as ONE broadcast launch (ibh_ew_eval), like a Julia `@.` line
+            H = ibamd.HipArray
+            return ((H(X) - H(P0)) / dtp - H(ibamd.residual_euler_hll(dpart, X))).t
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         lin, bb, prec = pi.linearize(f_pi, P, 1, h=1e-2, seed=1)

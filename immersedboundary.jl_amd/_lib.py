@@ -121,6 +121,7 @@ _SIGS = {
                                 c_vp, c_vp, c_vp, C.c_uint32, c_vp],
     "ibh_axpy_clamped": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_axpy_clamped_sumsq": [c_i64, C.c_float, c_vp, c_vp, c_vp],
+    "ibh_fas_update": [c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp],
     "ibh_axpy": [c_i64, C.c_float, c_vp, c_vp],
     "ibh_sumsq": [c_i64, c_vp, c_vp],
     "ibh_turb_wall_function_rey": [c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp],

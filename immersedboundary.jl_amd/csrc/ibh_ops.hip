@@ -597,6 +597,33 @@ __global__ void k_axpy_clamped_sumsq(int64_t n, float omega, const float* __rest
     }
 }
 
+// One pass of `FAS!` over a residual array (solver.jl:80-84): rr = r [+ source]; [q += clamp(omega, 0, 1) * rr]; [sum rr^2]
+// -- `r .+= source`, the fixed-point update and the norm on ONE read of r (round 3 had the sum as an ATen kernel).
+template <bool SRC, bool UPD, bool NRM>
+__global__ void k_fas_update(int64_t n, float omega, const float* __restrict__ r, const float* __restrict__ src,
+                             float* __restrict__ q, double* __restrict__ out) {
+    const float w = fminf(fmaxf(omega, 0.0f), 1.0f);
+    double s = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float ri = r[i];
+        if (SRC) ri = ri + src[i];
+        if (UPD) q[i] = q[i] + w * ri;
+        if (NRM) s += (double)ri * (double)ri;
+    }
+    if (NRM) {
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        __shared__ double part[OPS_BLOCK / 64];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) part[wv] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < OPS_BLOCK / 64; ++i) t += part[i];
+            out[blockIdx.x] = t;
+        }
+    }
+}
+
 inline dim3 grid2(int64_t n, int nv) { return dim3(ibh_grid(n, OPS_BLOCK) > 4096 ? 4096 : ibh_grid(n, OPS_BLOCK), nv); }
 
 // launch of the accumulation kernels: per (row, field) for one field, per row over blocks of up to 4 fields otherwise
@@ -910,6 +937,32 @@ int ibh_axpy_clamped_sumsq(int64_t n, float omega, const float* r, float* q, dou
     const int nwg = ibh_grid(n, OPS_BLOCK) > 2048 ? 2048 : ibh_grid(n, OPS_BLOCK);
     hipLaunchKernelGGL(k_axpy_clamped_sumsq, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, n, omega, r, q, part);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg, part, out);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+int ibh_fas_update(int64_t n, float omega, const float* r, const float* source, float* q, double* out_sumsq) {
+    IBH_REQUIRE(r || n <= 0, "ibh_fas_update: null residual");
+    double* part = out_sumsq ? red_scratch() : nullptr;
+    IBH_REQUIRE(!out_sumsq || part, "ibh_fas_update: no scratch");
+    if (n <= 0) {
+        if (out_sumsq) IBH_HIP(hipMemsetAsync(out_sumsq, 0, sizeof(double), ibh_stream));
+        return 0;
+    }
+    if (!q && !out_sumsq) return 0;
+    const int nwg = ibh_grid(n, OPS_BLOCK) > 2048 ? 2048 : ibh_grid(n, OPS_BLOCK);
+#define FAS_LAUNCH(S, U, N) \
+    hipLaunchKernelGGL((k_fas_update<S, U, N>), dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, n, omega, r, source, q, part)
+    if (source) {
+        if (q && out_sumsq) FAS_LAUNCH(true, true, true);
+        else if (q) FAS_LAUNCH(true, true, false);
+        else FAS_LAUNCH(true, false, true);
+    } else {
+        if (q && out_sumsq) FAS_LAUNCH(false, true, true);
+        else if (q) FAS_LAUNCH(false, true, false);
+        else FAS_LAUNCH(false, false, true);
+    }
+#undef FAS_LAUNCH
+    if (out_sumsq) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg, part, out_sumsq);
     IBH_LAUNCH_CHECK();
     return 0;
 }

@@ -45,16 +45,47 @@ def _update(Q, omega, r):
 
 def _update_norm(Q, omega, r):
     """``_update`` and ``_norm(r)`` in one pass over ``r`` (``ibh_axpy_clamped_sumsq``); None if the arrays do not allow it."""
+    return _fas_pass(r, None, Q, omega, True)
+
+
+def _dense_pair(a, b):
+    """True when two device arrays are column-major without padding and of one shape (one flat pass covers both)."""
+    if a.shape != b.shape:
+        return False
+    for t in (a, b):
+        f, _, ld = B._field(t)
+        if f.data_ptr() != t.data_ptr() or (t.ndim == 2 and ld != t.shape[0]):
+            return False
+    return True
+
+
+def _fas_pass(r, source, Q, omega, want_norm):
+    """``rr = r [+ source]; [Q += clamp(omega, 0, 1) * rr]; [||rr||]`` in ONE launch (``ibh_fas_update``: solver.jl:80-84 on
+    one read of ``r``).  ``source`` and ``Q`` may be None.  Returns the norm (or True when none was asked for), or None when
+    the arrays do not allow the flat pass (padded layouts, a per-cell ``omega``): the caller composes the steps then."""
     if isinstance(omega, torch.Tensor):
         return None
-    Qf, _, ldq = B._field(Q)
-    rf, _, ldr = B._field(r)
-    if Qf.data_ptr() != Q.data_ptr() or (Q.ndim == 2 and (ldq != Q.shape[0] or ldr != r.shape[0])) or Q.shape != r.shape:
+    if (source is not None and not _dense_pair(r, source)) or (Q is not None and not _dense_pair(r, Q)):
         return None
-    out = torch.empty(1, dtype=torch.float64, device=r.device)
+    f, _, ld = B._field(r)
+    if f.data_ptr() != r.data_ptr() or (r.ndim == 2 and ld != r.shape[0]):
+        return None
+    out = torch.empty(1, dtype=torch.float64, device=r.device) if want_norm else None
     B._stream()
-    B.call("ibh_axpy_clamped_sumsq", int(Q.numel()), C.c_float(float(omega)), B._ptr(rf), B._ptr(Q), B._ptr(out))
-    return float(out.item()) ** 0.5
+    B.call("ibh_fas_update", int(r.numel()), C.c_float(float(omega) if omega is not None else 0.0), B._ptr(r),
+           B._ptr(source), B._ptr(Q), B._ptr(out))
+    return float(out.item()) ** 0.5 if want_norm else True
+
+
+def _sub(a, b):
+    """``a .- b`` of two device arrays as a libibhip broadcast (``ibh_ew_*``), not an ATen kernel."""
+    from .hiparray import HipArray
+    return (HipArray(a) - HipArray(b)).t
+
+
+def _add(a, b):
+    from .hiparray import HipArray
+    return (HipArray(a) + HipArray(b)).t
 
 
 def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level=0, n_iter=50,
@@ -84,16 +115,18 @@ def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level
     fQ, omega = f(l, Q)
     source = None
     if perscribed_f is not None:
-        source = perscribed_f - fQ
-    r = fQ if source is None else fQ + source
-    nr0 = _norm(r)
+        source = _sub(perscribed_f, fQ)
+    nr0 = _fas_pass(fQ, source, None, None, True) if local_norm else None    # ||fQ + source|| on one read of fQ
+    if nr0 is None:
+        nr0 = _norm(fQ if source is None else _add(fQ, source))
     nr = nr0
     if len(coarseners) > 1:
         coars, prolong = B.to_backend(coarseners[0]), B.to_backend(prolongators[0])
         Qc = coars(Q)
         xch(l + 1, Qc)                       # (the prolongation below reads skirt rows of Qc - Qcold)
-        Qcold = Qc.clone()
-        pfQc = coars(r)
+        Qcold = B._like(Qc, Qc.shape[0])
+        Qcold.copy_(Qc)
+        pfQc = coars(fQ if source is None else _add(fQ, source))
         FAS(f, Qc, coarseners=coarseners[1:], prolongators=prolongators[1:], perscribed_f=pfQc,
             multigrid_level=multigrid_level + 1, n_iter=n_iter, atol=atol, rtol=rtol, norm=norm,
             check_every=check_every, exchange=exchange, level_norm=level_norm)
@@ -103,14 +136,19 @@ def FAS(f, Q, coarseners=(), prolongators=(), perscribed_f=None, multigrid_level
     for it in range(n_iter):
         xch(l, Q)
         r, omega = f(l, Q)
-        if source is not None:
-            r = r + source
         check = (it + 1) % check_every == 0 or it == n_iter - 1
-        fused = _update_norm(Q, omega, r) if (check and local_norm) else None
+        # r .+= source; Q .+= clamp(omega, 0, 1) .* r; norm(r): one launch where the layouts allow (and the norm is local)
+        fused = _fas_pass(r, source, Q, omega, check and local_norm)
         if fused is None:
+            if source is not None:
+                r = _add(r, source)
             _update(Q, omega, r)
+            if check:
+                fused = _norm(r)
+        elif check and not local_norm:
+            fused = _norm(r if source is None else _add(r, source))
         if check:
-            nr = fused if fused is not None else _norm(r)
+            nr = fused
             if nr < nr0 * rtol + atol:
                 break
     return nr / (nr0 + _eps32)

@@ -376,6 +376,9 @@ int ibh_axpy(int64_t n, float a, const float* x, float* y);
 int ibh_sumsq(int64_t n, const float* x, double* out);
 /* q += clamp(omega,0,1) * r and *out = sum(r^2) in one pass (solver.jl:82 + the norm of :84 on the same array) */
 int ibh_axpy_clamped_sumsq(int64_t n, float omega, const float* r, float* q, double* out);
+/* One pass of FAS! over a residual array (solver.jl:80-84): rr = r [+ source]; [q += clamp(omega,0,1) * rr]; [*out_sumsq =
+ * sum(rr^2)] -- `r .+= source`, the update and the norm on one read of r; source, q and out_sumsq may each be NULL. */
+int ibh_fas_update(int64_t n, float omega, const float* r, const float* source, float* q, double* out_sumsq);
 
 /* FlowBC call (cfd.jl:243-300): boundary state [p T u v (w)] from the image-point primitives P and the unit normals.
  * u_inf: nd components, or ONE component (the normal velocity) when normal_flow != 0.  image_distances / dudn: both

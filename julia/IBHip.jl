@@ -25,6 +25,7 @@ import ImmersedBoundary: Partition, Boundary, Domain, Accumulator, at_owners, at
     divergent, impose_bc!
 import ImmersedBoundary.CFD: JST_sensor
 import ImmersedBoundary.ArrayBackends: to_backend
+import ImmersedBoundary: CFD, Turbulence, Solver
 
 const lib = get(ENV, "IBHIP_LIB", "libibhip")
 
@@ -245,7 +246,7 @@ Base.sum(a::HipArray{Float32}) = _reduce(EW_SUM, a)
 # ---------------------------------------------------------------------------------------------------
 # Partition on the device: to_backend(part, hip) uploads once (the reference re-uploads per call, :848)
 # ---------------------------------------------------------------------------------------------------
-struct HipPartition{Ti, Tf}
+mutable struct HipPartition{Ti, Tf}   # (mutable: the handle is released by a finalizer, SURVEY.md 8b)
     handle::Ptr{Cvoid}
     host::Partition{Ti, Tf}
     nc::Int
@@ -299,6 +300,7 @@ function to_backend(part::Partition{Ti, Tf}, conv::HipConv) where {Ti, Tf}
                 length(iid), iid, domain, conv.block_size, 1 #= Julia indices =#))
         end
         hp = HipPartition{Ti, Tf}(h[], part, nc, Int.(nf), hip(Array(part.spacing)), hip(Array(part.centers)))
+        finalizer(x -> ccall((:ibh_partition_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), hp)
         hp
     end
 end
@@ -388,7 +390,7 @@ face_gradient(part::HipPartition, u::HipArray, ∇u::Tuple, dim::Int) =
 # Accumulator on the device (src/accumulator.jl:78-130, defaults op = +, f = identity, Δ = false: the only form the
 # reference's callers use) -- interpolators of `impose_bc!`, coarseners / prolongators of `multigrid`
 # ---------------------------------------------------------------------------------------------------
-struct HipAccumulator
+mutable struct HipAccumulator
     handle::Ptr{Cvoid}
     n_output::Int
     n_input::Int
@@ -415,7 +417,9 @@ function to_backend(acc::Accumulator, ::Union{typeof(hip), HipConv})
         check(ccall((:ibh_acc_create, lib), Cint,
             (Ptr{Ptr{Cvoid}}, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Float32}, Cint),
             h, acc.n_output, n_in, off, idx, w, 1))
-        HipAccumulator(h[], acc.n_output, n_in)
+        a = HipAccumulator(h[], acc.n_output, n_in)
+        finalizer(x -> ccall((:ibh_acc_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), a)
+        a
     end
 end
 
@@ -437,7 +441,7 @@ end
 # impose_bc! on device-resident global arrays (src/ImmersedBoundary.jl:1197-1247): per boundary chunk
 #   ia = W * a[image_domain]  (ibh_bc_interp),  ba = f(bdry, ia...),  a[ghost] = η ia + (1 - η) ba  (ibh_bc_blend)
 # ---------------------------------------------------------------------------------------------------
-struct HipBoundary{Ti, Tf}
+mutable struct HipBoundary{Ti, Tf}
     handle::Ptr{Cvoid}
     host::Boundary{Ti, Tf}
     ng::Int
@@ -457,8 +461,10 @@ function to_backend(b::Boundary{Ti, Tf}, ::Union{typeof(hip), HipConv}) where {T
              Ptr{Int32}, Ptr{Int32}, Ptr{Float32}, Cint),
             h, length(gi), gi, Float32.(b.ghost_distances), Float32.(b.image_distances), length(idm), idm,
             off, idx, w, 1))
-        HipBoundary{Ti, Tf}(h[], b, length(gi), hip(Array(b.projections)), hip(Array(b.normals)),
-                            hip(Array(b.image_distances)), hip(Array(b.ghost_distances)))
+        hb = HipBoundary{Ti, Tf}(h[], b, length(gi), hip(Array(b.projections)), hip(Array(b.normals)),
+                                 hip(Array(b.image_distances)), hip(Array(b.ghost_distances)))
+        finalizer(x -> ccall((:ibh_bc_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), hb)
+        hb
     end
 end
 
@@ -635,6 +641,242 @@ function relax_update!(x::HipArray{Float32}, r::HipArray{Float32}, s::HipArray{F
     check(ccall((:ibh_pi_update, lib), Cint, (Int64, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
         length(r), dots, eps(Float32), s.ptr, As.ptr, x.ptr, r.ptr))
     nothing
+end
+
+
+# ---------------------------------------------------------------------------------------------------
+# CFD pointwise physics on device arrays: methods of the reference's own functions (src/cfd.jl) for HipArray, so that a
+# residual closure written against `CFD.*` runs unchanged after `conv_to_backend` (configs[1]-[4]).  Cartesian `dim` only
+# (the matrix-normal forms of `inviscid_fluxes` / `viscous_fluxes` are a curvilinear extension outside this hot path).
+# ---------------------------------------------------------------------------------------------------
+_vec_like(a::HipArray{Float32}) = HipArray{Float32, ndims(a)}(undef, size(a))
+for (jl, c) in ((:speed_of_sound, :ibh_cfd_speed_of_sound), (:dynamic_viscosity, :ibh_cfd_dynamic_viscosity),
+                (:heat_conductivity, :ibh_cfd_heat_conductivity))
+    @eval function CFD.$jl(fluid::CFD.Fluid, T::HipArray{Float32})   # cfd.jl:62-64, 71-77, 84-90
+        out = _vec_like(T)
+        f = Ref(IbhFluid(fluid))
+        check(ccall(($(QuoteNode(c)), lib), Cint, (Ptr{IbhFluid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}), f, length(T), T.ptr, out.ptr))
+        out
+    end
+end
+_ndP(P::HipArray{Float32, 2}) = size(P, 2) - 2
+function CFD.primitive2state(fluid::CFD.Fluid, P::HipArray{Float32, 2})   # cfd.jl:106-123
+    Q = _vec_like(P)
+    f = Ref(IbhFluid(fluid))
+    check(ccall((:ibh_cfd_primitive2state, lib), Cint, (Ptr{IbhFluid}, Cint, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+        f, _ndP(P), size(P, 1), P.ptr, ld(P), Q.ptr, ld(Q)))
+    Q
+end
+function CFD.state2primitive(fluid::CFD.Fluid, Q::HipArray{Float32, 2})   # cfd.jl:137-151
+    P = _vec_like(Q)
+    f = Ref(IbhFluid(fluid))
+    check(ccall((:ibh_cfd_state2primitive, lib), Cint, (Ptr{IbhFluid}, Cint, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+        f, _ndP(Q), size(Q, 1), Q.ptr, ld(Q), P.ptr, ld(P)))
+    P
+end
+function CFD.inviscid_fluxes(fluid::CFD.Fluid, PL::HipArray{Float32, 2}, PR::HipArray{Float32, 2}, dim::Integer)   # :459-508
+    F = _vec_like(PL)
+    f = Ref(IbhFluid(fluid))
+    check(ccall((:ibh_cfd_inviscid_fluxes_hll, lib), Cint,
+        (Ptr{IbhFluid}, Cint, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+        f, _ndP(PL), dim, size(PL, 1), PL.ptr, PR.ptr, ld(PL), F.ptr, ld(F)))
+    F
+end
+function CFD.inviscid_fluxes(fluid::CFD.Fluid, PL::HipArray{Float32, 2}, PR::HipArray{Float32, 2},
+                             νL::HipArray{Float32, 1}, νR::HipArray{Float32, 1}, dim::Integer)                     # :516-554
+    F = _vec_like(PL)
+    f = Ref(IbhFluid(fluid))
+    check(ccall((:ibh_cfd_inviscid_fluxes_sensor, lib), Cint,
+        (Ptr{IbhFluid}, Cint, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+        f, _ndP(PL), dim, size(PL, 1), PL.ptr, PR.ptr, ld(PL), νL.ptr, νR.ptr, F.ptr, ld(F)))
+    F
+end
+"`viscous_fluxes(fluid, P, Pgrad, dim; μₜ)` (cfd.jl:664-736): `Pgrad` a tuple / vector of the gradients of P along each axis."
+function CFD.viscous_fluxes(fluid::CFD.Fluid, P::HipArray{Float32, 2}, Pgrad::Union{AbstractVector, Tuple}, dim::Integer;
+                            μₜ::Union{HipArray{Float32, 1}, Real} = 0.0f0)
+    F = _vec_like(P)
+    f = Ref(IbhFluid(fluid))
+    g = Ptr{Cvoid}[x.ptr for x in Pgrad]
+    GC.@preserve g Pgrad begin
+        check(ccall((:ibh_cfd_viscous_fluxes, lib), Cint,
+            (Ptr{IbhFluid}, Cint, Cint, Int64, Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Int64, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}, Int64),
+            f, _ndP(P), dim, size(P, 1), P.ptr, ld(P), g, ld(Pgrad[1]),
+            μₜ isa HipArray ? μₜ.ptr : C_NULL, μₜ isa HipArray ? 0f0 : Float32(μₜ), F.ptr, ld(F)))
+    end
+    F
+end
+"`R[:, 2:end] .+= Σ_d green_gauss(part, viscous_fluxes(fluid, at_faces(part, P, d), face_gradient(part, P, ∇P, d), d; μₜ = at_faces(part, μₜ, d)), d)`
+in one launch, bit-identical to that composition (`∇P = cell_gradient(part, P)`)."
+function viscous_residual!(R::HipArray{Float32, 2}, part::HipPartition, fluid::CFD.Fluid, P::HipArray{Float32, 2}, ∇P::Tuple,
+                           μₜ::HipArray{Float32, 1})
+    f = Ref(IbhFluid(fluid))
+    g = Ptr{Cvoid}[x.ptr for x in ∇P]
+    GC.@preserve g ∇P begin
+        check(ccall((:ibh_viscous_residual, lib), Cint,
+            (Ptr{Cvoid}, Ptr{IbhFluid}, Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+            part.handle, f, P.ptr, ld(P), g, ld(∇P[1]), μₜ.ptr, R.ptr, ld(R)))
+    end
+    R
+end
+"`(bc::FlowBC)(P, normals; image_distances, du!dn, transpiration)` (cfd.jl:243-300) on image-point arrays of a `HipBoundary`."
+function (bc::CFD.FlowBC)(P::HipArray{Float32, 2}, normals::HipArray{Float32, 2};
+                          image_distances::Union{Nothing, HipArray{Float32, 1}} = nothing,
+                          du!dn::Union{Nothing, HipArray{Float32, 1}} = nothing,
+                          transpiration::Union{Real, HipArray{Float32, 1}} = 0.0f0)
+    isnothing(du!dn) == isnothing(image_distances) ||
+        throw(error("du!dn and image_distances must be passed together for BC imposition"))
+    out = _vec_like(P)
+    f = Ref(IbhFluid(bc.fluid))
+    u∞ = Float32.(collect(bc.u∞))
+    check(ccall((:ibh_cfd_flow_bc, lib), Cint,
+        (Ptr{IbhFluid}, Cint, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Cfloat, Cfloat, Ptr{Float32}, Cint, Ptr{Cvoid},
+         Ptr{Cvoid}, Cfloat, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+        f, _ndP(P), size(P, 1), P.ptr, ld(P), normals.ptr, ld(normals), Float32(bc.p∞), Float32(bc.T∞), u∞,
+        bc.normal_flow ? 1 : 0, isnothing(image_distances) ? C_NULL : image_distances.ptr,
+        isnothing(du!dn) ? C_NULL : du!dn.ptr, transpiration isa Real ? Float32(transpiration) : 0f0,
+        transpiration isa HipArray ? transpiration.ptr : C_NULL, out.ptr, ld(out)))
+    out
+end
+
+# ---------------------------------------------------------------------------------------------------
+# Turbulence closures (src/turbulence.jl) on device arrays.  Velocity gradients: the reference's Matrix of vectors,
+# `velocity_gradient[i, j]` = ∂u_i/∂x_j -> an nd x nd table of device pointers, row-major g[(i-1) nd + j].
+# ---------------------------------------------------------------------------------------------------
+function _grad_table(g::AbstractMatrix)
+    nd = size(g, 1)
+    nd, Ptr{Cvoid}[g[i, j].ptr for i = 1:nd for j = 1:nd]
+end
+_wall_params(κ, C, A, β, βstar, D, A⁺, ω) = Float32[κ, C, A, β, βstar, D, A⁺, ω]
+function Turbulence.wall_function(y::HipArray{Float32, 1}, u::HipArray{Float32, 1}, ν::HipArray{Float32, 1};
+                                  κ::Real = 0.41f0, C::Real = 4.9f0, A::Real = 19.0f0, β::Real = 0.075f0,
+                                  βstar::Real = 0.09f0, D::Real = 4.2f0, A⁺::Real = 360.0f0,
+                                  ω_fixed_point::Real = 0.5f0, n_iter::Int = 20)                    # turbulence.jl:72-98
+    o = ntuple(_ -> _vec_like(y), 6)
+    par = _wall_params(κ, C, A, β, βstar, D, A⁺, ω_fixed_point)
+    check(ccall((:ibh_turb_wall_function, lib), Cint,
+        (Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+         Ptr{Cvoid}, Ptr{Cvoid}),
+        length(y), y.ptr, u.ptr, ν.ptr, par, n_iter, o[1].ptr, o[2].ptr, o[3].ptr, o[4].ptr, o[5].ptr, o[6].ptr))
+    (uτ = o[1], νₜ = o[2], k = o[3], ω = o[4], ϵ = o[5], du!dn = o[6])
+end
+function Turbulence.wall_function(Rey::HipArray{Float32, 1};
+                                  κ::Real = 0.41f0, C::Real = 4.9f0, A::Real = 19.0f0, β::Real = 0.075f0,
+                                  βstar::Real = 0.09f0, D::Real = 4.2f0, A⁺::Real = 360.0f0,
+                                  ω_fixed_point::Real = 0.5f0, n_iter::Int = 20)                    # turbulence.jl:27-70
+    o = ntuple(_ -> _vec_like(Rey), 5)
+    par = _wall_params(κ, C, A, β, βstar, D, A⁺, ω_fixed_point)
+    check(ccall((:ibh_turb_wall_function_rey, lib), Cint,
+        (Int64, Ptr{Cvoid}, Ptr{Float32}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        length(Rey), Rey.ptr, par, n_iter, o[1].ptr, o[2].ptr, o[3].ptr, o[4].ptr, o[5].ptr))
+    (y⁺ = o[1], u⁺ = o[2], μ⁺ = o[3], k⁺ = o[4], du⁺!dy⁺ = o[5])
+end
+function Turbulence.shear_rate(velocity_gradient::AbstractMatrix{<:HipArray})                       # :110-124
+    nd, tab = _grad_table(velocity_gradient)
+    S = _vec_like(velocity_gradient[1, 1])
+    GC.@preserve tab velocity_gradient check(ccall((:ibh_turb_shear_rate, lib), Cint,
+        (Cint, Int64, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}), nd, length(S), tab, S.ptr))
+    S
+end
+function Turbulence.Smagorinsky_νSGS(Δ::HipArray{Float32, 1}, S::HipArray{Float32, 1}; Cₛ::Real = 0.17f0)   # :134-138
+    out = _vec_like(S)
+    check(ccall((:ibh_turb_smagorinsky, lib), Cint, (Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}),
+        length(S), Δ.ptr, S.ptr, Float32(Cₛ), out.ptr))
+    out
+end
+function Turbulence.standard_kϵ(k::HipArray{Float32, 1}, ϵ::HipArray{Float32, 1}, S::HipArray{Float32, 1};
+                                Cμ::Real = 0.09f0, σk::Real = 1.0f0, σϵ::Real = 1.3f0, C1ϵ::Real = 1.44f0,
+                                C2ϵ::Real = 1.92f0)                                                 # :175-196
+    o = ntuple(_ -> _vec_like(k), 5)
+    par = Float32[Cμ, σk, σϵ, C1ϵ, C2ϵ]
+    check(ccall((:ibh_turb_k_epsilon, lib), Cint,
+        (Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        length(k), k.ptr, ϵ.ptr, S.ptr, par, o[1].ptr, o[2].ptr, o[3].ptr, o[4].ptr, o[5].ptr))
+    (νk = o[1], νϵ = o[2], Sk = o[3], Sϵ = o[4], νₜ = o[5])
+end
+function Turbulence.Wray_Agarwal(R::HipArray{Float32, 1}, S::HipArray{Float32, 1}, ∇R::HipArray{Float32, 2},
+                                 ∇S::HipArray{Float32, 2}; σR::Real = 0.72f0, C₁::Real = 0.0829f0, κ::Real = 0.41f0)   # :222-241
+    o = ntuple(_ -> _vec_like(R), 3)
+    check(ccall((:ibh_turb_wray_agarwal, lib), Cint,
+        (Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Cfloat, Cfloat, Cfloat, Ptr{Cvoid},
+         Ptr{Cvoid}, Ptr{Cvoid}),
+        size(∇R, 2), length(R), R.ptr, S.ptr, ∇R.ptr, ld(∇R), ∇S.ptr, ld(∇S), Float32(σR), Float32(C₁), Float32(κ),
+        o[1].ptr, o[2].ptr, o[3].ptr))
+    (νₜ = o[1], νR = o[2], S = o[3])
+end
+function Turbulence.Ducros_sensor(velocity_gradient::AbstractMatrix{<:HipArray})                    # :253-282
+    nd, tab = _grad_table(velocity_gradient)
+    out = _vec_like(velocity_gradient[1, 1])
+    GC.@preserve tab velocity_gradient check(ccall((:ibh_turb_ducros, lib), Cint,
+        (Cint, Int64, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}), nd, length(out), tab, out.ptr))
+    out
+end
+function Turbulence.WALE_νSGS(Δ::HipArray{Float32, 1}, velocity_gradient::AbstractMatrix{<:HipArray}; Cw::Real = 0.325f0)   # :292-337
+    nd, tab = _grad_table(velocity_gradient)
+    @assert nd == 3 "WALE model only implemented for 3D"
+    out = _vec_like(Δ)
+    GC.@preserve tab velocity_gradient check(ccall((:ibh_turb_wale, lib), Cint,
+        (Int64, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Cfloat, Ptr{Cvoid}), length(Δ), Δ.ptr, tab, Float32(Cw), out.ptr))
+    out
+end
+
+# ---------------------------------------------------------------------------------------------------
+# Solver.FAS! (src/solver.jl:39-91) on device arrays: the reference's loop with its array passes as library calls --
+# `r .+= source; Q .+= clamp(ω, 0, 1) .* r; norm(r)` is ONE launch (ibh_fas_update), the prolongation step another
+# (accumulate_diff_add!).  Same keyword arguments, same quirks (recursion guard `length(coarseners) > 1`), same return value.
+# ---------------------------------------------------------------------------------------------------
+const _norm2 = Ref{Ptr{Cvoid}}(C_NULL)
+function _dscalar()
+    if _norm2[] == C_NULL
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ibh_malloc, lib), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, 8))
+        _norm2[] = p[]
+    end
+    _norm2[]
+end
+"`rr = r [.+ source]; [Q .+= clamp(ω, 0, 1) .* rr]`; returns `norm(rr)`."
+function _fas_pass(r::HipArray{Float32}, source, Q, ω::Real)
+    d = _dscalar()
+    check(ccall((:ibh_fas_update, lib), Cint, (Int64, Cfloat, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        length(r), Float32(ω), r.ptr, isnothing(source) ? C_NULL : source.ptr, isnothing(Q) ? C_NULL : Q.ptr, d))
+    h = Ref{Float64}(0.0)
+    check(ccall((:ibh_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), h, d, 8))
+    Float32(sqrt(h[]))
+end
+function Solver.FAS!(f, Q::HipArray{Float32};
+                     coarseners = [], prolongators = [],
+                     perscribed_f::Union{HipArray, Nothing} = nothing,
+                     multigrid_level::Int = 0, n_iter::Int = 50, rtol::Real = 1.0f-1, atol::Real = 1.0f-7)
+    l = multigrid_level
+    fQ, ω = f(l, Q)
+    source = isnothing(perscribed_f) ? nothing : perscribed_f .- fQ
+    nr0 = _fas_pass(fQ, source, nothing, 0f0)
+    nr = nr0
+    if length(coarseners) > 1
+        coars, prolong = to_backend(coarseners[1], hip), to_backend(prolongators[1], hip)
+        Qc = coars(Q)
+        Qcold = copy(Qc)
+        pfQc = coars(isnothing(source) ? fQ : fQ .+ source)
+        Solver.FAS!(f, Qc; coarseners = coarseners[2:end], prolongators = prolongators[2:end], perscribed_f = pfQc,
+                    multigrid_level = l + 1, n_iter = n_iter, atol = atol, rtol = rtol)
+        accumulate_diff_add!(Q, prolong, Qc, Qcold)                  # Q .+= prolongators[1](Qc .- Qcold)
+    end
+    for _ = 1:n_iter
+        r, ω = f(l, Q)
+        nr = _fas_pass(r, source, Q, ω)                              # r .+= source; Q .+= clamp(ω, 0, 1) .* r; norm(r)
+        nr < nr0 * rtol + atol && break
+    end
+    nr / (nr0 + eps(Float32))
+end
+to_backend(a::HipAccumulator, ::Union{typeof(hip), HipConv}) = a
+
+import LinearAlgebra
+"`norm(a)` of a device array (what `FAS!` calls, src/solver.jl:57,84): sum of squares in Float64 on the device."
+function LinearAlgebra.norm(a::HipArray{Float32})
+    d = _dscalar()
+    check(ccall((:ibh_sumsq, lib), Cint, (Int64, Ptr{Cvoid}, Ptr{Cvoid}), length(a), a.ptr, d))
+    h = Ref{Float64}(0.0)
+    check(ccall((:ibh_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), h, d, 8))
+    Float32(sqrt(h[]))
 end
 
 end # module
