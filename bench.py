@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--dt-every", type=int, default=1,
+                    help="--step march: evaluate the time step every that many steps (1 = every step, like march! of "
+                         "test/advection.jl:65; C is constant in the script, so 10 gives the same march)")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: exchange on a second stream beside the interior blocks, boundary blocks after it. "
                          "Off by default: inside a HIP graph the cross-stream fork/join costs ~15 us per step "
@@ -275,11 +278,9 @@ def main():
         raise SystemExit("--step march: the explicit step of test/advection.jl on a 2-D workload, one GPU")
     if (config4 or config5) and (msh.ndims != 3 or args.residual != "euler"):
         raise SystemExit("--step config4 / config5 need a sphere3d workload and --residual euler")
-    if config5 and world > 1:
-        msh.distance_fields = {}  # (the multi-rank V-cycle line still runs without ghost cells: Euler + Wray-Agarwal only)
     fam4 = [("farfield", [(d, s_) for d in (1, 2, 3) for s_ in (False, True)])]
     fam2 = [("farfield", [(1, False), (1, True), (2, False), (2, True)])]
-    bc5 = config5 and world == 1       # configs[4] with its boundary conditions on every level (one GPU)
+    bc5 = config5                      # configs[4] with its boundary conditions on every level
     dom = ibamd.Domain(msh, max_partition_size=mps, boundaries=config4 or march or bc5, only=[rank + 1],
                        hypercube_families=fam4 if (config4 or bc5) else fam2 if march else ())
     part = dom.partitions[rank + 1]
@@ -430,9 +431,9 @@ def main():
     if config5 and world > 1:
         # FAS! across ranks (distributed.RankLevels): every rank holds its partition of every level, the transfer operators
         # restricted to its rows, a halo exchange per level; norms all-reduced over the owned cells
-        from ibamd.closures import euler_wray_agarwal_residual
+        from ibamd.closures import config5_boundary_conditions, navier_stokes_wray_agarwal_residual
         from ibamd.distributed import RankLevels, Reductions
-        lv5 = RankLevels(msh, rank + 1, world, 2, domain_kwargs=dict(boundaries=False))
+        lv5 = RankLevels(msh, rank + 1, world, 2, domain_kwargs=dict(hypercube_families=fam4))
         levels5 = [dpart] + [ibamd.to_backend(p_, ibamd.hip) for p_ in lv5.parts[1:]]
         hx5 = [HaloExchange(pl, u.device) for pl in lv5.plans]
         red5 = [Reductions(p_.image_in_domain, device=u.device) for p_ in lv5.parts]
@@ -447,17 +448,29 @@ def main():
         Q5_0 = Q5.clone()
         ncs5 = [int(l_.nc) for l_ in levels5]
 
+        FAR5 = [1.0e5, 288.15, 100.0, 0.0, 0.0]
+        ghosts5 = []
+        for ld5 in lv5.local_doms:                     # device-resident Boundary structs, built before the timed region
+            ghosts5.append({k: int(sum(b.ghost_indices.size for b in v.values())) for k, v in ld5.boundaries.items()})
+            for v5 in ld5.boundaries.values():
+                for b5 in v5.values():
+                    ibamd.to_backend(b5, ibamd.hip)
+
         def f5(level, Q):
+            # (FAS! has refreshed the skirt and donor rows): impose_bc! on the ghosts this rank owns, on the level's own
+            # boundaries; a second exchange brings the ghosts the peers own; then the residual on the local partition
             nc_l = ncs5[level]
+            config5_boundary_conditions(lv5.local_doms[level], Q, FAR5)
+            hx5[level].exchange(Q)
             if Q.shape[0] == nc_l:
-                return euler_wray_agarwal_residual(levels5[level], Q), 2e-7
+                return navier_stokes_wray_agarwal_residual(levels5[level], Q), 2e-7
             r = ibamd.colmajor_empty(Q.shape[0], nvp + 1)
             r[nc_l:] = 0.0
-            r[:nc_l] = euler_wray_agarwal_residual(levels5[level], Q[:nc_l])
+            r[:nc_l] = navier_stokes_wray_agarwal_residual(levels5[level], Q[:nc_l])
             return r, 2e-7
         dist5 = {"levels_rows": [int(n_) for n_ in lv5.nrows], "levels_cells": ncs5,
                  "extra_rows": [int(lv5.nrows[l_] - ncs5[l_]) for l_ in range(3)],
-                 "recv_cells": [int(pl.n_recv) for pl in lv5.plans]}
+                 "recv_cells": [int(pl.n_recv) for pl in lv5.plans], "owned_ghost_cells": ghosts5}
     elif config5:
         # one GPU: the level closure of configs[4] as a solver script would write it -- impose_bc! on the level's own
         # Boundary structs (FlowBC free stream; slip wall with wall_function), then Euler HLL + viscous_fluxes(mu + mu_t) +
@@ -487,7 +500,7 @@ def main():
     step_form = {"fused": fused_step, "overlap": comm_stream is not None}
 
     if march:
-        # march! of test/advection.jl:61-89, device resident: dt by a device reduction (every 10 steps here: C is constant),
+        # march! of test/advection.jl:61-89, device resident: dt by a device reduction (every step by default, --dt-every),
         # sweep + u .+= ud .* dt in one launch, the impose_bc! calls as one BC set (wall: value 0, far field: copy(u))
         bcs_m = ibamd.BCSet(dom, [(name, "copy" if name == "farfield" else 0.0) for name in dom.boundaries], ipart=rank + 1)
         dt_m = ibamd.timestep_advection(dpart, C, scale=0.75)
@@ -497,7 +510,7 @@ def main():
     def step():
         if march:
             k = mstate["k"]
-            if k % 10 == 0:
+            if k % max(1, args.dt_every) == 0:
                 ibamd.timestep_advection(dpart, C, scale=0.75, out=dt_m)
             ibamd.step_advection(dpart, um[k & 1], C, dt_m, bcs_m, out=um[(k + 1) & 1])
             mstate["k"] = k + 1
@@ -945,14 +958,13 @@ def main():
     if march:
         out["metric"] = "Mcells*steps/s, explicit march (device dt + sweep and update in one launch + BC set), 2D RAE2822"
         out["config"]["step"] = {"ghost_cells": int(bcs_m.n_ghost), "bc_set_levels": int(bcs_m.n_levels), "bc_set_levels_in_one_launch": int(bcs_m.n_direct_levels),
-                                 "dt_reduction_every": 10, "finite": bool(torch.isfinite(um[0]).all().item()),
+                                 "dt_reduction_every": max(1, args.dt_every), "finite": bool(torch.isfinite(um[0]).all().item()),
                                  "what": "test/advection.jl:61-89 without the host in the loop: ibh_timestep_advection every "
-                                         "10 steps, ibh_step_advection (k_sweep_quad storing u + dt ud, then the BC set) "
+                                         f"{max(1, args.dt_every)} step(s), ibh_step_advection (k_sweep_quad storing u + dt ud, then the BC set) "
                                          "ping-pong between two arrays; boundaries: wall = 0, far field = copy(u)"}
     if config5:
-        out["metric"] = ("Mcells*V-cycles/s, config-5 step (FAS! V-cycle, 3 levels x 2 smoothing iterations, " +
-                         ("impose_bc! on every level + Euler HLL + viscous fluxes with eddy viscosity + Wray-Agarwal scalar"
-                          if world == 1 else "Euler HLL + Wray-Agarwal scalar residual, no ghost cells") + "), 3D sphere")
+        out["metric"] = ("Mcells*V-cycles/s, config-5 step (FAS! V-cycle, 3 levels x 2 smoothing iterations, impose_bc! on "
+                         "every level + Euler HLL + viscous fluxes with eddy viscosity + Wray-Agarwal scalar), 3D sphere")
         if dist5 is not None:
             out["config"]["distributed"] = dist5
         out["config"]["step"] = {"levels_cells": [int(l.nc) for l in levels5],
@@ -962,9 +974,10 @@ def main():
                                          "wall_function: cfd.jl:243-300, turbulence.jl:27-98), fused 3-D Euler sweep "
                                          "(face-list kernels on the coarse levels), viscous_fluxes(mu + mu_t) at operator "
                                          "granularity (cfd.jl:664-736), Wray-Agarwal transport (closures.py); one host sync "
-                                         "per iteration for the convergence test" if world == 1 else
-                                         "solver.jl:39-91 over multigrid(); residual = fused 3-D Euler sweep + Wray-Agarwal "
-                                         "transport (closures.euler_wray_agarwal_residual), no ghost cells on this line"}
+                                         "per iteration for the convergence test" +
+                                         ("" if world == 1 else "; across ranks: distributed.RankLevels (the rank's partition, "
+                                          "local boundaries and transfer operators of every level), two exchanges per "
+                                          "residual evaluation (before and after impose_bc!), all-reduced norms")}
         if world == 1:
             out["config"]["step"]["ghost_cells"] = ghosts5
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not euler and not is3d:

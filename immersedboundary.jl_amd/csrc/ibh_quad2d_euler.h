@@ -53,6 +53,18 @@ __device__ __forceinline__ void euler_state2(const v2f* P, bool dn, const blk2::
     a = sqrt2((gas.gamma * gas.R) * T);
 }
 
+// density, energy per mass, pressure, normal velocity and speed of sound of one side of a face pair
+__device__ __forceinline__ void euler_side_pm2(const v2f* P, bool dn, const blk2::Gas& gas, v2f& rho, v2f& e, v2f& p, v2f& un,
+                                               v2f& a) {
+    p = P[0];
+    const v2f T = max2(P[1], v2f{10.0f, 10.0f});
+    const v2f q = P[2] * P[2] + P[3] * P[3];
+    rho = p * rcp2(gas.R * T);
+    e = (gas.R / (gas.gamma - 1.0f)) * T + 0.5f * q;
+    un = dn ? P[3] : P[2];
+    a = sqrt2((gas.gamma * gas.R) * T);
+}
+
 // MUSCL states from undivided slopes, then HLL: F = (SL FL - SR FR + SL SR (QR - QL)) / (SL - SR) with FL = QL unL +
 // pressure terms, regrouped by state (as strip3e::euler_flux): F = QL (wL unL - c) + QR (c - wR unR) + pressure terms,
 // wL = SL / (SL - SR), wR = SR / (SL - SR), c = SL wR -- two instructions per variable instead of five, and the physical
@@ -71,20 +83,24 @@ __device__ __forceinline__ void euler_flux_w2(const v2f* Pa, const v2f* Pb, cons
         const v2f t16 = (Sa[v] - Sb[v]) * 0.0625f;
         const v2f uf = (Pa[v] + wa * d) + t16;
         PL[v] = uf + Df * ((s - wa * d) - t16);
-        PR[v] = uf + Df * ((wb * d - s) - t16);
+        // PR = uf + Df ((wb d - s) - t16) = PL + Df (d - 2 s)   (wa + wb = 1; round 4, as strip3e::euler_flux)
+        PR[v] = PL[v] + Df * (d - 2.0f * s);
     }
-    v2f QL[4], QR[4], pL, pR, uL, aL, uR, aR;
-    euler_state2(PL, dn, gas, QL, pL, uL, aL);
-    euler_state2(PR, dn, gas, QR, pR, uR, aR);
+    // with Q = rho (1, e, u, v) the conserved states are never formed: F = AL (1, eL, uL, vL) + AR (1, eR, uR, vR), A = rho c
+    v2f rL, eL, pL, uL, aL, rR, eR, pR, uR, aR;
+    euler_side_pm2(PL, dn, gas, rL, eL, pL, uL, aL);
+    euler_side_pm2(PR, dn, gas, rR, eR, pR, uR, aR);
     const v2f z = v2f{0.0f, 0.0f};
     const v2f SR = min2(uR - aR, z);
     const v2f SL = max2(uL + aL, z);
     const v2f rs = rcp2(SL - SR);
     const v2f wL = SL * rs, wR = SR * rs;
     const v2f c = SL * wR;
-    const v2f cL = wL * uL - c, cR = c - wR * uR;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) F[v] = QL[v] * cL + QR[v] * cR;
+    const v2f AL = rL * (wL * uL - c), AR = rR * (c - wR * uR);
+    F[0] = AL + AR;
+    F[1] = AL * eL + AR * eR;
+    F[2] = AL * PL[2] + AR * PR[2];
+    F[3] = AL * PL[3] + AR * PR[3];
     const v2f mL = wL * pL, mR = wR * pR;
     const v2f m = mL - mR;
     F[2] += dn ? z : m;

@@ -99,6 +99,9 @@ __device__ __forceinline__ void tr_read(const float* r, Col& c) {
 // reused quantity after quantity without waiting)
 template <int FROM, int TO>
 __device__ __forceinline__ void transpose(float* buf, int ta, int tb, Col& c) {
+#ifdef S3E_ABLATE_TRANSPOSE  // (timing diagnostic, wrong results)
+    return;
+#endif
     float* w = buf + TrMap<FROM, TO>::base(FROM, ta, tb);
     const float* r = buf + TrMap<FROM, TO>::base(TO, ta, tb);
     tr_write<FROM, TO>(w, c);
@@ -359,6 +362,12 @@ __device__ __forceinline__ void side_eval(const BlockDesc3& bb, const LaneGeo& L
     constexpr int d = S >> 1;
     constexpr bool low = (S & 1) == 0;
     constexpr int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+#ifdef S3E_ABLATE_SIDE  // (timing diagnostic, wrong results: no slope / sensor work for the halo cells)
+#pragma unroll
+    for (int v = 0; v < 5; ++v) Sh[v] = Sb[v] + hu[v] - hde[v];
+    Dh = Db + rv0;
+    return;
+#endif
     const int ty = bb.type[S];
     const float qs = bb.q[S];
 #ifdef S3E_COUNT_SAME_ONLY  // (instruction counts of the path without FINE / COARSE sides: scripts/isa_count.py)
@@ -795,6 +804,15 @@ __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ block
     Col Dc;
     {
         Col p = pz, N, Dn;
+#ifdef S3E_ABLATE_SENSOR  // (timing diagnostic, wrong results: no sensor passes)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            N.e[j] = p.e[j] * 1e-9f + hp[j];
+            Dn.e[j] = v2f{1.0f, 1.0f};
+        }
+        if (false)
+#endif
+        {
         sensor_pass<2, true>(bb, ftab, P, lane, hp[4], hp[5], p, N, Dn);
         transpose<2, 1>(buf, ta, tb, p);
         transpose<2, 1>(buf, ta, tb, N);
@@ -804,6 +822,7 @@ __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ block
         transpose<1, 0>(buf, ta, tb, N);
         transpose<1, 0>(buf, ta, tb, Dn);
         sensor_pass<0, false>(bb, ftab, P, lane, hp[0], hp[1], p, N, Dn);
+        }
 #pragma unroll
         for (int j = 1; j < 4; ++j)
             Dc.e[j] = v2f{fmaxf(N.e[j].x * __builtin_amdgcn_rcpf(Dn.e[j].x), 1e-7f),

@@ -318,6 +318,18 @@ __device__ __forceinline__ void euler_state(const float* P, int dn, const Gas& g
     a = __builtin_amdgcn_sqrtf(gas.gamma * gas.R * T);
 }
 
+// density, energy per mass, pressure, normal velocity and speed of sound of one side of a face (quad2::euler_side_pm2)
+__device__ __forceinline__ void euler_side_pm(const float* P, int dn, const Gas& gas, float& rho, float& e, float& p, float& un,
+                                              float& a) {
+    p = P[0];
+    const float T = fmaxf(P[1], 10.0f);
+    const float q = P[2] * P[2] + P[3] * P[3];
+    rho = p * __builtin_amdgcn_rcpf(gas.R * T);
+    e = (gas.R / (gas.gamma - 1.0f)) * T + 0.5f * q;
+    un = dn ? P[3] : P[2];
+    a = __builtin_amdgcn_sqrtf((gas.gamma * gas.R) * T);
+}
+
 // MUSCL states from undivided slopes (see flux_w), then the HLL flux of blk2::euler_flux
 __device__ __forceinline__ void euler_flux_w(const float* Pa, const float* Pb, const float* Sa, const float* Sb, float Da,
                                              float Db, float wa, int dn, const Gas& gas, float* F) {
@@ -333,21 +345,24 @@ __device__ __forceinline__ void euler_flux_w(const float* Pa, const float* Pb, c
         const float t16 = (Sa[v] - Sb[v]) * 0.0625f;
         const float uf = (Pa[v] + wa * d) + t16;
         PL[v] = uf + Df * ((s - wa * d) - t16);   // (Pa + s) - uf
-        PR[v] = uf + Df * ((wb * d - s) - t16);   // (Pb - s) - uf
+        PR[v] = PL[v] + Df * (d - 2.0f * s);      // uf + Df ((wb d - s) - t16) = PL + Df (d - 2 s)
     }
     // HLL regrouped by state, operation for operation what quad2::euler_flux_w2 does on pairs (ibh_quad2d_euler.h): a block
-    // gives the same bits whether a quad wave or a single-block wave sweeps it
-    float QL[4], QR[4], pL, pR, uL, aL, uR, aR;
-    euler_state(PL, dn, gas, QL, pL, uL, aL);
-    euler_state(PR, dn, gas, QR, pR, uR, aR);
+    // gives the same bits whether a quad wave or a single-block wave sweeps it.  Q = rho (1, e, u, v) is never formed:
+    // F = AL (1, eL, uL, vL) + AR (1, eR, uR, vR), A = rho c
+    float rL, eL, pL, uL, aL, rR, eR, pR, uR, aR;
+    euler_side_pm(PL, dn, gas, rL, eL, pL, uL, aL);
+    euler_side_pm(PR, dn, gas, rR, eR, pR, uR, aR);
     const float SR = fminf(uR - aR, 0.0f);
     const float SL = fmaxf(uL + aL, 0.0f);
     const float rs = __builtin_amdgcn_rcpf(SL - SR);
     const float wL = SL * rs, wR = SR * rs;
     const float c = SL * wR;
-    const float cL = wL * uL - c, cR = c - wR * uR;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) F[v] = QL[v] * cL + QR[v] * cR;
+    const float AL = rL * (wL * uL - c), AR = rR * (c - wR * uR);
+    F[0] = AL + AR;
+    F[1] = AL * eL + AR * eR;
+    F[2] = AL * PL[2] + AR * PR[2];
+    F[3] = AL * PL[3] + AR * PR[3];
     const float mL = wL * pL, mR = wR * pR;
     const float m = mL - mR;
     F[2] += dn ? 0.0f : m;

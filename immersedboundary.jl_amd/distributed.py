@@ -104,6 +104,7 @@ class LocalDomain:
         self.boundaries, self.n_rows = local_boundaries(dom, pid, self.extras)
         self.pid = pid
         self.nc = int(np.asarray(dom.domains[pid]).size)
+        self.ndims = dom.ndims
 
     def __len__(self):
         return self.n_rows
@@ -245,7 +246,11 @@ class RankLevels:
       all ranks at set-up.
 
     Same stencils and weights as the global operators (the interpolator is called on the same points with the same
-    trees), so a V-cycle over these reproduces the one-partition V-cycle on the owned cells."""
+    trees), so a V-cycle over these reproduces the one-partition V-cycle on the owned cells.
+
+    With boundaries (``domain_kwargs`` without ``boundaries=False``): ``local_doms[l]`` is the ``LocalDomain`` of level l --
+    its boundary chunks restricted to the ghosts the rank owns, re-indexed to local rows -- for ``impose_bc`` inside the
+    level closure; the BC donor cells beyond the skirt are part of the level's extra rows (one exchange refreshes all)."""
 
     def __init__(self, msh, pid, world, max_levels, factor=2, group=None, domain_kwargs=None):
         from scipy.spatial import cKDTree
@@ -300,10 +305,22 @@ class RankLevels:
             else:
                 every = [mine]
             tables.append({q + 1: np.asarray(every[q], dtype=np.int64) for q in range(world)})
+        # impose_bc! on every level's own boundaries (multigrid builds each coarse Domain with them, :1381-1382): the donor
+        # cells of the ghosts a rank owns that lie beyond its skirt join the level's extra rows and halo lists
+        self.local_doms = [None] * (max_levels + 1)
+        with_bc = bool(kw.get("boundaries", True)) and any(len(v) for d in self.doms for v in d.boundaries.values())
+        if with_bc:
+            for l in range(max_levels + 1):
+                bx = bc_donor_extras(self.doms[l])
+                tables[l] = {q: np.union1d(tables[l][q], bx.get(q, np.zeros(0, dtype=np.int64))).astype(np.int64)
+                             for q in tables[l]}
         for l in range(max_levels + 1):
             self.extras.append(tables[l])
             self.plans.append(HaloPlan(self.doms[l], pid, extra=tables[l]))
             self.nrows.append(int(self.parts[l].domain.size + tables[l][pid].size))
+            if with_bc:
+                self.local_doms[l] = LocalDomain(self.doms[l], pid, tables[l])
+                assert self.local_doms[l].n_rows == self.nrows[l]
         # local operators
         co_local, pr_local = [], []
         for l in range(max_levels):

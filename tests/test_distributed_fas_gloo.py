@@ -46,7 +46,15 @@ def _residual(od, opart, Q):
     return r, f32(0.2) * h * h
 
 
-def _worker(rank, world, port, out):
+def _bcs(od, view, Q):
+    """the boundary conditions of test/dissipation.jl:30-52 on a level's own boundaries (two-column field)"""
+    od.impose_bc(lambda b, a: np.broadcast_to(f32([1.0, 0.0]), a.shape).copy(), view, "upper", Q)
+    od.impose_bc(lambda b, a: np.broadcast_to(f32([0.0, 1.0]), a.shape).copy(), view, "lower", Q)
+    od.impose_bc(lambda b, a: a.copy(), view, "outlet", Q)
+
+
+def _worker(rank, world, port, out, with_bc=False):
+    from conftest import ADV_FAMILIES, oracle_boundaries_view
     from oracle import domain as od
     from oracle.solver import FAS as oFAS
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -55,8 +63,10 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         msh = advection_mesh(2e-2)
-        lv = RankLevels(msh, rank + 1, world, MAXLEV, domain_kwargs=dict(boundaries=False))
+        lv = RankLevels(msh, rank + 1, world, MAXLEV,
+                        domain_kwargs=dict(hypercube_families=ADV_FAMILIES) if with_bc else dict(boundaries=False))
         assert lv.n_levels == MAXLEV + 1
+        views = [oracle_boundaries_view(ld) for ld in lv.local_doms] if with_bc else None
         oparts = [oracle_view(p) for p in lv.parts]
         hxs = [HaloExchange(pl, "cpu") for pl in lv.plans]
         reds = [Reductions(p.image_in_domain) for p in lv.parts]
@@ -67,6 +77,11 @@ def _worker(rank, world, port, out):
             hxs[l].exchange(torch.from_numpy(Q))        # in place: skirt rows (and donor extras) of level l
 
         def f(l, Q):
+            if with_bc:
+                # impose_bc! on the ghosts this rank owns (the level's own boundaries, local rows), then the ghosts the
+                # peers own arrive with a second exchange: the sweep sees every ghost as the one-partition run does
+                _bcs(od, views[l], Q)
+                exchange(l, Q)
             r = np.zeros_like(Q)
             rr, om = _residual(od, oparts[l], Q[:ncs[l]])
             r[:ncs[l]] = rr
@@ -92,14 +107,19 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_vcycle_matches_the_one_partition_vcycle():
+import pytest
+
+
+@pytest.mark.parametrize("with_bc", [False, True], ids=["no_ghost_cells", "impose_bc_on_every_level"])
+def test_two_rank_vcycle_matches_the_one_partition_vcycle(with_bc):
+    from conftest import ADV_FAMILIES, oracle_boundaries_view
     from oracle import domain as od
     from oracle.solver import FAS as oFAS
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, with_bc)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -108,12 +128,16 @@ def test_two_rank_vcycle_matches_the_one_partition_vcycle():
         assert p.exitcode == 0
     # the one-partition run: global operators of the product's multigrid(), the oracle's loop and operators
     msh = advection_mesh(2e-2)
-    dom = ibamd.Domain(msh, max_partition_size=10 ** 9, boundaries=False)
+    dom = (ibamd.Domain(msh, max_partition_size=10 ** 9, hypercube_families=ADV_FAMILIES) if with_bc
+           else ibamd.Domain(msh, max_partition_size=10 ** 9, boundaries=False))
     cds, prol, coar = ibamd.multigrid(dom, max_levels=MAXLEV)
     oparts = [oracle_view(d.partitions[1]) for d in [dom] + cds]
+    gviews = [oracle_boundaries_view(d) for d in [dom] + cds] if with_bc else None
     norms_ref = []
 
     def f(l, Q):
+        if with_bc:
+            _bcs(od, gviews[l], Q)
         return _residual(od, oparts[l], Q)
 
     def norm(r):
