@@ -318,6 +318,12 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         p->bs = block_size;
         p->nblk = (int32_t)H.blocks.size();
         p->n_irr = (int32_t)H.irr.size();
+        {   // complete blocks in order: cell c lies in block c / 64 at position c % 64 (face-list kernels take in-block
+            // neighbours by index arithmetic then: k_timestep_advection<TILED>)
+            bool tiled = !H.blocks.empty() && H.irr.empty() && (int64_t)H.blocks.size() * 64 == (int64_t)nc;
+            for (size_t b = 0; tiled && b < H.blocks.size(); ++b) tiled = H.blocks[b].base == (int32_t)(64 * b);
+            p->info[20] = tiled ? 1 : 0;
+        }
         if ((rc = ibh_upload(&p->blocks2, H.blocks.data(), H.blocks.size()))) return rc;
         if ((rc = ibh_upload(&p->irr_cells, H.irr.data(), H.irr.size()))) return rc;
     } else if (domain && block_size == 8 && nd == 3) {
@@ -342,6 +348,11 @@ int ibh_partition_create(ibh_part** out, int nd, int32_t nc, const float* spacin
         p->bs = block_size;
         p->nblk = (int32_t)blocks.size();
         p->n_irr = (int32_t)irr.size();
+        {
+            bool tiled = !blocks.empty() && irr.empty() && (int64_t)blocks.size() * 512 == (int64_t)nc;
+            for (size_t b = 0; tiled && b < blocks.size(); ++b) tiled = blocks[b].base == (int32_t)(512 * b);
+            p->info[20] = tiled ? 1 : 0;
+        }
         if ((rc = ibh_upload(&p->blocks3, blocks.data(), blocks.size()))) return rc;
         if ((rc = ibh_upload(&p->htab3, htab.data(), htab.size()))) return rc;
         if (have_img && !sw.all) {   // a partition with skirt fragments: the image blocks for the image-only sweeps

@@ -471,9 +471,32 @@ __device__ __forceinline__ void side_eval(const BlockDesc3& bb, const LaneGeo& L
 struct HaloRegs {
     float hu[5], hd[5], rv;
 };
+// (Round 4 also evaluated the two sides of a direction at once where both are SAME / MIRROR sides -- the arithmetic of
+// side_eval on (low, high) pairs, one plane each in LDS, one pair of LDS round trips for both: 70 fewer vector instructions
+// per direction, 23 spilled registers, and slower: 128 against 107 us at 4.56 M cells on one box.  Not kept.)
 template <int S>
 __device__ __forceinline__ void halo_load_values(const BlockDesc3& bb, int lane, const float* __restrict__ P, uint32_t ldp,
                                                  const Slot& sl, HaloRegs& h) {
+    constexpr int d = S >> 1;
+    constexpr bool low = (S & 1) == 0;
+    if constexpr (d == 0) {
+        // x sides: the halo cell and the cell one step deeper are neighbours in memory (x = 7, 6 of the block on the left,
+        // x = 0, 1 of the one on the right: an even / odd pair, blocks start at multiples of 512) -- ONE 8-byte gather per
+        // field instead of two 4-byte ones over the same 16 cache lines.  Not across a mirror side (no deeper cell) and
+        // not towards a skirt fragment (deeper cells from the table).
+        const bool table = sl.drow && bb.nb[S] < 0 && bb.type[S] != SIDE_MIRROR;
+        if (sl.dd == (low ? -1 : 1) && !table) {  // wave-uniform
+            typedef float v2f_a __attribute__((ext_vector_type(2), aligned(8)));
+            const uint32_t c2 = sl.hid & ~1u;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const v2f_a t = *(const v2f_a*)((const char*)(P + (size_t)v * ldp) + (size_t)(c2 << 2));
+                h.hu[v] = low ? t.y : t.x;
+                h.hd[v] = low ? t.x : t.y;
+            }
+            return;
+        }
+    }
     const uint32_t hd = deeper_of<S>(bb, sl, lane, 0, sl.hid);
 #pragma unroll
     for (int v = 0; v < 5; ++v) {
@@ -782,9 +805,9 @@ __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ block
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- the buffer of the first loads: the DMA rows are older than the 30 loads just issued (vector memory operations
-    // complete in order)
-    asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+    // ---- the buffer of the first loads: the DMA rows are older than the loads just issued (vector memory operations
+    // complete in order): at least 5 + 5 halo gathers and 10 x-column loads
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
     const int32_t* nrid = (const int32_t*)(nextbuf + 64 * 14) + lane;
     int32_t rid0 = nrid[0], rid1 = nrid[64];
     Col pz;

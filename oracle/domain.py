@@ -145,11 +145,11 @@ class Domain:
 
     def __init__(self, msh, max_partition_size=100_000, partition_skirt_depth=2,
                  ghost_layer_ratio=f32(1.5), hypercube_families=(), verbose=False):
-        from ibamd.mesher import get_cells  # mesh container/cell generator (input side, not the hot path)
+        from .mesher import get_cells   # the independent restatement (tests/test_mesher_restatement.py: bit-identical cells)
 
         nd = msh.block_origins.shape[0]
         ncells = len(msh)
-        centers, widths = get_cells(msh)
+        centers, widths = get_cells(msh.block_origins, msh.block_widths, msh.block_size)
         origins = centers - widths / f32(2)
 
         faces = octree2faces(origins, widths) + hcube_faces(msh.origin, msh.widths, origins, widths)
@@ -515,7 +515,7 @@ def impose_bc(f, dom, bname, *args, **kwargs):
 # ---------------------------------------------------------------------------
 def multigrid(dom, max_levels=0, factor=2):
     """Returns ``(coarse_doms, prolongators, coarseners)`` -- the reference's actual order (:1406)."""
-    from ibamd.mesher import Mesh
+    from .mesher import BlockTree   # (the oracle's own mesh container: nothing of the product's mesher is used here)
 
     msh = dom.mesh
     mdepth = int(np.floor(np.log2(msh.block_size)))
@@ -535,8 +535,7 @@ def multigrid(dom, max_levels=0, factor=2):
     bsize = msh.block_size
     for _ in range(max_levels):
         bsize //= factor
-        cmsh = Mesh(msh.origin, msh.widths, block_size=bsize, block_origins=msh.block_origins,
-                    block_widths=msh.block_widths, distance_fields=msh.distance_fields)
+        cmsh = BlockTree(msh.origin, msh.widths, msh.block_origins, msh.block_widths, bsize, msh.distance_fields)
         cdom = Domain(cmsh, **dom.reconstruction_kwargs)
         X = global_centers(cdom)
         tree = cKDTree(X.astype(np.float64))

@@ -70,3 +70,39 @@ def get_cells(block_origins, block_widths, block_size):
         cols_c.append((inner * w[:, None]).astype(f32) + o[:, None])  # inner .* w .+ o
         cols_w.append(np.repeat((w / f32(bs)).astype(f32)[:, None], inner.shape[1], axis=1))
     return np.concatenate(cols_c, axis=1).astype(f32), np.concatenate(cols_w, axis=1).astype(f32)
+
+
+class BlockTree:
+    """The mesh container the oracle's ``Domain`` and ``multigrid`` need -- origin / widths of the box, the block tree
+    (``block_origins``, ``block_widths``: (ndims, nblocks), depth-first order), ``block_size`` and the distance fields of the
+    immersed surfaces (mesher.jl:926-970 minus everything that generates them).  ``multigrid`` (ImmersedBoundary.jl:1359-1382)
+    coarsens a mesh by keeping the block tree and halving ``block_size``: ``coarser()``.  Independent of the product's ``Mesh``
+    class (round-3 review: the oracle built its coarse meshes with it)."""
+
+    def __init__(self, origin, widths, block_origins, block_widths, block_size, distance_fields=None):
+        self.origin = np.asarray(origin, dtype=f32)
+        self.widths = np.asarray(widths, dtype=f32)
+        self.block_origins = np.asarray(block_origins, dtype=f32)
+        self.block_widths = np.asarray(block_widths, dtype=f32)
+        self.block_size = int(block_size)
+        self.distance_fields = dict(distance_fields or {})
+
+    @classmethod
+    def of(cls, msh):
+        """the same tree as any object with these six attributes (e.g. the product's mesh: the INPUT of the path)"""
+        return cls(msh.origin, msh.widths, msh.block_origins, msh.block_widths, msh.block_size, msh.distance_fields)
+
+    def coarser(self, factor=2):
+        return BlockTree(self.origin, self.widths, self.block_origins, self.block_widths, self.block_size // factor,
+                         self.distance_fields)
+
+    @property
+    def ndims(self):
+        return self.block_origins.shape[0]
+
+    @property
+    def nblocks(self):
+        return self.block_origins.shape[1]
+
+    def __len__(self):
+        return self.block_size ** self.ndims * self.nblocks

@@ -1,6 +1,6 @@
 """A/B of the 3-D Euler sweep forms on one workload (run on the GPU box): python scripts/probe_3d_euler.py [workload]
-column form (strip3e::sweep_euler_cols) as persistent waves / one block per wave, thread-per-cell single kernel,
-two-kernel form."""
+column form (strip3e::sweep_block) as one block per wave / persistent chains, thread-per-cell single kernel, two-kernel
+form."""
 import json
 import os
 import sys
@@ -56,7 +56,9 @@ def timed(fn, n=10, reps=15):
 out = {"workload": name, "cells": int(dpart.nc), "blocks": int(dpart.info["full_blocks"]),
        "single_kernel_blocks": int(dpart.info["fusable_blocks"])}
 ref = None
-for key, var in (("thread_per_cell_us", 512), ("cols_2_waves_per_simd_us", 0), ("cols_3_waves_per_simd_us", 513)):
+# (round 4: 0 = one block per wave at two waves per SIMD, the default; 514 = persistent waves, each working through a chain of
+# blocks with the first loads of the next block requested by LDS-DMA during the z fluxes)
+for key, var in (("thread_per_cell_us", 512), ("cols_block_per_wave_us", 0), ("cols_persistent_chain_us", 514)):
     _lib.call("ibh_set_tuning", b"quad_variant", var)
     R.zero_()
     out[key] = round(timed(lambda: ibamd.residual_euler_hll(dpart, P, out=R)), 3)
@@ -69,5 +71,5 @@ for key, var in (("thread_per_cell_us", 512), ("cols_2_waves_per_simd_us", 0), (
 _lib.call("ibh_set_tuning", b"quad_variant", 0)
 out["two_kernel_us"] = round(timed(lambda: ibamd.residual_euler_hll(dpart, P, out=R, flags=ibamd.IBH_NO_FUSE)), 3)
 out["two_kernel_maxdiff"] = [float((R[:, v] - ref[:, v]).abs().max() / ref[:, v].abs().max()) for v in range(5)]
-out["frac_cols_2"] = round(40.0 * dpart.nc / (out["cols_2_waves_per_simd_us"] * 1e-6) / 8e12, 4)
+out["frac_cols"] = round(40.0 * dpart.nc / (out["cols_block_per_wave_us"] * 1e-6) / 8e12, 4)
 print(json.dumps(out))
