@@ -70,6 +70,12 @@ def icosphere(radius=1.0, subdiv=3):
     return Stereolitography(v.T.astype(np.float32), (f.T + 1).astype(np.int64))
 
 
+# Hutchinson samples per variable of the point-implicit lines (the reference's default is 30, point_implicit.jl:185-209).
+# With ONE sample the block estimate of a few cells is so poor that the preconditioned direction drives their temperature
+# negative in the finite-difference product and the solve returns NaN (rounds 2-3 reported that NaN at 7.9 M cells).
+PI_SAMPLES = 8
+
+
 def build_mesh(name):
     import ibamd
     from ibamd.mesher import DistanceField, Mesh, Stereolitography, feature_regions, merge_points
@@ -917,7 +923,7 @@ def main():
         f_pi = ops4.closure(f_pi_local)
         barrier()
         t0 = time.perf_counter()
-        lin, bb, prec = pi.linearize(f_pi, P4, 1, h=1e-2, seed=1 + rank)
+        lin, bb, prec = pi.linearize(f_pi, P4, PI_SAMPLES, h=1e-2, seed=1 + rank)
         barrier()
         t1 = time.perf_counter()
         _, ratio = pi.solve(lin, bb, prec, n_iter=1, rtol=1e-9, reduce=ops4)
@@ -926,8 +932,8 @@ def main():
         out["config"]["step"]["point_implicit"] = {
             "linearize_ms": round((t1 - t0) * 1e3, 2), "solve_1_iteration_ms": round((t2 - t1) * 1e3, 2),
             "residual_ratio": round(float(ratio), 4),
-            "what": "pseudo-time step (P - P0)/dt - R(P) across the ranks: Hutchinson block estimate with 1 sample per "
-                    "variable (6 exchanges + sweeps), one two-direction relaxation (2 exchanges + sweeps, 2 x 2 all-reduced "
+            "what": f"pseudo-time step (P - P0)/dt - R(P) across the ranks: Hutchinson block estimate with {PI_SAMPLES} samples per "
+                    f"variable ({5 * PI_SAMPLES + 1} exchanges + sweeps), one two-direction relaxation (2 exchanges + sweeps, 2 x 2 all-reduced "
                     "dot products, max |r| and the norm all-reduced)"}
     if config4 and world == 1:
         from ibamd import point_implicit as pi
@@ -939,7 +945,7 @@ def main():
             return ((H(X) - H(P0)) / dtp - H(ibamd.residual_euler_hll(dpart, X))).t
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        lin, bb, prec = pi.linearize(f_pi, P, 1, h=1e-2, seed=1)
+        lin, bb, prec = pi.linearize(f_pi, P, PI_SAMPLES, h=1e-2, seed=1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         _, ratio = pi.solve(lin, bb, prec, n_iter=1, rtol=1e-9)
@@ -953,8 +959,9 @@ def main():
                                                     "residual_ratio": round(float(ratio), 4),
                                                     "residual_finite": bool(torch.isfinite(Rres).all().item()),
                                                     "what": "pseudo-time step (P - P0)/dt - R(P), Hutchinson block "
-                                                            "estimate with 1 sample per variable (6 sweeps), one two-"
-                                                            "direction relaxation (2 sweeps)"}}
+                                                            f"estimate with {PI_SAMPLES} samples per variable "
+                                                            f"({5 * PI_SAMPLES + 1} sweeps), one two-direction relaxation "
+                                                            "(2 sweeps)"}}
     if march:
         out["metric"] = "Mcells*steps/s, explicit march (device dt + sweep and update in one launch + BC set), 2D RAE2822"
         out["config"]["step"] = {"ghost_cells": int(bcs_m.n_ghost), "bc_set_levels": int(bcs_m.n_levels), "bc_set_levels_in_one_launch": int(bcs_m.n_direct_levels),

@@ -512,6 +512,10 @@ __device__ __forceinline__ void halo_load(const BlockDesc3& bb, int lane, const 
     h.rv = ldg(P, (uint32_t)(rid >= 0 ? rid : bb.base));
 }
 
+// r += v in LDS: read, add, write.  (Round 4 tried ds_add_f32 -- one LDS instruction, no wait for the read -- for the ~50
+// accumulations of a pass: the sweep took 264 us instead of 107 at 4.56 M cells; LDS float atomics are that slow here.)
+__device__ __forceinline__ void lds_add(float* r, float v) { *r = *r + v; }
+
 // residual in LDS: A = x + 9 y + 72 z (x- and y-columns free of bank conflicts, z-columns two-way)
 template <int D>
 __device__ __forceinline__ int rbase(int ta, int tb) {
@@ -548,11 +552,15 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const int32_t* _
     float* const Rl = lds + S3E_R + rbase<D>(lane & 7, lane >> 3);
     // cell I of the column: R (op) -(Fhi - Flo) / h; `pre`: the cell already holds the flux of a FINE side (MODE 0)
     auto put = [&](int v, int i, float dF, bool pre = false) {
+#ifdef S3E_ABLATE_R  // (timing diagnostic, wrong results: no residual accumulation in LDS)
+        if constexpr (MODE == 2) Rr[(size_t)v * ldr + (uint32_t)bb.base + lane + 64 * i] = dF * rh;
+        return;
+#endif
         float* r = Rl + v * 576 + rstride<D>() * i;
         if constexpr (MODE == 0) {
-            if (pre) *r = *r - dF * rh;  // wave-uniform
+            if (pre) lds_add(r, -(dF * rh));  // wave-uniform
             else *r = -(dF * rh);
-        } else if constexpr (MODE == 1) *r = *r - dF * rh;
+        } else if constexpr (MODE == 1) lds_add(r, -(dF * rh));
         else Rr[(size_t)v * ldr + (uint32_t)bb.base + lane + 64 * i] = *r - dF * rh;
     };
     // ---- face 4 (between cells 3 and 4) first, straight into the residual of its two cells (nothing of it is held
@@ -569,6 +577,7 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const int32_t* _
             Sbb[v] = 0.5f * (p.e[1].y - p.e[0].y) + 0.5f * d4;
         }
         euler_flux<float, D>(Pa, Pbb, Sa, Sbb, Dc.e[4].x, Dc.e[0].y, 0.5f, gas, F4);
+#ifndef S3E_ABLATE_R
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
             float* r3 = Rl + v * 576 + rstride<D>() * 3;
@@ -578,10 +587,13 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const int32_t* _
                 *r3 = -f;
                 *r4 = f;
             } else {
-                *r3 = *r3 - f;
-                *r4 = *r4 + f;
+                lds_add(r3, -f);
+                lds_add(r4, f);
             }
         }
+#else
+        Dc.e[4].x += F4[0] + F4[1] + F4[2] + F4[3] + F4[4];
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     const LaneGeo LG = lane_geo(lane);
@@ -630,7 +642,7 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const int32_t* _
             for (int v = 0; v < 5; ++v) {
                 float* r = Rl + v * 576;
                 if constexpr (MODE == 0) *r = Ff[v] * rh;
-                else *r = *r + Ff[v] * rh;
+                else lds_add(r, Ff[v] * rh);
             }
         }
         float Sh1[5];
@@ -647,7 +659,7 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const int32_t* _
             for (int v = 0; v < 5; ++v) {
                 float* r = Rl + v * 576 + rstride<D>() * 7;
                 if constexpr (MODE == 0) *r = -(Ff[v] * rh);
-                else *r = *r - Ff[v] * rh;
+                else lds_add(r, -(Ff[v] * rh));
             }
         }
         wave_lds_sync();  // (the plane of the side is read by other lanes)
