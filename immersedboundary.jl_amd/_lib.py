@@ -103,7 +103,7 @@ _SIGS = {
     "ibh_cfd_shock_sensor": [c_int, c_i64, C.POINTER(c_vp), c_vp],
     "ibh_cfd_viscous_fluxes": [C.POINTER(ibh_fluid), c_int, c_int, c_i64, c_vp, c_i64, C.POINTER(c_vp), c_i64, c_vp,
                                C.c_float, c_vp, c_i64],
-    "ibh_viscous_residual": [c_vp, C.POINTER(ibh_fluid), c_vp, c_i64, C.POINTER(c_vp), c_i64, c_vp, c_vp, c_i64],
+    "ibh_viscous_residual": [c_vp, C.POINTER(ibh_fluid), c_vp, c_i64, C.POINTER(c_vp), c_i64, c_int, c_vp, c_vp, c_i64],
     "ibh_cfd_flow_bc": [C.POINTER(ibh_fluid), c_int, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_float, C.c_float, c_vp, c_int,
                         c_vp, c_vp, C.c_float, c_vp, c_vp, c_i64],
     "ibh_ipc_alloc": [C.POINTER(c_vp), C.c_size_t, c_int],

@@ -160,11 +160,13 @@ def viscous_fluxes(fluid, P, Pgrad, dim, mu_t=0.0):
     return F
 
 
-def viscous_residual(part, fluid, P, Pgrad, mu_t, R):
+def viscous_residual(part, fluid, P, Pgrad, mu_t, R, velocity_gradients_only=False):
     """``R[:, 1:] .+= sum_d green_gauss(part, viscous_fluxes(fluid, at_faces(part, P, d), face_gradient(part, P, Pgrad, d), d;
     mu_t = at_faces(part, mu_t, d)), d)`` in ONE launch (``ibh_viscous_residual``), bit-identical to that composition
-    (cfd.jl:664-736 over ImmersedBoundary.jl:899-926, 1039-1069).  ``Pgrad`` = the tuple ``cell_gradient(part, P)``,
-    ``mu_t`` a cell array, ``R`` the (nc, nd + 2) residual updated in place."""
+    (cfd.jl:664-736 over ImmersedBoundary.jl:899-926, 1039-1069).  ``Pgrad`` = the tuple ``cell_gradient(part, P)`` -- or, with
+    ``velocity_gradients_only``, ``cell_gradient(part, P[:, 3:end])``: the viscous fluxes read the gradients of the velocities
+    and the NORMAL derivative of T only, which is a ``face_gradient`` --, ``mu_t`` a cell array, ``R`` the (nc, nd + 2)
+    residual updated in place."""
     part = B._part(part)
     P, _, ldp = B._field(P, part.nc)
     nd = _nd(P)
@@ -182,7 +184,8 @@ def viscous_residual(part, fluid, P, Pgrad, mu_t, R):
         raise ValueError("R must be (nc, nd + 2)")
     f = fluid._c()
     B._stream()
-    B.call("ibh_viscous_residual", part.handle, C.byref(f), B._ptr(P), ldp, ptrs, int(ldg.pop()), B._ptr(mt), B._ptr(R), ldr)
+    B.call("ibh_viscous_residual", part.handle, C.byref(f), B._ptr(P), ldp, ptrs, int(ldg.pop()),
+           0 if velocity_gradients_only else 2, B._ptr(mt), B._ptr(R), ldr)
     return R
 
 

@@ -85,11 +85,13 @@ def navier_stokes_wray_agarwal_residual(part, Q, nu=1.5e-5, fluid=None, out=None
     T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"], out=r[:, nvp])
     from .hiparray import HipArray
     mut = (HipArray(Q[:, 0]) / (HipArray(Q[:, 1]) * fluid.R) * HipArray(wa["nut"])).t   # mu_t = rho nu_t, one launch
-    gP = B.cell_gradient(part, P)                                     # tuple over the dimensions of (nc, nd + 2)
     if fused_viscous:
-        # sum_d green_gauss(viscous_fluxes(at_faces(P), face_gradient(P, gP, d), d; mu_t = at_faces(mu_t)), d) in one launch
-        cfd.viscous_residual(part, fluid, P, gP, mut, r[:, :nvp])
+        # sum_d green_gauss(viscous_fluxes(at_faces(P), face_gradient(P, gP, d), d; mu_t = at_faces(mu_t)), d) in one launch;
+        # of cell_gradient(part, P) it reads the velocity columns only (the gradients of p and T are not formed)
+        gV = B.cell_gradient(part, Q[:, 2:2 + nd])
+        cfd.viscous_residual(part, fluid, P, gV, mut, r[:, :nvp], velocity_gradients_only=True)
         return r
+    gP = B.cell_gradient(part, P)                                     # tuple over the dimensions of (nc, nd + 2)
     for d in range(1, nd + 1):
         Fv = cfd.viscous_fluxes(fluid, B.at_faces(part, P, d), B.face_gradient(part, P, gP, d), d,
                                 mu_t=B.at_faces(part, mut.contiguous(), d))

@@ -169,7 +169,8 @@ template <int ND>
 struct ViscDims {
     DimData d[ND];
     const float* h[ND];
-    const float* g[ND];       // cell gradients of P along each axis, (nc, ND + 2) column-major, leading dimension ldg
+    const float* g[ND];       // cell gradients along each axis, column-major with leading dimension ldg; u_a in column gcol + a
+    int gcol;                 // 2: gradients of P = [p T u v (w)]; 0: gradients of the velocity columns only
     const int32_t* side;
 };
 __device__ __forceinline__ float v_face_avg(float uo, float un, float ho, float hn) { return (uo * hn + un * ho) / (hn + ho); }
@@ -189,7 +190,7 @@ __device__ __forceinline__ void visc_flux_on(const ibh_fluid& f, const ViscDims<
 #pragma unroll
         for (int b = 0; b < ND; ++b)                                     // vel_grad(a, b) = Pgrad[b][:, 2 + a]
             vg[a][b] = b == D0 ? (un - uo) / fd                          // face_gradient(part, P, dim)
-                               : v_face_avg(V.g[b][o + (2 + a) * ldg], V.g[b][n + (2 + a) * ldg], ho, hn);  // at_faces(grad_b P)
+                               : v_face_avg(V.g[b][o + (V.gcol + a) * ldg], V.g[b][n + (V.gcol + a) * ldg], ho, hn);  // at_faces(grad_b P)
     }
     const float gT = (P[n + ldp] - P[o + ldp]) / fd;                     // Pgrad[dim][:, 2]
     const float mu = sutherland(f, T) + v_face_avg(mut[o], mut[n], ho, hn);
@@ -436,8 +437,9 @@ int ibh_cfd_viscous_fluxes(const ibh_fluid* f, int nd, int dim, int64_t n, const
 }
 
 int ibh_viscous_residual(const ibh_part* p, const ibh_fluid* f, const float* P, int64_t ldp, const float* const* Pgrad,
-                         int64_t ldg, const float* mu_t, float* R, int64_t ldr) {
+                         int64_t ldg, int grad_vel_col, const float* mu_t, float* R, int64_t ldr) {
     IBH_REQUIRE(p && f && P && Pgrad && mu_t && R && (p->nd == 2 || p->nd == 3), "ibh_viscous_residual: bad argument");
+    IBH_REQUIRE(grad_vel_col == 0 || grad_vel_col == 2, "ibh_viscous_residual: grad_vel_col is 2 (gradients of P) or 0 (of the velocities)");
     IBH_REQUIRE(f->nk >= 0 && f->nk <= 4, "ibh_cfd: nk out of range");
     IBH_REQUIRE(p->side, "ibh_viscous_residual: the partition has no side table");
     if (p->nc == 0) return 0;
@@ -450,6 +452,7 @@ int ibh_viscous_residual(const ibh_part* p, const ibh_fluid* f, const float* P, 
             V.g[d] = Pgrad[d];
         }
         V.side = p->side;
+        V.gcol = grad_vel_col;
         hipLaunchKernelGGL(k_viscous_residual<2>, grid1(p->nc), dim3(CFD_BLOCK), 0, ibh_stream, *f, p->nc, V, P, ldp, ldg,
                            mu_t, R, ldr);
     } else {
@@ -461,6 +464,7 @@ int ibh_viscous_residual(const ibh_part* p, const ibh_fluid* f, const float* P, 
             V.g[d] = Pgrad[d];
         }
         V.side = p->side;
+        V.gcol = grad_vel_col;
         hipLaunchKernelGGL(k_viscous_residual<3>, grid1(p->nc), dim3(CFD_BLOCK), 0, ibh_stream, *f, p->nc, V, P, ldp, ldg,
                            mu_t, R, ldr);
     }

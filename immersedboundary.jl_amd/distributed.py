@@ -173,11 +173,17 @@ class RankOps(Reductions):
         m[np.asarray(image_in_domain, dtype=np.int64)] = 1.0
         self.mask_np = m
         self.mask = self.torch.from_numpy(m).to(self.device)
+        self.not_own_np = m == 0
+        self.not_own = self.torch.from_numpy(self.not_own_np).to(self.device)
 
     def own(self, a):
+        """``a`` with the rows this rank does not own set to zero -- assigned, not multiplied: an image-only sweep leaves
+        whatever was in memory (possibly NaN) on the skirt rows of its output."""
         if isinstance(a, np.ndarray):
-            return a * (self.mask_np if a.ndim == 1 else self.mask_np[:, None])
-        a *= (self.mask if a.ndim == 1 else self.mask[:, None])
+            a = a.copy()
+            a[self.not_own_np] = 0
+            return a
+        a[self.not_own] = 0
         return a
 
     def closure(self, f_local):

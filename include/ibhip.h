@@ -295,9 +295,11 @@ int ibh_cfd_viscous_fluxes(const ibh_fluid*, int nd, int dim, int64_t n, const f
  *                                                          mu_t = at_faces(part, mu_t, d)), d)
  * (cfd.jl:664-736 over ImmersedBoundary.jl:899-926, 1039-1069; R[:, 1] gets the zero mass flux: untouched), operation by
  * operation in the composition's order: bit-identical to the twenty-odd operator launches per dimension it replaces.
- * Pgrad[d] = cell_gradient(part, P, d + 1), (nc, nd + 2) column-major with leading dimension ldg; mu_t: nc values (cells). */
+ * Pgrad[d] = cell_gradient(part, P, d + 1), (nc, nd + 2) column-major with leading dimension ldg (grad_vel_col = 2), or the
+ * gradients of the velocity columns only, (nc, nd) (grad_vel_col = 0: the gradients of p and T are not read -- the normal
+ * derivative of T at a face is a face_gradient); mu_t: nc values (cells). */
 int ibh_viscous_residual(const ibh_part*, const ibh_fluid*, const float* P, int64_t ldp, const float* const* Pgrad,
-                         int64_t ldg, const float* mu_t, float* R, int64_t ldr);
+                         int64_t ldg, int grad_vel_col, const float* mu_t, float* R, int64_t ldr);
 
 /* ---- direct peer halo exchange over xGMI ("or direct peer ... IPC writes") -------
  * Building blocks; the orchestration (who writes where) is host-side (halo.py / the Julia shim):

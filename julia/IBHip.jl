@@ -713,8 +713,8 @@ function viscous_residual!(R::HipArray{Float32, 2}, part::HipPartition, fluid::C
     g = Ptr{Cvoid}[x.ptr for x in ∇P]
     GC.@preserve g ∇P begin
         check(ccall((:ibh_viscous_residual, lib), Cint,
-            (Ptr{Cvoid}, Ptr{IbhFluid}, Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
-            part.handle, f, P.ptr, ld(P), g, ld(∇P[1]), μₜ.ptr, R.ptr, ld(R)))
+            (Ptr{Cvoid}, Ptr{IbhFluid}, Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+            part.handle, f, P.ptr, ld(P), g, ld(∇P[1]), size(∇P[1], 2) == size(P, 2) ? 2 : 0, μₜ.ptr, R.ptr, ld(R)))
     end
     R
 end

@@ -44,8 +44,8 @@ for tag, workload, kernel, match in (("28M", "rae2822_28M", "k_sweep_quad", "k_s
                             "averages, KB; FETCH_SIZE x2 on gfx950)" % (P, tag)})
 for e in E:
     if "kernel_trace_avg_us" not in e:
-        print(e["workload"], e["kernel"], round((2 * e["fetch_kb"] + e["write_kb"]) / 1024, 1), "MB")
+        print(e["workload"], e["kernel"], round((2 * e["fetch_kb"] + e["write_kb"]) * 1024 / 1e6, 1), "MB (1e6 bytes)")
         continue
-    print(e["workload"], e["kernel"], e["kernel_trace_avg_us"], "us", round((2 * e["fetch_kb"] + e["write_kb"]) / 1024, 1), "MB",
+    print(e["workload"], e["kernel"], e["kernel_trace_avg_us"], "us", round((2 * e["fetch_kb"] + e["write_kb"]) * 1024 / 1e6, 1), "MB (1e6 bytes)",
           e["valu_insts_per_wave"], e["valu_busy_frac"], e["wave_wait_frac"])
 json.dump({"entries": E}, open(os.path.join(ROOT, "profiles", "current_pmc.json"), "w"), indent=1)

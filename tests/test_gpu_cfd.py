@@ -154,3 +154,6 @@ def test_viscous_residual_is_the_operator_composition(rae_domains):
         gcfd.viscous_residual(dpart, fluid, P, gP, mut, got)
         assert not torch.equal(got, R0)
         assert torch.equal(got, ref), float((got - ref).abs().max())
+        got2 = R0.clone()                       # the same from the gradients of the velocity columns alone
+        gcfd.viscous_residual(dpart, fluid, P, ibamd.cell_gradient(dpart, P[:, 2:]), mut, got2, velocity_gradients_only=True)
+        assert torch.equal(got2, ref)
