@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(64 * WPB3E) __attribute__((amdgpu_waves_per_eu(WAVE
     const int32_t* __restrict__ rtab, const int32_t* __restrict__ r4tab, int32_t n, int32_t nwg,
     const int32_t* __restrict__ dtab = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[WPB3E * S3E_LDS];
-    __shared__ __attribute__((aligned(16))) float nextbuf[WPB3E * S3E_NEXT];  // (an array of its own: the LDS-DMA rows)
+    __shared__ __attribute__((aligned(16))) float nextbuf[PERSIST ? WPB3E * S3E_NEXT : 1];  // (the LDS-DMA rows)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int32_t first, stride, end;
     if constexpr (PERSIST) {
@@ -1024,8 +1024,8 @@ __global__ __launch_bounds__(64 * WPB3E) __attribute__((amdgpu_waves_per_eu(WAVE
         stride = n;
         end = n;
     }
-    strip3e::sweep_euler_chain<STAMP>(blocks, htab, ftab, rtab, r4tab, first, stride, end, P, ldp, R, ldr,
-                                      blk3::Gas3{Rgas, gamma}, lds + wave * S3E_LDS, nextbuf + wave * S3E_NEXT, lane,
+    strip3e::sweep_euler_chain<STAMP, PERSIST>(blocks, htab, ftab, rtab, r4tab, first, stride, end, P, ldp, R, ldr,
+                                      blk3::Gas3{Rgas, gamma}, lds + wave * S3E_LDS, nextbuf + (PERSIST ? wave * S3E_NEXT : 0), lane,
                                       STAMP ? ibh_dbg_buf : nullptr,
                                       TAB ? dtab : nullptr);
 }

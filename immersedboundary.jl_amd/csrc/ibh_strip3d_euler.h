@@ -414,12 +414,17 @@ __device__ __forceinline__ void side_eval(const BlockDesc3& bb, const LaneGeo& L
             Dh = slot_sensor<true>(pl, pA, hu[0], hde[0], Pb[0], m1, m2, m3, la, ha, lb, hb, t1 <= 1, t1 >= 6, t2 <= 1,
                                    t2 >= 6, t1, t2, 8, rn, ra, rb);
         }
+        if (mirror) {  // wave-uniform (domain boundary): the halo cell is the boundary cell itself
 #pragma unroll
-        for (int v = 0; v < 5; ++v) {
-            const float x = (1.0f - qs) * (mean[v] - hu[v]) - 0.5f * (hde[v] - hu[v]);
-            Sh[v] = mirror ? Sb[v] : (low ? x : -x);
+            for (int v = 0; v < 5; ++v) Sh[v] = Sb[v];
+            Dh = Db;
+        } else {
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const float x = (1.0f - qs) * (mean[v] - hu[v]) - 0.5f * (hde[v] - hu[v]);
+                Sh[v] = low ? x : -x;
+            }
         }
-        Dh = mirror ? Db : Dh;
     } else {  // the 2 x 2 finer cells behind this boundary cell, one after the other (rolled loop)
         const int32_t* ft = ftab + (((size_t)bb.fine * 6 + S) * 64 + lane) * 3;
         pl[(2 * t1 + 1) + 18 * (2 * t2 + 1)] = hu[0];
@@ -637,7 +642,7 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const int32_t* _
         }
         side_eval<S0>(bb, LG, ftab, r4tab, P, ldp, lds, lane, sl0, h0.hu, h0.hd, rid0, h0.rv, Pb, Sb, Dc.e[1].x, gas, Sh0,
                       Dh0, Ff);
-        if (isF0) {  // cell 0: R -= (F1 - Ff) / h
+        if (isF0) {  // cell 0: R -= (F1 - Ff) / h  (the packed value of face 0 is taken out again in the flux loop)
 #pragma unroll
             for (int v = 0; v < 5; ++v) {
                 float* r = Rl + v * 576;
@@ -713,8 +718,8 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const int32_t* _
         euler_flux<v2f, D>(Pa, Pbb, Sc, Sn, Dc.e[j], Dc.e[j + 1], wa, gas, F);
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
-            if (j == 0 && isF0) F[v].x = 0.0f;
-            if (j == 3 && isF1) F[v].y = 0.0f;
+            if (j == 0 && isF0) lds_add(Rl + v * 576, -(F[v].x * rh));                        // wave-uniform, rare
+            if (j == 3 && isF1) lds_add(Rl + v * 576 + rstride<D>() * 7, F[v].y * rh);
             if (j == 0) {
                 put(v, 4, F[v].y, true);  // cell 4: faces 4 (in R already) and 5
             } else {                      // cells (j - 1, j + 4)
@@ -779,7 +784,7 @@ __device__ __forceinline__ void request_first(const BlockDesc3* __restrict__ blo
 // (called in the z pass, when the buffer has long been read).
 // STAMP: phase time stamps of the wave (100 MHz ticks) for scripts/wave_timeline_3d.py: 0 start, 1 first loads landed,
 // 2 sensor done, 3 x fluxes, 4 transposed, 5 y fluxes, 6 transposed, 7 end
-template <bool STAMP, class Next>
+template <bool STAMP, bool DMA, class Next>
 __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
                                             const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
                                             const int32_t* __restrict__ r4tab, int32_t blk, const float* __restrict__ P,
@@ -798,6 +803,28 @@ __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ block
     const BlockDesc3 bb = blocks[blk];
     const int ta = lane & 7, tb = lane >> 3;
     float* buf = lds + S3E_BUF;
+    // ---- DMA = false (one block per wave: nothing to prefetch for): the first loads of the block -- rim ids, the pressure
+    // as z-columns, the halo pressures -- as plain loads, ahead of everything else (the LDS-DMA form costs ~100 vector and
+    // ~400 scalar instructions of address and M0 handling per block)
+    int32_t ridk[6] = {0, 0, 0, 0, 0, 0};
+    Col pz;
+    float hp[6];
+    if constexpr (!DMA) {
+        uint32_t hid[6];
+        hid[0] = halo_cell3s<0>(bb, htab, blk, lane);
+        hid[1] = halo_cell3s<1>(bb, htab, blk, lane);
+        hid[2] = halo_cell3s<2>(bb, htab, blk, lane);
+        hid[3] = halo_cell3s<3>(bb, htab, blk, lane);
+        hid[4] = halo_cell3s<4>(bb, htab, blk, lane);
+        hid[5] = halo_cell3s<5>(bb, htab, blk, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) ridk[s] = rtab[(size_t)blk * 384 + s * 64 + lane];
+        load_zcol(P + (uint32_t)bb.base + lane, pz);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) hp[s] = ldg(P, hid[s]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- the halo values of the x sides and the five primitives as x-columns (two float4 per field): requested now, in
     // flight during the sensor
     HaloRegs h0, h1;
@@ -819,17 +846,20 @@ __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ block
     __builtin_amdgcn_sched_barrier(0);
     // ---- the buffer of the first loads: the DMA rows are older than the loads just issued (vector memory operations
     // complete in order): at least 5 + 5 halo gathers and 10 x-column loads
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    const int32_t* nrid = (const int32_t*)(nextbuf + 64 * 14) + lane;
-    int32_t rid0 = nrid[0], rid1 = nrid[64];
-    Col pz;
-    float hp[6];
-    {
+    int32_t rid0, rid1;
+    if constexpr (DMA) {
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        const int32_t* nrid = (const int32_t*)(nextbuf + 64 * 14) + lane;
+        rid0 = nrid[0];
+        rid1 = nrid[64];
         const float* np_ = nextbuf + lane;
         set_cell<0>(pz, np_[0]); set_cell<1>(pz, np_[64]); set_cell<2>(pz, np_[128]); set_cell<3>(pz, np_[192]);
         set_cell<4>(pz, np_[256]); set_cell<5>(pz, np_[320]); set_cell<6>(pz, np_[384]); set_cell<7>(pz, np_[448]);
 #pragma unroll
         for (int s = 0; s < 6; ++s) hp[s] = np_[64 * (8 + s)];
+    } else {
+        rid0 = ridk[0];
+        rid1 = ridk[1];
     }
     h0.rv = ldg(P, (uint32_t)(rid0 >= 0 ? rid0 : bb.base));
     h1.rv = ldg(P, (uint32_t)(rid1 >= 0 ? rid1 : bb.base));
@@ -876,8 +906,8 @@ __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ block
     Slot tl0, tl1;
     int32_t tid0, tid1;
     flux_pass<0, 0>(bx, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, sl0, sl1, rid0, rid1, h0, h1, Rr, ldr, [&]() {
-        tid0 = ((const int32_t*)(nextbuf + 64 * 16))[lane];
-        tid1 = ((const int32_t*)(nextbuf + 64 * 17))[lane];
+        tid0 = DMA ? ((const int32_t*)(nextbuf + 64 * 16))[lane] : ridk[2];
+        tid1 = DMA ? ((const int32_t*)(nextbuf + 64 * 17))[lane] : ridk[3];
         tl0 = slot_of<2>(bx, htab, blk, lane, dtab);
         tl1 = slot_of<3>(bx, htab, blk, lane, dtab);
         halo_load<2>(bx, lane, P, ldp, tl0, tid0, g0);
@@ -892,8 +922,8 @@ __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ block
     transpose<0, 1>(buf, ta, tb, Dc);
     stamp(4);
     flux_pass<1, 1>(by, ftab, r4tab, P, ldp, lds, lane, gas, Pc, Dc, tl0, tl1, tid0, tid1, g0, g1, Rr, ldr, [&]() {
-        rid0 = ((const int32_t*)(nextbuf + 64 * 18))[lane];
-        rid1 = ((const int32_t*)(nextbuf + 64 * 19))[lane];
+        rid0 = DMA ? ((const int32_t*)(nextbuf + 64 * 18))[lane] : ridk[4];
+        rid1 = DMA ? ((const int32_t*)(nextbuf + 64 * 19))[lane] : ridk[5];
         sl0 = slot_of<4>(by, htab, blk, lane, dtab);
         sl1 = slot_of<5>(by, htab, blk, lane, dtab);
         halo_load<4>(by, lane, P, ldp, sl0, rid0, h0);
@@ -913,7 +943,7 @@ __device__ __forceinline__ void sweep_block(const BlockDesc3* __restrict__ block
 
 // A chain of blocks first, first + stride, ... < end for one wave: the first loads of a block are requested while the z
 // fluxes of the block before are computed.
-template <bool STAMP = false>
+template <bool STAMP = false, bool DMA = true>
 __device__ __forceinline__ void sweep_euler_chain(const BlockDesc3* __restrict__ blocks, const int32_t* __restrict__ htab,
                                                   const int32_t* __restrict__ ftab, const int32_t* __restrict__ rtab,
                                                   const int32_t* __restrict__ r4tab, int32_t first, int32_t stride,
@@ -922,11 +952,16 @@ __device__ __forceinline__ void sweep_euler_chain(const BlockDesc3* __restrict__
                                                   float* nextbuf, int lane, unsigned long long* stamps = nullptr,
                                                   const int32_t* __restrict__ dtab = nullptr) {
     if (first >= end) return;
+    if constexpr (!DMA) {   // one block per wave
+        sweep_block<STAMP, false>(blocks, htab, ftab, rtab, r4tab, first, P, ldp, Rr, ldr, gas, lds, lane,
+                                  STAMP && stamps ? stamps + (size_t)first * 8 : nullptr, dtab, nextbuf, []() {});
+        return;
+    }
     request_first(blocks, htab, rtab, P, first, lane, nextbuf);
 #pragma unroll 1
     for (int32_t blk = first; blk < end; blk += stride) {
         const int32_t nb = blk + stride;
-        sweep_block<STAMP>(blocks, htab, ftab, rtab, r4tab, blk, P, ldp, Rr, ldr, gas, lds, lane,
+        sweep_block<STAMP, true>(blocks, htab, ftab, rtab, r4tab, blk, P, ldp, Rr, ldr, gas, lds, lane,
                            STAMP && stamps ? stamps + (size_t)blk * 8 : nullptr, dtab, nextbuf, [&]() {
                                if (nb < end) request_first(blocks, htab, rtab, P, nb, lane, nextbuf);  // wave-uniform
                            });
