@@ -697,7 +697,17 @@ def main():
     # or 400 of them have run; every block is exactly `steps` steps between barrier + synchronize
     n_rep = max(1, args.repeats)
     n_goal = None                      # total number of blocks, decided (by all ranks alike) after the first n_rep
+    # configs[3] imposes its boundary conditions on a FROZEN field every step (nothing updates the cells): the ghost values
+    # feed their own image-point interpolation, and over hundreds of steps the temperature of a few ghost cells drifts
+    # linearly (-1.7 K per step at 7.9 M cells) until the sound speed is NaN.  Every timed block starts from the initial
+    # state (restored outside the timed region), as a solver's step would start from a state its update produced.
+    state4 = None
+    if config4:
+        state4 = (P4, P4.clone()) if world > 1 else (P, P.clone())
     while len(dts) < n_rep or len(dts) < n_goal:
+        if state4 is not None:
+            state4[0].copy_(state4[1])
+            torch.cuda.synchronize()
         barrier()
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()

@@ -51,6 +51,7 @@ _SIGS = {
     "ibh_cell_gradient": [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_cell_gradient_all": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64],
     "ibh_cell_gradient_nd": [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64],
+    "ibh_cell_gradient_fields": [c_vp, c_vp, c_int, c_i64, c_vp],
     "ibh_face_distance": [c_vp, c_int, c_vp],
     "ibh_owner_distance": [c_vp, c_int, c_vp],
     "ibh_neighbor_distance": [c_vp, c_int, c_vp],

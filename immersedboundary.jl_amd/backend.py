@@ -501,6 +501,12 @@ def cell_gradient(part, u, dim=None):
             # gradients + sensor back to back: the block sweep writes them in place (no copy out of a workspace)
             buf = colmajor_empty(nc, nd + 1)
             call("ibh_cell_gradient_nd", part.handle, _ptr(u), 1, ld, _ptr(buf), nc, c_vp(buf.data_ptr() + 4 * nd * nc), nc)
+        elif nv > 1 and part.info["full_blocks"] > 0:
+            # several fields: every field's block sweep writes [grad_1 .. grad_nd, sensor] in place, the tuple's arrays are
+            # strided views (columns d, d + nd + 1, ...: leading dimension (nd + 1) nc) -- no copies out of a workspace
+            buf = colmajor_empty(nc, nv * (nd + 1))
+            call("ibh_cell_gradient_fields", part.handle, _ptr(u), nv, ld, _ptr(buf))
+            return tuple(buf[:, d::nd + 1] for d in range(nd))
         else:
             buf = colmajor_empty(nc, nd * nv)
             call("ibh_cell_gradient_nd", part.handle, _ptr(u), nv, ld, _ptr(buf), nc, None, 0)

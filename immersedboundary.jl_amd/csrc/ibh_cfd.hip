@@ -7,6 +7,8 @@
 
 #define CFD_BLOCK 256
 
+// ibh_set_tuning("viscous_per_cell", 1): ibh_viscous_residual as one thread per cell (A/B against the LDS-shared faces)
+int ibh_viscous_per_cell = 0;
 namespace {
 
 __device__ __forceinline__ float sutherland(const ibh_fluid& f, float T) {
@@ -174,6 +176,26 @@ struct ViscDims {
     const int32_t* side;
 };
 __device__ __forceinline__ float v_face_avg(float uo, float un, float ho, float hn) { return (uo * hn + un * ho) / (hn + ho); }
+// a / d for several numerators over ONE denominator: the IEEE division the compiler expands `a / d` into (v_rcp, one
+// Newton step on the reciprocal, quotient, two residual corrections -- AMDGPU's f32 fdiv lowering) with the part that depends
+// on d alone done once.  Bit-identical to `a / d` whenever v_div_scale would not rescale, i.e. for |d| and |a / d| inside
+// [2^-96, 2^96] (spacings, velocities, temperatures, their gradients); the operator kernels divide with `/`, and
+// tests/test_gpu_cfd.py holds the two against each other bit for bit.  11 instead of 16.5 x 11 instructions per face.
+struct Recip {
+    float d, r;
+};
+__device__ __forceinline__ Recip recip_of(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return Recip{d, __builtin_fmaf(e, r0, r0)};
+}
+__device__ __forceinline__ float div_by(float a, const Recip& R) {
+    float q = a * R.r;
+    float e = __builtin_fmaf(-R.d, q, a);
+    q = __builtin_fmaf(e, R.r, q);
+    e = __builtin_fmaf(-R.d, q, a);
+    return __builtin_fmaf(e, R.r, q);
+}
 // flux through the face between owner o and neighbour n normal to D0: F[0] = energy, F[1 + j] = momentum j
 template <int ND, int D0>
 __device__ __forceinline__ void visc_flux_on(const ibh_fluid& f, const ViscDims<ND>& V, int32_t o, int32_t n,
@@ -181,19 +203,22 @@ __device__ __forceinline__ void visc_flux_on(const ibh_fluid& f, const ViscDims<
                                              const float* __restrict__ mut, float* F) {
     const float ho = V.h[D0][o], hn = V.h[D0][n];
     const float fd = (ho + hn) / 2.0f;                                   // face_distance
-    const float T = v_face_avg(P[o + ldp], P[n + ldp], ho, hn);         // at_faces(P)[:, 2]
+    const Recip rs = recip_of(hn + ho), rf = recip_of(fd);
+#define V_FACE_AVG(uo_, un_) div_by((uo_) * hn + (un_) * ho, rs)         /* v_face_avg(uo, un, ho, hn) */
+    const float T = V_FACE_AVG(P[o + ldp], P[n + ldp]);                  // at_faces(P)[:, 2]
     float u[ND], vg[ND][ND];
 #pragma unroll
     for (int a = 0; a < ND; ++a) {
         const float uo = P[o + (2 + a) * ldp], un = P[n + (2 + a) * ldp];
-        u[a] = v_face_avg(uo, un, ho, hn);
+        u[a] = V_FACE_AVG(uo, un);
 #pragma unroll
         for (int b = 0; b < ND; ++b)                                     // vel_grad(a, b) = Pgrad[b][:, 2 + a]
-            vg[a][b] = b == D0 ? (un - uo) / fd                          // face_gradient(part, P, dim)
-                               : v_face_avg(V.g[b][o + (V.gcol + a) * ldg], V.g[b][n + (V.gcol + a) * ldg], ho, hn);  // at_faces(grad_b P)
+            vg[a][b] = b == D0 ? div_by(un - uo, rf)                     // face_gradient(part, P, dim)
+                               : V_FACE_AVG(V.g[b][o + (V.gcol + a) * ldg], V.g[b][n + (V.gcol + a) * ldg]);  // at_faces(grad_b P)
     }
-    const float gT = (P[n + ldp] - P[o + ldp]) / fd;                     // Pgrad[dim][:, 2]
-    const float mu = sutherland(f, T) + v_face_avg(mut[o], mut[n], ho, hn);
+    const float gT = div_by(P[n + ldp] - P[o + ldp], rf);                // Pgrad[dim][:, 2]
+    const float mu = sutherland(f, T) + V_FACE_AVG(mut[o], mut[n]);
+#undef V_FACE_AVG
     const float k = conductivity(f, T);
     float divu = 0.f;
 #pragma unroll
@@ -267,6 +292,144 @@ __global__ __launch_bounds__(CFD_BLOCK) void k_viscous_residual(ibh_fluid f, int
     }
 }
 
+// The same sum with every face evaluated ONCE per workgroup (512 consecutive cells).  Phase A: each thread evaluates the
+// flux through the "right" face of its cell in every direction and leaves it in LDS with the index of the cell on the other
+// side.  The "left" face of a cell is its left neighbour's right face -- visc_flux_on(l, c) is the same call with the same
+// arguments in both threads, so the sum is bit-identical to k_viscous_residual's -- and is taken from LDS when the neighbour
+// is in the workgroup and names this cell.  The left faces that are not (block rims, level jumps, boundary faces: with 8^3
+// blocks tiled in order one plane of 64 per direction) are compacted into one task list per direction and evaluated in phase B
+// by whole waves (threads 128 d .. 128 d + 127 take direction d: wave-uniform), not by the eight scattered lanes of every
+// wave that own them -- 27 wave-evaluations of the flux per 8 waves instead of 48.  Tasks beyond 128 per direction
+// (partitions that are not tiled) are evaluated in place, as k_viscous_residual does.
+#define VISC_WG 512
+#define VISC_CAP 128
+template <int ND, int D0>
+__device__ __forceinline__ void visc_right(const ibh_fluid& f, const ViscDims<ND>& V, int32_t nc, int32_t c,
+                                           const float* __restrict__ P, int64_t ldp, int64_t ldg,
+                                           const float* __restrict__ mut, float* ar, int32_t& r) {
+    r = V.side[(int64_t)(2 * D0 + 1) * nc + c];
+    if (r >= 0) {
+        visc_flux_on<ND, D0>(f, V, c, r, P, ldp, ldg, mut, ar);
+    } else if (r == -2) {
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) ar[v] = 0.0f;
+    } else visc_mean<ND, D0>(f, V, V.d[D0].roff, V.d[D0].ridx, c, P, ldp, ldg, mut, ar);
+}
+template <int ND, int D0>
+__device__ __forceinline__ void visc_left(const ibh_fluid& f, const ViscDims<ND>& V, int32_t l, int32_t c,
+                                          const float* __restrict__ P, int64_t ldp, int64_t ldg,
+                                          const float* __restrict__ mut, float* al) {
+    if (l >= 0) {
+        visc_flux_on<ND, D0>(f, V, l, c, P, ldp, ldg, mut, al);
+    } else if (l == -2) {
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) al[v] = 0.0f;
+    } else visc_mean<ND, D0>(f, V, V.d[D0].loff, V.d[D0].lidx, c, P, ldp, ldg, mut, al);
+}
+template <int ND>
+struct ViscShared {
+    float Fs[ND][ND + 1][VISC_WG];      // right-face fluxes of the workgroup's cells
+    int32_t Rs[ND][VISC_WG];            // the cell on the other side of each
+    float Fl[ND][ND + 1][VISC_CAP];     // left-face fluxes evaluated in phase B
+    int32_t list[ND][VISC_CAP];         // their cells (thread ids)
+    int32_t cnt[ND];
+};
+// phase B of direction D0: task i of the list
+template <int ND, int D0>
+__device__ __forceinline__ void visc_task(const ibh_fluid& f, const ViscDims<ND>& V, int32_t nc, int32_t base, int i,
+                                          const float* __restrict__ P, int64_t ldp, int64_t ldg,
+                                          const float* __restrict__ mut, ViscShared<ND>& sh) {
+    const int n = sh.cnt[D0] < VISC_CAP ? sh.cnt[D0] : VISC_CAP;
+    if (i >= n) return;
+    const int32_t c = base + sh.list[D0][i];
+    float al[ND + 1];
+    visc_left<ND, D0>(f, V, V.side[(int64_t)(2 * D0) * nc + c], c, P, ldp, ldg, mut, al);
+#pragma unroll
+    for (int v = 0; v <= ND; ++v) sh.Fl[D0][v][i] = al[v];
+}
+// phase C of direction D0: slot -1 = the neighbour's right face in LDS, >= 0 = task slot, -2 = evaluate here
+template <int ND, int D0>
+__device__ __forceinline__ void visc_accumulate(const ibh_fluid& f, const ViscDims<ND>& V, int32_t nc, int32_t c, int32_t l,
+                                                int32_t base, int slot, const float* __restrict__ P, int64_t ldp,
+                                                int64_t ldg, const float* __restrict__ mut, const ViscShared<ND>& sh,
+                                                const float* ar, float* acc) {
+    float al[ND + 1];
+    if (slot == -1) {
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) al[v] = sh.Fs[D0][v][l - base];
+    } else if (slot >= 0) {
+#pragma unroll
+        for (int v = 0; v <= ND; ++v) al[v] = sh.Fl[D0][v][slot];
+    } else visc_left<ND, D0>(f, V, l, c, P, ldp, ldg, mut, al);
+    const Recip rh = recip_of(V.h[D0][c]);
+#pragma unroll
+    for (int v = 0; v <= ND; ++v) acc[v] = acc[v] + div_by(ar[v] - al[v], rh);
+}
+template <int ND>
+__global__ __launch_bounds__(VISC_WG) void k_viscous_residual_shared(ibh_fluid f, int32_t nc, ViscDims<ND> V,
+                                                                     const float* __restrict__ P, int64_t ldp, int64_t ldg,
+                                                                     const float* __restrict__ mut, float* __restrict__ R,
+                                                                     int64_t ldr) {
+    __shared__ ViscShared<ND> sh;
+    const int tid = threadIdx.x;
+    const int32_t nchunks = (nc + VISC_WG - 1) / VISC_WG;
+    for (int32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {      // (uniform bounds: every thread reaches the barriers)
+        const int32_t base = ch * VISC_WG, c = base + tid;
+        const bool on = c < nc;
+        float ar[ND][ND + 1];
+        int32_t r[ND], l[ND];
+        int slot[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) r[d] = -1;
+        if (on) {   // phase A
+            visc_right<ND, 0>(f, V, nc, c, P, ldp, ldg, mut, ar[0], r[0]);
+            visc_right<ND, 1>(f, V, nc, c, P, ldp, ldg, mut, ar[1], r[1]);
+            if constexpr (ND == 3) visc_right<ND, 2>(f, V, nc, c, P, ldp, ldg, mut, ar[2], r[2]);
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int v = 0; v <= ND; ++v) sh.Fs[d][v][tid] = ar[d][v];
+        }
+#pragma unroll
+        for (int d = 0; d < ND; ++d) sh.Rs[d][tid] = r[d];
+        if (tid < ND) sh.cnt[tid] = 0;
+        __syncthreads();
+        if (on) {   // which left faces are in LDS; the others become tasks
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                l[d] = V.side[(int64_t)(2 * d) * nc + c];
+                const int32_t k = l[d] - base;
+                if (l[d] >= 0 && k >= 0 && k < VISC_WG && sh.Rs[d][k] == c) slot[d] = -1;
+                else {
+                    const int s = atomicAdd(&sh.cnt[d], 1);
+                    slot[d] = s < VISC_CAP ? s : -2;
+                    if (s < VISC_CAP) sh.list[d][s] = tid;
+                }
+            }
+        }
+        __syncthreads();
+        {   // phase B: threads 128 d .. 128 d + 127 evaluate the tasks of direction d
+            const int d = tid / VISC_CAP, i = tid % VISC_CAP;
+            if (d == 0) visc_task<ND, 0>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
+            else if (d == 1) visc_task<ND, 1>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
+            else if (ND == 3 && d == 2) visc_task<ND, ND == 3 ? 2 : 0>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
+        }
+        __syncthreads();
+        if (on) {   // phase C: R .+= green_gauss(...), one dimension after the other
+            float acc[ND + 1];
+#pragma unroll
+            for (int v = 0; v <= ND; ++v) acc[v] = R[c + (1 + v) * ldr];
+            visc_accumulate<ND, 0>(f, V, nc, c, l[0], base, slot[0], P, ldp, ldg, mut, sh, ar[0], acc);
+            visc_accumulate<ND, 1>(f, V, nc, c, l[1], base, slot[1], P, ldp, ldg, mut, sh, ar[1], acc);
+            if constexpr (ND == 3) visc_accumulate<ND, 2>(f, V, nc, c, l[2], base, slot[2], P, ldp, ldg, mut, sh, ar[2], acc);
+#pragma unroll
+            for (int v = 0; v <= ND; ++v) R[c + (1 + v) * ldr] = acc[v];
+        }
+        __syncthreads();
+    }
+}
+
+inline dim3 visc_grid(int64_t n) { int64_t g = (n + VISC_WG - 1) / VISC_WG; return dim3((unsigned)(g > 16384 ? 16384 : g)); }
 inline dim3 grid1(int64_t n) { int g = ibh_grid(n, CFD_BLOCK); return dim3(g > 4096 ? 4096 : g); }
 
 // FlowBC call, cfd.jl:243-300: characteristic-style boundary state from the image-point primitives
@@ -453,8 +616,12 @@ int ibh_viscous_residual(const ibh_part* p, const ibh_fluid* f, const float* P, 
         }
         V.side = p->side;
         V.gcol = grad_vel_col;
-        hipLaunchKernelGGL(k_viscous_residual<2>, grid1(p->nc), dim3(CFD_BLOCK), 0, ibh_stream, *f, p->nc, V, P, ldp, ldg,
-                           mu_t, R, ldr);
+        if (ibh_viscous_per_cell)   // (A/B: one thread per cell, both faces of every direction evaluated by it)
+            hipLaunchKernelGGL(k_viscous_residual<2>, grid1(p->nc), dim3(CFD_BLOCK), 0, ibh_stream, *f, p->nc, V, P, ldp,
+                               ldg, mu_t, R, ldr);
+        else
+            hipLaunchKernelGGL(k_viscous_residual_shared<2>, visc_grid(p->nc), dim3(VISC_WG), 0, ibh_stream, *f, p->nc, V,
+                               P, ldp, ldg, mu_t, R, ldr);
     } else {
         ViscDims<3> V;
         for (int d = 0; d < 3; ++d) {
@@ -465,8 +632,12 @@ int ibh_viscous_residual(const ibh_part* p, const ibh_fluid* f, const float* P, 
         }
         V.side = p->side;
         V.gcol = grad_vel_col;
-        hipLaunchKernelGGL(k_viscous_residual<3>, grid1(p->nc), dim3(CFD_BLOCK), 0, ibh_stream, *f, p->nc, V, P, ldp, ldg,
-                           mu_t, R, ldr);
+        if (ibh_viscous_per_cell)   // (A/B: one thread per cell, both faces of every direction evaluated by it)
+            hipLaunchKernelGGL(k_viscous_residual<3>, grid1(p->nc), dim3(CFD_BLOCK), 0, ibh_stream, *f, p->nc, V, P, ldp,
+                               ldg, mu_t, R, ldr);
+        else
+            hipLaunchKernelGGL(k_viscous_residual_shared<3>, visc_grid(p->nc), dim3(VISC_WG), 0, ibh_stream, *f, p->nc, V,
+                               P, ldp, ldg, mu_t, R, ldr);
     }
     IBH_LAUNCH_CHECK();
     return 0;

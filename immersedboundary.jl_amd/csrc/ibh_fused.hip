@@ -1403,8 +1403,13 @@ int ibh_debug_buffer(void* buf) {  // device buffer of 8 x uint64 per wave of th
     return 0;
 }
 
+extern int ibh_viscous_per_cell;   // ibh_cfd.hip
 int ibh_set_tuning(const char* key, int value) {
     IBH_REQUIRE(key, "ibh_set_tuning: null key");
+    if (!strcmp(key, "viscous_per_cell")) {
+        ibh_viscous_per_cell = value;
+        return 0;
+    }
     if (!strcmp(key, "quad_variant")) ibh_quad_variant = value;
     else if (!strcmp(key, "quad_parts")) ibh_quad_parts = value;
     else if (!strcmp(key, "quad_singles_first")) ibh_quad_singles_first = value;
@@ -1806,6 +1811,35 @@ int ibh_cell_gradient_nd(ibh_part* p, const float* u, int nv, int64_t ldu, float
         if (sensor)
             IBH_HIP(hipMemcpyAsync(sensor + (size_t)v * lds, p->G + (size_t)nd * p->nc, sizeof(float) * p->nc,
                                    hipMemcpyDeviceToDevice, ibh_stream));
+    }
+    return 0;
+}
+
+// The same gradients FIELD by field: out is (nc, nv * (nd + 1)) column-major with leading dimension nc, the gradient of field
+// v along dimension d in column v * (nd + 1) + d and the JST sensor of field v in column v * (nd + 1) + nd -- the layout pass A
+// writes, so that on a block-structured partition every field's sweep writes in place (ibh_cell_gradient_nd copies nd
+// columns per field out of the partition's workspace: 9 device-to-device copies for the velocity gradients of a 3-D
+// closure, 0.3 ms of a configs[4] V-cycle at 7.9 M cells).  The gradient of all fields along d is the strided view
+// out[:, d : nv * (nd + 1) : nd + 1] (leading dimension (nd + 1) * nc).
+int ibh_cell_gradient_fields(ibh_part* p, const float* u, int nv, int64_t ldu, float* out) {
+    IBH_REQUIRE(p && u && out && nv >= 1, "ibh_cell_gradient_fields: bad argument");
+    if (p->nc == 0) return 0;
+    const int nd = p->nd;
+    const bool blocks = p->bs == 8 && p->nblk > 0 && (nd == 2 ? p->blocks2 != nullptr : p->blocks3 != nullptr);
+    for (int v = 0; v < nv; ++v) {
+        const float* uv = u + (size_t)v * ldu;
+        float* ov = out + (size_t)v * (nd + 1) * p->nc;
+        int rc;
+        if (blocks) {
+            float* const own = p->G;
+            p->G = ov;
+            rc = ibh_residual_advection(p, uv, uv, p->nc, ov, IBH_PASS_A_ONLY | IBH_NO_FUSE);
+            p->G = own;
+        } else {
+            rc = ibh_cell_gradient_all(p, uv, 1, p->nc, ov, p->nc);
+            if (!rc) rc = ibh_jst_sensor(p, 0, uv, 1, p->nc, ov + (size_t)nd * p->nc, p->nc);
+        }
+        if (rc) return rc;
     }
     return 0;
 }

@@ -181,6 +181,10 @@ int ibh_cell_gradient_all(const ibh_part*, const float* u, int nv, int64_t ldu, 
  * With nv = 1, ldo = lds = nc and sensor = out + nd * nc (one (nc, nd + 1) buffer) the sweep writes in place: no copy. */
 int ibh_cell_gradient_nd(ibh_part*, const float* u, int nv, int64_t ldu, float* out, int64_t ldo, float* sensor,
                          int64_t lds);
+/* The same FIELD by field, every sweep in place (no copies): out (nc, nv * (nd + 1)), leading dimension nc -- gradient of field
+ * v along dimension d in column v * (nd + 1) + d, JST sensor of field v in column v * (nd + 1) + nd; the gradients of all
+ * fields along d are the strided view of columns d, d + (nd + 1), ... (leading dimension (nd + 1) * nc). */
+int ibh_cell_gradient_fields(ibh_part*, const float* u, int nv, int64_t ldu, float* out);
 int ibh_face_distance(const ibh_part*, int dim, float* out);     /* :995  */
 int ibh_owner_distance(const ibh_part*, int dim, float* out);    /* :1010 */
 int ibh_neighbor_distance(const ibh_part*, int dim, float* out); /* :1024 */

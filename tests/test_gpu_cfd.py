@@ -157,3 +157,13 @@ def test_viscous_residual_is_the_operator_composition(rae_domains):
         got2 = R0.clone()                       # the same from the gradients of the velocity columns alone
         gcfd.viscous_residual(dpart, fluid, P, ibamd.cell_gradient(dpart, P[:, 2:]), mut, got2, velocity_gradients_only=True)
         assert torch.equal(got2, ref)
+        # the default kernel shares faces between the cells of a workgroup through LDS; one thread per cell with both faces
+        # of every direction evaluated by it (the round-4 first form) must give the same bits
+        from ibamd import _lib
+        got3 = R0.clone()
+        _lib.call("ibh_set_tuning", b"viscous_per_cell", 1)
+        try:
+            gcfd.viscous_residual(dpart, fluid, P, gP, mut, got3)
+        finally:
+            _lib.call("ibh_set_tuning", b"viscous_per_cell", 0)
+        assert torch.equal(got3, ref)

@@ -38,3 +38,20 @@ def test_device_fas_across_two_ranks_one_gpu():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "distributed device V-cycle == one-partition device V-cycle on the owned cells: True" in r.stdout, r.stdout[-1500:]
+
+
+def test_device_point_implicit_across_two_ranks_one_gpu():
+    """The point-implicit smoother (orphan src/point_implicit.jl) across ranks, device resident (point_implicit.py with
+    distributed.RankOps; 2 processes on the one GPU, gloo group): right-hand side and inverse Hutchinson blocks bit for bit,
+    two relaxation steps to the rounding of the all-reduced sums, against the one-partition device smoother
+    (scripts/rehearse_pi.py)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "rehearse_pi.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "distributed device point-implicit smoother == one-partition device smoother on the owned cells: True" in r.stdout, \
+        r.stdout[-1500:]
