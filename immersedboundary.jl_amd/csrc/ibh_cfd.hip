@@ -14,7 +14,10 @@ namespace {
 __device__ __forceinline__ float sutherland(const ibh_fluid& f, float T) {
     T = fmaxf(T, 10.0f);
     // mu_ref * ((T/Tref)^(2/3)) * (Tref + S) / (T + S)     (cfd.jl:75, exponent as in the reference)
-    return f.mu_ref * powf(T / f.Tref, 2.0f / 3.0f) * (f.Tref + f.S) / (T + f.S);
+    // x^(2/3) = exp2(2/3 log2 x) on the transcendental unit (v_log_f32 / v_exp_f32, 1 ulp each; x = T / Tref in [0.03, 30]:
+    // inside 4e-7 of the correctly rounded power) instead of the ~100 instructions of the library's powf -- a third of a
+    // viscous face flux
+    return f.mu_ref * __builtin_amdgcn_exp2f((2.0f / 3.0f) * __builtin_amdgcn_logf(T / f.Tref)) * (f.Tref + f.S) / (T + f.S);
 }
 
 __device__ __forceinline__ float conductivity(const ibh_fluid& f, float T) {
@@ -299,7 +302,8 @@ __global__ __launch_bounds__(CFD_BLOCK) void k_viscous_residual(ibh_fluid f, int
 // is in the workgroup and names this cell.  The left faces that are not (block rims, level jumps, boundary faces: with 8^3
 // blocks tiled in order one plane of 64 per direction) are compacted into one task list per direction and evaluated in phase B
 // by whole waves (threads 128 d .. 128 d + 127 take direction d: wave-uniform), not by the eight scattered lanes of every
-// wave that own them -- 27 wave-evaluations of the flux per 8 waves instead of 48.  Tasks beyond 128 per direction
+// wave that own them -- 27 wave-evaluations of the flux per 8 waves instead of 48.  The task lists are made first (from the
+// side table alone), so that phase B follows phase A in the same waves without a barrier.  Tasks beyond 128 per direction
 // (partitions that are not tiled) are evaluated in place, as k_viscous_residual does.
 #define VISC_WG 512
 #define VISC_CAP 128
@@ -372,16 +376,34 @@ __global__ __launch_bounds__(VISC_WG) void k_viscous_residual_shared(ibh_fluid f
                                                                      int64_t ldr) {
     __shared__ ViscShared<ND> sh;
     const int tid = threadIdx.x;
-    const int32_t nchunks = (nc + VISC_WG - 1) / VISC_WG;
-    for (int32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {      // (uniform bounds: every thread reaches the barriers)
+    {   // one chunk of 512 cells per workgroup, every XCD a contiguous run of chunks: the neighbour lines of a rim cell (a
+        // block's rim gathers 99 KB of lines next to 30 KB of its own) are then in the L2 that read them as own cells --
+        // round-robin placement fetched 2.3 x the algorithmic bytes from HBM
+        const int32_t ch = ibh_xcd_chunk(blockIdx.x, gridDim.x);
         const int32_t base = ch * VISC_WG, c = base + tid;
         const bool on = c < nc;
         float ar[ND][ND + 1];
         int32_t r[ND], l[ND];
         int slot[ND];
+        if (tid < ND) sh.cnt[tid] = 0;
+        __syncthreads();
+        if (on) {   // left faces whose neighbour is outside the workgroup's cells become tasks (the others are expected in LDS)
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                l[d] = V.side[(int64_t)(2 * d) * nc + c];
+                const int32_t k = l[d] - base;
+                if (l[d] >= 0 && k >= 0 && k < VISC_WG) slot[d] = -1;
+                else {
+                    const int s = atomicAdd(&sh.cnt[d], 1);
+                    slot[d] = s < VISC_CAP ? s : -2;
+                    if (s < VISC_CAP) sh.list[d][s] = tid;
+                }
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int d = 0; d < ND; ++d) r[d] = -1;
-        if (on) {   // phase A
+        if (on) {   // phase A: the right faces
             visc_right<ND, 0>(f, V, nc, c, P, ldp, ldg, mut, ar[0], r[0]);
             visc_right<ND, 1>(f, V, nc, c, P, ldp, ldg, mut, ar[1], r[1]);
             if constexpr (ND == 3) visc_right<ND, 2>(f, V, nc, c, P, ldp, ldg, mut, ar[2], r[2]);
@@ -392,44 +414,32 @@ __global__ __launch_bounds__(VISC_WG) void k_viscous_residual_shared(ibh_fluid f
         }
 #pragma unroll
         for (int d = 0; d < ND; ++d) sh.Rs[d][tid] = r[d];
-        if (tid < ND) sh.cnt[tid] = 0;
-        __syncthreads();
-        if (on) {   // which left faces are in LDS; the others become tasks
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                l[d] = V.side[(int64_t)(2 * d) * nc + c];
-                const int32_t k = l[d] - base;
-                if (l[d] >= 0 && k >= 0 && k < VISC_WG && sh.Rs[d][k] == c) slot[d] = -1;
-                else {
-                    const int s = atomicAdd(&sh.cnt[d], 1);
-                    slot[d] = s < VISC_CAP ? s : -2;
-                    if (s < VISC_CAP) sh.list[d][s] = tid;
-                }
+        {   // phase B, no barrier in between: wave w < ND takes the first 64 tasks of direction w, wave ND + w the next 64
+            const int w = tid >> 6, d = w % ND, i = (w / ND) * 64 + (tid & 63);
+            if (w < 2 * ND) {
+                if (d == 0) visc_task<ND, 0>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
+                else if (d == 1) visc_task<ND, 1>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
+                else visc_task<ND, ND == 3 ? 2 : 0>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
             }
-        }
-        __syncthreads();
-        {   // phase B: threads 128 d .. 128 d + 127 evaluate the tasks of direction d
-            const int d = tid / VISC_CAP, i = tid % VISC_CAP;
-            if (d == 0) visc_task<ND, 0>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
-            else if (d == 1) visc_task<ND, 1>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
-            else if (ND == 3 && d == 2) visc_task<ND, ND == 3 ? 2 : 0>(f, V, nc, base, i, P, ldp, ldg, mut, sh);
         }
         __syncthreads();
         if (on) {   // phase C: R .+= green_gauss(...), one dimension after the other
             float acc[ND + 1];
 #pragma unroll
             for (int v = 0; v <= ND; ++v) acc[v] = R[c + (1 + v) * ldr];
+#pragma unroll
+            for (int d = 0; d < ND; ++d)   // a neighbour in the workgroup that does not name this cell as its right one: here
+                if (slot[d] == -1 && sh.Rs[d][l[d] - base] != c) slot[d] = -2;
             visc_accumulate<ND, 0>(f, V, nc, c, l[0], base, slot[0], P, ldp, ldg, mut, sh, ar[0], acc);
             visc_accumulate<ND, 1>(f, V, nc, c, l[1], base, slot[1], P, ldp, ldg, mut, sh, ar[1], acc);
             if constexpr (ND == 3) visc_accumulate<ND, 2>(f, V, nc, c, l[2], base, slot[2], P, ldp, ldg, mut, sh, ar[2], acc);
 #pragma unroll
             for (int v = 0; v <= ND; ++v) R[c + (1 + v) * ldr] = acc[v];
         }
-        __syncthreads();
     }
 }
 
-inline dim3 visc_grid(int64_t n) { int64_t g = (n + VISC_WG - 1) / VISC_WG; return dim3((unsigned)(g > 16384 ? 16384 : g)); }
+inline dim3 visc_grid(int64_t n) { return dim3((unsigned)((n + VISC_WG - 1) / VISC_WG)); }
 inline dim3 grid1(int64_t n) { int g = ibh_grid(n, CFD_BLOCK); return dim3(g > 4096 ? 4096 : g); }
 
 // FlowBC call, cfd.jl:243-300: characteristic-style boundary state from the image-point primitives

@@ -264,3 +264,20 @@ static inline int ibh_grid(int64_t n, int block) {
     if (g > 65535 * 16) g = 65535 * 16;
     return (int)g;
 }
+
+// XCD-aware placement of workgroup `wg` of `nwg` (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8
+// XCDs, each with its own L2; this gives every XCD one CONTIGUOUS run of the work list (cells and blocks are in depth-first
+// order: a run is a compact patch of the mesh), so that the lines a workgroup gathers from its neighbours' cells are in the
+// L2 that fetched them as own cells.  Bijective for any nwg.
+#ifdef __HIPCC__
+__device__ __forceinline__ int32_t ibh_xcd_chunk(int32_t wg, int32_t nwg) {
+    const int32_t q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// the workgroup's position along x for kernels that run over cells (or output rows) and gather from neighbouring cells
+#ifdef IBH_NO_XCD_CELLS   // (A/B builds)
+#define IBH_WG_X() ((int64_t)blockIdx.x)
+#else
+#define IBH_WG_X() ((int64_t)ibh_xcd_chunk((int32_t)blockIdx.x, (int32_t)gridDim.x))
+#endif
+#endif

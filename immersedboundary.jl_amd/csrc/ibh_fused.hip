@@ -595,7 +595,11 @@ __global__ __launch_bounds__(64 * WPB) void k_passA(PartView p, const float* __r
         }
         return;
     }
+#ifdef IBH_NO_XCD_CELLS
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#else
+    int64_t t = (int64_t)ibh_xcd_chunk((int32_t)blockIdx.x, gI) * blockDim.x + threadIdx.x;   // (the face-list workgroups)
+#endif
     if (t >= ncells) return;
     int32_t c = cells ? cells[t] : (int32_t)t;
     if (flat.rec) passA_flat<ND, NV>(p, flat, (int32_t)t, c, u, ldu, G);
@@ -1141,7 +1145,7 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_euler(PartView p, const floa
                                                      const float* __restrict__ G, float* __restrict__ R, int64_t ldr,
                                                      float Rgas, float gamma, const int32_t* __restrict__ cells,
                                                      int32_t ncells) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t t = IBH_WG_X() * blockDim.x + threadIdx.x;
     if (t >= ncells) return;
     int32_t c = cells ? cells[t] : (int32_t)t;
     passB_euler_cell<ND>(p, P, ldp, G, R, ldr, Rgas, gamma, c);

@@ -124,7 +124,7 @@ __global__ void k_cell_gradient_all(int32_t nc, GradDims G, const float* __restr
                                     float* __restrict__ out, int64_t ldo) {
     const int64_t v = blockIdx.y;
     const float* uv = u + v * ldu;
-    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         int32_t sd[2 * ND];
 #pragma unroll
         for (int s = 0; s < 2 * ND; ++s) sd[s] = G.side[(int64_t)s * nc + c];
@@ -158,7 +158,7 @@ template <int ND, bool TILED>
 __global__ __launch_bounds__(OPS_BLOCK) void k_timestep_advection(int32_t nc, GradDims G, const float* __restrict__ C,
                                                                   int64_t ldc, float* __restrict__ partial) {
     float m = 0.0f;
-    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         int32_t sd[2 * ND];
 #pragma unroll
         for (int s = 0; s < 2 * ND; ++s) {
@@ -233,7 +233,7 @@ __device__ __forceinline__ void cell_gradient_at(const GradDims& G, const int32_
 template <int ND>
 __global__ void k_shear_of_velocity_cells(int32_t nc, GradDims G, const float* __restrict__ vel, int64_t ldv,
                                           float* __restrict__ S) {
-    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         int32_t sd[2 * ND];
 #pragma unroll
         for (int s = 0; s < 2 * ND; ++s) sd[s] = G.side[(int64_t)s * nc + c];
@@ -257,7 +257,7 @@ __global__ void k_wray_agarwal_of_cells(int32_t nc, GradDims G, const float* __r
                                         float* __restrict__ nuR, float* __restrict__ Sout) {
     const float C2 = sigmaR + C1 / (kappa * kappa);
     constexpr float EPS32 = 1.1920929e-07f;
-    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         int32_t sd[2 * ND];
 #pragma unroll
         for (int s = 0; s < 2 * ND; ++s) sd[s] = G.side[(int64_t)s * nc + c];
@@ -279,7 +279,7 @@ __global__ void k_cell_gradient(int32_t nc, DimData D, const float* __restrict__
                                 int64_t ldu, float* __restrict__ out, int64_t ldo) {
     int64_t v = blockIdx.y;
     const float* uv = u + v * ldu;
-    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         float ar = csr_mean_face_avg(D.roff, D.ridx, (int32_t)c, D.owners, D.neighbors, h, uv);
         float al = csr_mean_face_avg(D.loff, D.lidx, (int32_t)c, D.owners, D.neighbors, h, uv);
         out[c + v * ldo] = (ar - al) / h[c];
@@ -320,7 +320,7 @@ __global__ void k_jst(int32_t nc, int nd, int dim, DimData D0, DimData D1, DimDa
                       float* __restrict__ out, int64_t ldo) {
     int64_t v = blockIdx.y;
     const float* pv = p + v * ldp;
-    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         float nu;
         if (dim > 0) {
             const DimData& D = dim == 1 ? D0 : (dim == 2 ? D1 : D2);
@@ -372,7 +372,7 @@ __global__ void k_accumulate(int32_t n_out, const int32_t* __restrict__ off, con
                              const float* __restrict__ v, int64_t ldv, float* __restrict__ out, int64_t ldo) {
     int64_t var = blockIdx.y;
     const float* vv = v + var * ldv;
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t r = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
         int32_t b = off[r], e = off[r + 1];
         float s = 0.0f;
         for (int32_t k = b; k < e; ++k) {
@@ -398,7 +398,7 @@ __global__ void k_accumulate_rows(int32_t n_out, const int32_t* __restrict__ off
     const float* vv = v + (int64_t)v0 * ldv;
     const float* vv2 = v2 ? v2 + (int64_t)v0 * ldv : nullptr;
     float* oo = out + (int64_t)v0 * ldo;
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t r = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
         const int32_t b = off[r], e = off[r + 1];
         float s[NVB];
 #pragma unroll
@@ -474,7 +474,7 @@ template <int NV>
 __global__ void k_accumulate_packed_add(int32_t n_out, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
                                         const float* __restrict__ w, const float4* __restrict__ d, float* __restrict__ out,
                                         int64_t ldo) {
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t r = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; r < n_out; r += (int64_t)gridDim.x * blockDim.x) {
         const int32_t b = off[r], e = off[r + 1];
         float s[8];
 #pragma unroll

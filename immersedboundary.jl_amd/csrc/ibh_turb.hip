@@ -216,7 +216,7 @@ __device__ __forceinline__ float tr_mean(const int32_t* __restrict__ off, const 
 template <int ND>
 __global__ void k_scalar_transport(int32_t nc, TransportDims T, const float* __restrict__ R, const float* __restrict__ nuR,
                                    float nu, const float* __restrict__ S, float* __restrict__ out) {
-    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         float rt = S[c];
         int32_t sd[2 * ND];
 #pragma unroll

@@ -8,7 +8,7 @@ for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            m = re.search(r"k_(?:pass|sweep|probe)\w*(?:<[^>]*>)?", k)
+            m = re.search(os.environ.get("PMC_KERNEL_RE", r"k_(?:pass|sweep|probe)\w*(?:<[^>]*>)?"), k)
             if not m:
                 continue
             k = m.group(0).replace(" ", "")
