@@ -260,7 +260,11 @@ __device__ __forceinline__ void flux_pass(const BlockDesc3& bb, const LaneGeo& L
 template <int I = 0>
 __device__ __forceinline__ void store_zcol(float* __restrict__ p, const Col& c) {
     if constexpr (I < 8) {
+#ifdef C3_NO_NT_STORE   // (A/B)
         p[64 * I] = cellv<I>(c);
+#else   // the residual is not read again by this sweep: a store that does not allocate in L2 leaves it to the halo lines
+        __builtin_nontemporal_store(cellv<I>(c), p + 64 * I);
+#endif
         store_zcol<I + 1>(p, c);
     }
 }
