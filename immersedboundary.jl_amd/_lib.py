@@ -73,6 +73,7 @@ _SIGS = {
     "ibh_residual_advection": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int],
     "ibh_residual_advection_n": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_int],
     "ibh_shear_rate_of_velocity": [c_vp, c_vp, c_i64, c_vp],
+    "ibh_shear_rate_of_velocity_grad": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64],
     "ibh_wray_agarwal_of": [c_vp, c_vp, c_vp, C.c_float, C.c_float, C.c_float, c_vp, c_vp, c_vp],
     "ibh_scalar_transport": [c_vp, c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp],
     "ibh_bcset_create": [C.POINTER(c_vp), c_int, C.POINTER(c_vp), c_vp, c_vp],

@@ -80,7 +80,11 @@ def navier_stokes_wray_agarwal_residual(part, Q, nu=1.5e-5, fluid=None, out=None
     P = Q[:, :nvp]
     B.residual_euler_hll(part, P, out=r[:, :nvp])
     R = Q[:, nvp].contiguous()
-    S = T.shear_rate_of_velocity(part, Q[:, 2:2 + nd])
+    # the velocity gradients are made once: the shear rate consumes them on the way, the viscous sum reads them again
+    if fused_viscous:
+        S, gV = T.shear_rate_of_velocity(part, Q[:, 2:2 + nd], gradients=True)
+    else:
+        S = T.shear_rate_of_velocity(part, Q[:, 2:2 + nd])
     wa = T.Wray_Agarwal_of(part, R, S)
     T.scalar_transport(part, R, wa["nuR"], Q[:, 2:2 + nd], float(nu), wa["S"], out=r[:, nvp])
     from .hiparray import HipArray
@@ -88,7 +92,6 @@ def navier_stokes_wray_agarwal_residual(part, Q, nu=1.5e-5, fluid=None, out=None
     if fused_viscous:
         # sum_d green_gauss(viscous_fluxes(at_faces(P), face_gradient(P, gP, d), d; mu_t = at_faces(mu_t)), d) in one launch;
         # of cell_gradient(part, P) it reads the velocity columns only (the gradients of p and T are not formed)
-        gV = B.cell_gradient(part, Q[:, 2:2 + nd])
         cfd.viscous_residual(part, fluid, P, gV, mut, r[:, :nvp], velocity_gradients_only=True)
         return r
     gP = B.cell_gradient(part, P)                                     # tuple over the dimensions of (nc, nd + 2)

@@ -191,7 +191,8 @@ struct ibh_bcset {
 };
 
 // internal: face-list forms of the fused turbulence closures (ibh_ops.hip), dispatched from ibh_fused.hip
-extern "C" int ibh_shear_rate_of_velocity_cells(const ibh_part* p, const float* vel, int64_t ldv, float* S);
+extern "C" int ibh_shear_rate_of_velocity_cells(const ibh_part* p, const float* vel, int64_t ldv, float* S, float* Gout,
+                                                int64_t ldg);
 extern "C" int ibh_wray_agarwal_of_cells(const ibh_part* p, const float* R, const float* S, float sigmaR, float C1,
                                          float kappa, float* nut, float* nuR, float* Sout);
 

@@ -1164,7 +1164,10 @@ struct FieldPtrs {
 __global__ __launch_bounds__(256) void k_shear_of_velocity3(const BlockDesc3* __restrict__ blocks,
                                                             const int32_t* __restrict__ htab,
                                                             const int32_t* __restrict__ ftab, int32_t nblk, int32_t nwg,
-                                                            FieldPtrs<3> V, float* __restrict__ S) {
+                                                            FieldPtrs<3> V, float* __restrict__ S,
+                                                            float* __restrict__ Gout, uint32_t ldg) {
+    // Gout (or null): the nine gradients on the way, d u_i / d x_j in column 3 j + i (the tuple cell_gradient's layout) --
+    // a Navier-Stokes closure needs them again for its viscous fluxes (three pass-A sweeps otherwise)
     __shared__ float lds[4 * BLK3W_PASSA_LDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t blk = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nwg) * 4 + wave);
@@ -1183,6 +1186,13 @@ __global__ __launch_bounds__(256) void k_shear_of_velocity3(const BlockDesc3* __
                 s = s + t * t;
             }
         S[(uint32_t)bb.base + lane + 64 * k] = sqrtf(2.0f * s);
+        if (Gout) {  // (uniform)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    __builtin_nontemporal_store(g[i][k][j], Gout + (size_t)(3 * j + i) * ldg + (uint32_t)bb.base + lane + 64 * k);
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_wray_agarwal_of3(const BlockDesc3* __restrict__ blocks,
@@ -1870,18 +1880,22 @@ int ibh_scalar_transport_blocks(const ibh_part* p, const float* R, const float* 
 static bool no_blocks(const ibh_part* p) {
     return !(p->bs == 8 && p->nblk > 0 && (p->nd == 2 ? p->blocks2 != nullptr : p->blocks3 != nullptr));
 }
-int ibh_shear_rate_of_velocity(ibh_part* p, const float* vel, int64_t ldv, float* S) {
+int ibh_shear_rate_of_velocity_grad(ibh_part* p, const float* vel, int64_t ldv, float* S, float* G, int64_t ldg) {
     IBH_REQUIRE(p && vel && S, "ibh_shear_rate_of_velocity: null argument");
+    IBH_REQUIRE(!G || ldg >= p->nc, "ibh_shear_rate_of_velocity_grad: ldg < nc");
     if (p->nc == 0) return 0;
-    if (no_blocks(p)) return ibh_shear_rate_of_velocity_cells(p, vel, ldv, S);
+    if (no_blocks(p)) return ibh_shear_rate_of_velocity_cells(p, vel, ldv, S, G, ldg);
     IBH_REQUIRE(all_blocks3(p), "ibh_shear_rate_of_velocity: needs a 3-D partition made of complete blocks or one without "
                                 "block structure (compose cell_gradient and shear_rate otherwise)");
     FieldPtrs<3> V{{vel, vel + ldv, vel + 2 * ldv}};
     const int32_t nwg = (p->nblk + 3) / 4;
     hipLaunchKernelGGL(k_shear_of_velocity3, dim3(nwg), dim3(256), 0, ibh_stream, p->blocks3, p->htab3, p->ftab3, p->nblk, nwg,
-                       V, S);
+                       V, S, G, (uint32_t)ldg);
     IBH_LAUNCH_CHECK();
     return 0;
+}
+int ibh_shear_rate_of_velocity(ibh_part* p, const float* vel, int64_t ldv, float* S) {
+    return ibh_shear_rate_of_velocity_grad(p, vel, ldv, S, nullptr, 0);
 }
 int ibh_wray_agarwal_of(ibh_part* p, const float* R, const float* S, float sigmaR, float C1, float kappa, float* nut,
                         float* nuR, float* Sout) {

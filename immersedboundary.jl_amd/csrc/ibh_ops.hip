@@ -232,7 +232,7 @@ __device__ __forceinline__ void cell_gradient_at(const GradDims& G, const int32_
 // k_wray_agarwal: bit-identical to the composition)
 template <int ND>
 __global__ void k_shear_of_velocity_cells(int32_t nc, GradDims G, const float* __restrict__ vel, int64_t ldv,
-                                          float* __restrict__ S) {
+                                          float* __restrict__ S, float* __restrict__ Gout, int64_t ldg) {
     for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
         int32_t sd[2 * ND];
 #pragma unroll
@@ -249,6 +249,12 @@ __global__ void k_shear_of_velocity_cells(int32_t nc, GradDims G, const float* _
                 s = s + t * t;
             }
         S[c] = sqrtf(2.0f * s);
+        if (Gout) {  // d u_i / d x_j in column ND j + i (the tuple cell_gradient's layout)
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+#pragma unroll
+                for (int j = 0; j < ND; ++j) Gout[(int64_t)(ND * j + i) * ldg + c] = g[i][j];
+        }
     }
 }
 template <int ND>
@@ -745,12 +751,12 @@ static GradDims grad_dims(const ibh_part* p) {
 }
 // face-list forms of ibh_shear_rate_of_velocity / ibh_wray_agarwal_of (ibh_fused.hip dispatches here on partitions
 // without block structure)
-int ibh_shear_rate_of_velocity_cells(const ibh_part* p, const float* vel, int64_t ldv, float* S) {
+int ibh_shear_rate_of_velocity_cells(const ibh_part* p, const float* vel, int64_t ldv, float* S, float* Gout, int64_t ldg) {
     const GradDims G = grad_dims(p);
     if (p->nd == 2)
-        hipLaunchKernelGGL(k_shear_of_velocity_cells<2>, grid2(p->nc, 1), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, vel, ldv, S);
+        hipLaunchKernelGGL(k_shear_of_velocity_cells<2>, grid2(p->nc, 1), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, vel, ldv, S, Gout, ldg);
     else
-        hipLaunchKernelGGL(k_shear_of_velocity_cells<3>, grid2(p->nc, 1), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, vel, ldv, S);
+        hipLaunchKernelGGL(k_shear_of_velocity_cells<3>, grid2(p->nc, 1), dim3(OPS_BLOCK), 0, ibh_stream, p->nc, G, vel, ldv, S, Gout, ldg);
     IBH_LAUNCH_CHECK();
     return 0;
 }

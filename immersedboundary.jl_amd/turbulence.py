@@ -119,10 +119,12 @@ def fused_closures_apply(part):
     return all_blocks(part) or part.info["full_blocks"] == 0
 
 
-def shear_rate_of_velocity(part, vel):
+def shear_rate_of_velocity(part, vel, gradients=False):
     """``shear_rate([cell_gradient(part, vel[:, i]) ...])`` (:110-124 over the tuple ``cell_gradient``,
     ImmersedBoundary.jl:980-988): ONE launch on an all-block 3-D partition (``ibh_shear_rate_of_velocity``), the composition
-    elsewhere -- bit-identical."""
+    elsewhere -- bit-identical.  ``gradients=True`` returns ``(S, cell_gradient(part, vel))`` -- the tuple over the
+    dimensions of ``(nc, nd)`` arrays -- with the gradients made once (``ibh_shear_rate_of_velocity_grad``): a Navier-Stokes
+    closure needs them again for its viscous fluxes."""
     part = B._part(part)
     v, nd, ldv = B._field(vel, part.nc)
     if nd != part.nd:
@@ -130,9 +132,14 @@ def shear_rate_of_velocity(part, vel):
     if fused_closures_apply(part):
         S = B.colmajor_empty(part.nc)
         B._stream()
+        if gradients:
+            G = B.colmajor_empty(part.nc, nd * nd)
+            B.call("ibh_shear_rate_of_velocity_grad", part.handle, B._ptr(v), ldv, B._ptr(S), B._ptr(G), part.nc)
+            return S, tuple(G[:, j * nd:(j + 1) * nd] for j in range(nd))
         B.call("ibh_shear_rate_of_velocity", part.handle, B._ptr(v), ldv, B._ptr(S))
         return S
-    return shear_rate([list(B.cell_gradient(part, vel[:, i].contiguous())) for i in range(nd)])
+    S = shear_rate([list(B.cell_gradient(part, vel[:, i].contiguous())) for i in range(nd)])
+    return (S, B.cell_gradient(part, vel)) if gradients else S
 
 
 def Wray_Agarwal_of(part, R, S, sigmaR=0.72, C1=0.0829, kappa=0.41):

@@ -429,6 +429,11 @@ int ibh_scalar_transport(const ibh_part*, const float* R, const float* nuR, floa
  *   (nut, nuR, Sout) = Wray_Agarwal(R, S, cell_gradient(part, R), cell_gradient(part, S))          turbulence.jl:222-241
  * with the arithmetic of the tuple cell_gradient's block sweep (ibh_cell_gradient_nd) and of the pointwise kernels. */
 int ibh_shear_rate_of_velocity(ibh_part*, const float* vel, int64_t ldv, float* S);
+/* The same with the velocity gradients kept: G (nc, nd * nd), leading dimension ldg, d u_i / d x_j in column nd * j + i -- the
+ * layout of the tuple cell_gradient (ibh_cell_gradient_nd), so that G + nd * j * ldg is `cell_gradient(part, vel)[j]` for
+ * ibh_viscous_residual (grad_vel_col = 0): a Navier-Stokes closure with a turbulence model needs both, and the gradients
+ * are made once.  G may be NULL (= ibh_shear_rate_of_velocity). */
+int ibh_shear_rate_of_velocity_grad(ibh_part*, const float* vel, int64_t ldv, float* S, float* G, int64_t ldg);
 int ibh_wray_agarwal_of(ibh_part*, const float* R, const float* S, float sigmaR, float C1, float kappa, float* nut,
                         float* nuR, float* Sout);
 int ibh_turb_ducros(int nd, int64_t n, const float* const* g, float* out);

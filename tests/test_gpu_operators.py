@@ -125,3 +125,35 @@ def test_tuple_cell_gradient_block_fast_path(rae_domains):
                 assert rel_inf(one, exp) <= 1e-6
                 assert rel_inf(g, exp) <= 5e-6          # tuned arithmetic (reciprocal spacings)
     assert used_blocks > 0
+
+
+def test_cell_gradient_fields_entry_on_both_kinds_of_partition(rae_mesh_small):
+    """``ibh_cell_gradient_fields`` called directly: out (nc, nv (nd + 1)) with the gradient of field v along d in column
+    v (nd + 1) + d and its JST sensor in column v (nd + 1) + nd -- on a block-structured partition (every field's block
+    sweep in place) and on a partition without block structure (a coarse level of ``multigrid``: the face-list kernels field
+    by field), against ``ibh_cell_gradient_nd`` / ``cell_gradient(part, u, d)`` and ``JST_sensor(part, u)``."""
+    import torch
+    from ibamd import _lib
+    from ibamd import backend as B
+    dp = ibamd.Domain(rae_mesh_small, max_partition_size=10 ** 9, boundaries=False)
+    cds, _, _ = ibamd.multigrid(dp, max_levels=1)
+    rng = np.random.default_rng(9)
+    seen = set()
+    for part in (dp.partitions[1], cds[0].partitions[1]):
+        dpart = ibamd.to_backend(part, ibamd.hip)
+        seen.add(dpart.info["full_blocks"] > 0)
+        nc, nd, nv = dpart.nc, 2, 3
+        U = ibamd.hip((np.sin(3 * part.centers[:, :1]) + 0.3 * rng.uniform(-1, 1, (nc, nv))).astype(np.float32))
+        out = ibamd.colmajor_empty(nc, nv * (nd + 1))
+        out.fill_(float("nan"))
+        B._stream()
+        _lib.call("ibh_cell_gradient_fields", dpart.handle, B._ptr(U), nv, nc, B._ptr(out))
+        assert torch.isfinite(out).all()
+        for v in range(nv):
+            uv = U[:, v].contiguous()
+            g = ibamd.cell_gradient(dpart, uv)                      # the one-field tuple form (in place as well)
+            for d in range(nd):
+                assert torch.equal(out[:, v * (nd + 1) + d], g[d])
+            sens = ibamd.JST_sensor(dpart, uv)
+            assert rel_inf(ibamd.to_host(out[:, v * (nd + 1) + nd]), ibamd.to_host(sens)) <= 5e-6
+    assert seen == {True, False}

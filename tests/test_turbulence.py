@@ -148,6 +148,13 @@ def test_fused_closures_on_an_all_block_octree_are_the_composition():
         S_comp = T.shear_rate(gu)
         assert torch.equal(S_fused, S_comp)
         assert float(S_comp.abs().max()) > 0
+        # gradients=True: the same S and cell_gradient(part, vel) -- the tuple over the dimensions -- made on the way
+        # (ibh_shear_rate_of_velocity_grad on the all-block partition, the composition on the other)
+        S_g, gV = T.shear_rate_of_velocity(dpart, vel, gradients=True)
+        assert torch.equal(S_g, S_comp) and len(gV) == 3
+        for j in range(3):
+            for i in range(3):
+                assert torch.equal(gV[j][:, i], gu[i][j]), (i, j)
         wa_f = T.Wray_Agarwal_of(dpart, R, S_comp)
         wa_c = T.Wray_Agarwal(R, S_comp, ibamd.cell_gradient_array(dpart, R), ibamd.cell_gradient_array(dpart, S_comp))
         for k in ("nut", "nuR", "S"):
@@ -181,6 +188,11 @@ def test_fused_closures_on_face_list_partitions_are_the_composition(nd):
     S_fused = T.shear_rate_of_velocity(dpart, vel)
     S_comp = T.shear_rate([list(ibamd.cell_gradient(dpart, vel[:, i].contiguous())) for i in range(nd)])
     assert torch.equal(S_fused, S_comp) and float(S_comp.abs().max()) > 0
+    S_g, gV = T.shear_rate_of_velocity(dpart, vel, gradients=True)      # the gradients kept on the way (same kernel)
+    assert torch.equal(S_g, S_comp) and len(gV) == nd
+    for j in range(nd):
+        for i in range(nd):
+            assert torch.equal(gV[j][:, i], ibamd.cell_gradient(dpart, vel[:, i].contiguous())[j]), (i, j)
     wa_f = T.Wray_Agarwal_of(dpart, R, S_comp)
     wa_c = T.Wray_Agarwal(R, S_comp, ibamd.cell_gradient_array(dpart, R), ibamd.cell_gradient_array(dpart, S_comp))
     for k in ("nut", "nuR", "S"):
