@@ -52,19 +52,22 @@ struct EwProg {
     int32_t arr_nv[8];
     float scal[8];
 };
+// BCAST: some operand is a column vector broadcast over the columns of the result (row index = t mod n); without one every
+// operand is a flat array of the result's shape and the 64-bit modulo -- half of the interpreter's instructions -- is not made.
+template <bool BCAST>
 __global__ __launch_bounds__(256) void k_ew_eval(int64_t n, int nv, EwProg P, float* out) {
     __shared__ float stk[7][256];
     const int64_t total = n * nv;
     const int tid = threadIdx.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + tid; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = t % n;
+        const int64_t i = BCAST ? t % n : t;
         float tos = 0.0f;
         int sp = 0;  // entries on the stack, the last one in `tos`
         for (int pc = 0; pc < P.nprog; ++pc) {
             const int ins = P.prog[pc], op = ins & 255, k = ins >> 8;
             if (op >= IBH_EW_PUSH_ARRAY) {
                 if (sp > 0) stk[sp - 1][tid] = tos;
-                tos = op == IBH_EW_PUSH_ARRAY ? (P.arr_nv[k] == 1 ? P.arr[k][i] : P.arr[k][t]) : P.scal[k];
+                tos = op == IBH_EW_PUSH_ARRAY ? (BCAST && P.arr_nv[k] == 1 ? P.arr[k][i] : P.arr[k][t]) : P.scal[k];
                 ++sp;
             } else if (op >= IBH_EW_ABS) {
                 tos = op == IBH_EW_ABS ? fabsf(tos) : op == IBH_EW_NEG ? -tos : op == IBH_EW_SQRT ? sqrtf(tos) : tos;
@@ -82,6 +85,46 @@ __global__ __launch_bounds__(256) void k_ew_eval(int64_t n, int nv, EwProg P, fl
             }
         }
         out[t] = tos;
+    }
+}
+// The same program on FOUR consecutive elements per thread (flat operands, 16-byte aligned): the interpreter's decode and
+// branches -- ~10 instructions per operation, more than the operation -- are paid once per four elements, the loads and the
+// store are 16 bytes per lane.  Same operations on every element: bit-identical to k_ew_eval.
+__global__ __launch_bounds__(256) void k_ew_eval4(int64_t total4, EwProg P, float* out) {
+    __shared__ float4 stk[7][256];
+    const int tid = threadIdx.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + tid; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
+        float4 tos = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sp = 0;
+        for (int pc = 0; pc < P.nprog; ++pc) {
+            const int ins = P.prog[pc], op = ins & 255, k = ins >> 8;
+            if (op >= IBH_EW_PUSH_ARRAY) {
+                if (sp > 0) stk[sp - 1][tid] = tos;
+                if (op == IBH_EW_PUSH_ARRAY) tos = ((const float4*)P.arr[k])[t];
+                else tos = make_float4(P.scal[k], P.scal[k], P.scal[k], P.scal[k]);
+                ++sp;
+            } else if (op >= IBH_EW_ABS) {
+                if (op == IBH_EW_ABS) tos = make_float4(fabsf(tos.x), fabsf(tos.y), fabsf(tos.z), fabsf(tos.w));
+                else if (op == IBH_EW_NEG) tos = make_float4(-tos.x, -tos.y, -tos.z, -tos.w);
+                else if (op == IBH_EW_SQRT) tos = make_float4(sqrtf(tos.x), sqrtf(tos.y), sqrtf(tos.z), sqrtf(tos.w));
+            } else {
+                const float4 a = stk[sp - 2][tid];
+                --sp;
+                switch (op) {
+                    case IBH_EW_ADD: tos = make_float4(a.x + tos.x, a.y + tos.y, a.z + tos.z, a.w + tos.w); break;
+                    case IBH_EW_SUB: tos = make_float4(a.x - tos.x, a.y - tos.y, a.z - tos.z, a.w - tos.w); break;
+                    case IBH_EW_MUL: tos = make_float4(a.x * tos.x, a.y * tos.y, a.z * tos.z, a.w * tos.w); break;
+                    case IBH_EW_DIV: tos = make_float4(a.x / tos.x, a.y / tos.y, a.z / tos.z, a.w / tos.w); break;
+                    case IBH_EW_MAX:
+                        tos = make_float4(fmaxf(a.x, tos.x), fmaxf(a.y, tos.y), fmaxf(a.z, tos.z), fmaxf(a.w, tos.w));
+                        break;
+                    default:
+                        tos = make_float4(fminf(a.x, tos.x), fminf(a.y, tos.y), fminf(a.z, tos.z), fminf(a.w, tos.w));
+                        break;
+                }
+            }
+        }
+        ((float4*)out)[t] = tos;
     }
 }
 
@@ -182,6 +225,8 @@ int ibh_ew_binary(int op, int64_t n, int nv, const float* a, int nva, float sa, 
     return 0;
 }
 
+// ibh_set_tuning("ew_scalar", 1): the one-element-per-thread interpreter everywhere (A/B, tests)
+int ibh_ew_scalar_only = 0;
 int ibh_ew_eval(int64_t n, int nv, int nprog, const int32_t* prog, int narr, const float* const* arrays,
                 const int32_t* arr_nv, int nscal, const float* scalars, float* out) {
     IBH_REQUIRE(out && prog && n >= 0 && nv >= 1, "ibh_ew_eval: bad argument");
@@ -217,7 +262,26 @@ int ibh_ew_eval(int64_t n, int nv, int nprog, const int32_t* prog, int narr, con
         P.scal[k] = k < nscal ? scalars[k] : 0.0f;
     }
     if (n * nv == 0) return 0;
-    hipLaunchKernelGGL(k_ew_eval, dim3(ibh_grid(n * nv, 256 * 4)), dim3(256), 0, ibh_stream, n, nv, P, out);
+    const int64_t total = n * nv;
+    bool bcast = false, aligned = ((uintptr_t)out & 15) == 0;
+    for (int k = 0; k < narr; ++k) {
+        bcast = bcast || (arr_nv[k] == 1 && nv > 1);
+        aligned = aligned && ((uintptr_t)arrays[k] & 15) == 0;
+    }
+    if (bcast) {
+        hipLaunchKernelGGL(k_ew_eval<true>, dim3(ibh_grid(total, 256 * 4)), dim3(256), 0, ibh_stream, n, nv, P, out);
+    } else if (aligned && total >= 4 && !ibh_ew_scalar_only) {
+        // flat operands: four elements per thread, and the last total mod 4 elements one by one
+        const int64_t total4 = total / 4, tail = total - 4 * total4;
+        hipLaunchKernelGGL(k_ew_eval4, dim3(ibh_grid(total4, 256)), dim3(256), 0, ibh_stream, total4, P, out);
+        if (tail) {
+            EwProg T = P;
+            for (int k = 0; k < narr; ++k) T.arr[k] = P.arr[k] + 4 * total4;
+            hipLaunchKernelGGL(k_ew_eval<false>, dim3(1), dim3(256), 0, ibh_stream, tail, 1, T, out + 4 * total4);
+        }
+    } else {
+        hipLaunchKernelGGL(k_ew_eval<false>, dim3(ibh_grid(total, 256 * 4)), dim3(256), 0, ibh_stream, total, 1, P, out);
+    }
     IBH_LAUNCH_CHECK();
     return 0;
 }

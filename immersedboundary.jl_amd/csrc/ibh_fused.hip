@@ -1418,10 +1418,15 @@ int ibh_debug_buffer(void* buf) {  // device buffer of 8 x uint64 per wave of th
 }
 
 extern int ibh_viscous_per_cell;   // ibh_cfd.hip
+extern int ibh_ew_scalar_only;     // ibh_ew.hip
 int ibh_set_tuning(const char* key, int value) {
     IBH_REQUIRE(key, "ibh_set_tuning: null key");
     if (!strcmp(key, "viscous_per_cell")) {
         ibh_viscous_per_cell = value;
+        return 0;
+    }
+    if (!strcmp(key, "ew_scalar")) {
+        ibh_ew_scalar_only = value;
         return 0;
     }
     if (!strcmp(key, "quad_variant")) ibh_quad_variant = value;

@@ -213,3 +213,38 @@ def test_graphed_closure_replays_the_operator_closure(adv_domains):
         g()
         assert np.array_equal(ud.to_host(), eager)
         assert np.abs(eager).max() > 0
+
+
+@pytest.mark.parametrize("n,nv", [(1003, 1), (1003, 5), (4096, 3), (3, 1), (257, 4)])
+def test_vector_interpreter_equals_the_one_element_interpreter(n, nv):
+    """``ibh_ew_eval`` runs a flat program four elements per thread (``k_ew_eval4``, 16-byte loads, the tail one by one);
+    operands that are column vectors broadcast over the result, or not 16-byte aligned, take the one-element interpreter.
+    All three against the one-element interpreter forced by ``ibh_set_tuning("ew_scalar", 1)``: bit for bit, odd sizes."""
+    import torch
+    from ibamd import _lib
+    H = ibamd.HipArray
+    rng = np.random.default_rng(n + nv)
+    shp = (n,) if nv == 1 else (n, nv)
+    a, b, c = (ibamd.hip(rng.uniform(0.5, 2.0, shp).astype(np.float32)) for _ in range(3))
+    col = ibamd.hip(rng.uniform(0.5, 2.0, n).astype(np.float32))
+    big = ibamd.hip(rng.uniform(0.5, 2.0, (n + 1, 1)).astype(np.float32))
+    off = big[1:, 0]                                    # a view 4 bytes off a 16-byte boundary
+
+    def exprs():
+        out = [((H(a) - H(b)) / 1e-3 - H(c) * H(a)).t,
+               (abs(H(a) - H(b)).maximum_with(H(c) * 0.25) + (H(a) / H(c)).sqrt()).t]
+        if nv > 1:
+            out.append((H(a) * H(col) - H(b)).t)        # column vector broadcast over the columns
+        else:
+            out.append((H(a) * H(off) - H(b)).t)        # misaligned operand
+        return out
+    fast = exprs()
+    _lib.call("ibh_set_tuning", b"ew_scalar", 1)
+    try:
+        slow = exprs()
+    finally:
+        _lib.call("ibh_set_tuning", b"ew_scalar", 0)
+    for f, s in zip(fast, slow):
+        assert torch.equal(f, s)
+    ref = (ibamd.to_host(a) - ibamd.to_host(b)) / np.float32(1e-3) - ibamd.to_host(c) * ibamd.to_host(a)
+    assert np.array_equal(ibamd.to_host(fast[0]), ref.astype(np.float32))
