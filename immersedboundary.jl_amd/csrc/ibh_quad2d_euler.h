@@ -379,7 +379,13 @@ __device__ __forceinline__ void sweep_quad_euler(const QuadDesc2* __restrict__ q
                 FTf[c] = t15 ? ex[c] : FT[v][c];
             }
             const v4f r = res[v] - ((FTf - FB) * rhy);
+            // the residual is not read again by this sweep: stores that do not allocate in L2 -- 14.13 -> 12.78 us per sweep at
+            // 0.87 M cells (same box, alternating builds, three times)
+#ifdef Q2E_NO_NT_STORE   // (A/B)
             *(v4f_g*)((char*)(Rr + (size_t)v * ldr) + ((size_t)a0 << 2)) = r;
+#else
+            __builtin_nontemporal_store(r, (v4f_g*)((char*)(Rr + (size_t)v * ldr) + ((size_t)a0 << 2)));
+#endif
         }
     }
 }
