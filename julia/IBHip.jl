@@ -586,6 +586,15 @@ function shear_rate_of_velocity!(S::HipArray{Float32}, part::HipPartition, vel::
     S
 end
 
+"The same with the velocity gradients kept: `G` is `(nc, nd * nd)`, `∂u_i/∂x_j` in column `nd (j - 1) + i` -- the tuple
+`cell_gradient(part, vel)` is the column blocks `G[:, nd (j - 1) + 1 : nd j]` -- for `viscous_residual!` (the gradients of a
+Navier-Stokes closure with a turbulence model are made once)."
+function shear_rate_of_velocity!(S::HipArray{Float32}, G::HipArray{Float32, 2}, part::HipPartition, vel::HipArray{Float32})
+    check(ccall((:ibh_shear_rate_of_velocity_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+        part.handle, vel.ptr, ld(vel), S.ptr, G.ptr, ld(G)))
+    S, G
+end
+
 "`Wray_Agarwal(R, S, cell_gradient(part, R), cell_gradient(part, S))` (src/turbulence.jl:222-241) in one launch; returns
 `(νt = nut, νR = nuR, S = Sout)` written into the three arrays."
 function wray_agarwal_of!(nut::HipArray{Float32}, nuR::HipArray{Float32}, Sout::HipArray{Float32}, part::HipPartition,
