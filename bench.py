@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--dt-every", type=int, default=1,
                     help="--step march: evaluate the time step every that many steps (1 = every step, like march! of "
                          "test/advection.jl:65; C is constant in the script, so 10 gives the same march)")
+    ap.add_argument("--dt-separate", action="store_true",
+                    help="--step march: the time step as its own two launches in front of every sweep (A/B of the default, "
+                         "which evaluates the next step's dt beside the boundary conditions of the step in hand)")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: exchange on a second stream beside the interior blocks, boundary blocks after it. "
                          "Off by default: inside a HIP graph the cross-stream fork/join costs ~15 us per step "
@@ -516,9 +519,14 @@ def main():
     def step():
         if march:
             k = mstate["k"]
-            if k % max(1, args.dt_every) == 0:
-                ibamd.timestep_advection(dpart, C, scale=0.75, out=dt_m)
-            ibamd.step_advection(dpart, um[k & 1], C, dt_m, bcs_m, out=um[(k + 1) & 1])
+            if args.dt_every <= 1 and not args.dt_separate:
+                # dt of the NEXT step evaluated beside this step's boundary conditions (it depends on C alone): extra
+                # workgroups of the BC set's two launches instead of two launches in front of the next sweep
+                ibamd.step_advection(dpart, um[k & 1], C, dt_m, bcs_m, out=um[(k + 1) & 1], next_dt=dt_m, scale=0.75)
+            else:
+                if k % max(1, args.dt_every) == 0:
+                    ibamd.timestep_advection(dpart, C, scale=0.75, out=dt_m)
+                ibamd.step_advection(dpart, um[k & 1], C, dt_m, bcs_m, out=um[(k + 1) & 1])
             mstate["k"] = k + 1
             return
         if config5 and world > 1:
@@ -996,7 +1004,9 @@ def main():
     if march:
         out["metric"] = "Mcells*steps/s, explicit march (device dt + sweep and update in one launch + BC set), 2D RAE2822"
         out["config"]["step"] = {"ghost_cells": int(bcs_m.n_ghost), "bc_set_levels": int(bcs_m.n_levels), "bc_set_levels_in_one_launch": int(bcs_m.n_direct_levels),
-                                 "dt_reduction_every": max(1, args.dt_every), "finite": bool(torch.isfinite(um[0]).all().item()),
+                                 "dt_reduction_every": max(1, args.dt_every),
+                                 "dt_beside_the_bc_set": bool(args.dt_every <= 1 and not args.dt_separate),
+                                 "finite": bool(torch.isfinite(um[0]).all().item()),
                                  "what": "test/advection.jl:61-89 without the host in the loop: ibh_timestep_advection every "
                                          f"{max(1, args.dt_every)} step(s), ibh_step_advection (k_sweep_quad storing u + dt ud, then the BC set) "
                                          "ping-pong between two arrays; boundaries: wall = 0, far field = copy(u)"}

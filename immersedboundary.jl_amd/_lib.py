@@ -83,6 +83,7 @@ _SIGS = {
     "ibh_timestep_advection": [c_vp, c_vp, c_i64, C.c_float, c_vp],
     "ibh_update_dev": [c_i64, c_vp, c_vp, c_vp, c_vp],
     "ibh_step_advection": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],
+    "ibh_step_advection_dt": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, C.c_float, c_vp],
     "ibh_ew_binary": [c_int, c_i64, c_int, c_vp, c_int, C.c_float, c_vp, c_int, C.c_float, c_vp],
     "ibh_ew_unary": [c_int, c_i64, c_vp, c_vp],
     "ibh_ew_fill": [c_i64, C.c_float, c_vp],

@@ -695,10 +695,13 @@ def timestep_advection(part, C_, scale=1.0, out=None):
     return dt
 
 
-def step_advection(part, u, C_, dt, bcs=None, out=None):
+def step_advection(part, u, C_, dt, bcs=None, out=None, next_dt=None, scale=1.0):
     """One ``march!`` of test/advection.jl:61-89 without the host: ``out = u + dt * R(u)`` (sweep and update in one launch
     where the quad sweep applies), then the boundary conditions ``bcs`` (a ``BCSet``) on ``out``.  ``dt``: one-element
-    device tensor (``timestep_advection``).  ``u`` and ``out`` must be different arrays (ping-pong)."""
+    device tensor (``timestep_advection``).  ``u`` and ``out`` must be different arrays (ping-pong).
+    ``next_dt`` (a one-element device tensor, may be ``dt`` itself): ``timestep_advection(part, C, scale)`` for the NEXT step
+    is evaluated on the way -- it depends on ``C`` alone --, by extra workgroups of the BC set's own launches
+    (``ibh_step_advection_dt``) instead of two launches in front of the next sweep; same value."""
     part = _part(part)
     u, nv, _ = _field(u, part.nc)
     if nv != 1:
@@ -712,6 +715,10 @@ def step_advection(part, u, C_, dt, bcs=None, out=None):
     if nvo != 1 or o.data_ptr() == u.data_ptr():
         raise ValueError("out must be a scalar field other than u")
     _stream()
+    if next_dt is not None:
+        call("ibh_step_advection_dt", part.handle, _ptr(u), _ptr(o), _ptr(C_), ldc, _ptr(dt),
+             bcs.handle if bcs is not None else c_vp(None), C.c_float(scale), _ptr(next_dt))
+        return out
     call("ibh_step_advection", part.handle, _ptr(u), _ptr(o), _ptr(C_), ldc, _ptr(dt),
          bcs.handle if bcs is not None else c_vp(None))
     return out

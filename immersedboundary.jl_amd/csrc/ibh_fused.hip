@@ -1737,6 +1737,22 @@ int ibh_step_advection(ibh_part* p, const float* u, float* u_out, const float* C
     return rc;
 }
 
+// The step with the time step of the NEXT step evaluated beside its boundary conditions (ibh_bcset_apply_with_dt,
+// ibh_ops.hip): dt_next = scale * 0.5 / max(...) depends on C alone, so its two launches ride in the two launches of the BC
+// set instead of standing in front of the next sweep.  dt_next may be dt_dev (the sweep has read it by then).
+// (Tried and dropped: the partial maxima beside the SWEEP instead -- its workgroups then carry the sweep's 27 KB of LDS and
+// its register budget, and the launch takes longer than the two side by side save: 26.8 against 26.1 us per step.)
+extern "C" int ibh_bcset_apply_with_dt(const ibh_bcset* s, float* a, ibh_part* p, const float* C, int64_t ldc, float scale,
+                                       float* dt_next, int partials_done);
+int ibh_step_advection_dt(ibh_part* p, const float* u, float* u_out, const float* C, int64_t ldc, const float* dt_dev,
+                          const ibh_bcset* bcs, float scale, float* dt_next) {
+    IBH_REQUIRE(dt_next, "ibh_step_advection_dt: null dt_next");
+    int rc = ibh_step_advection(p, u, u_out, C, ldc, dt_dev, nullptr);
+    if (rc) return rc;
+    if (bcs && bcs->ng > 0) return ibh_bcset_apply_with_dt(bcs, u_out, p, C, ldc, scale, dt_next, 0);
+    return ibh_timestep_advection(p, C, ldc, scale, dt_next);
+}
+
 int ibh_step_advection_xgmi(ibh_part* p, float* u, const float* C, int64_t ldc, float* ud, const int32_t* send_all,
                             int n_send_peers, const int32_t* send_seg, float* const* dst0, float* const* dst1,
                             uint32_t* const* send_flags, const int32_t* recv_all, const float* src0, const float* src1,

@@ -12,23 +12,12 @@
 #include <cstdlib>
 #include <vector>
 
+#include "ibh_bcset_dev.h"
 #include "ibh_common.h"
 
 #define MARCH_BLOCK 256
 
 namespace {
-
-// interpolated value of ghost g of the set: sum over its stencil in the order of k_accumulate (ibh_ops.hip)
-__device__ __forceinline__ float bc_interp1(const int32_t* __restrict__ off, const int32_t* __restrict__ donor,
-                                            const float* __restrict__ w, const float* __restrict__ a, int32_t g) {
-    const int32_t b = off[g], e = off[g + 1];
-    float s = 0.0f;
-    for (int32_t k = b; k < e; ++k) {
-        const float t = a[donor[k]] * w[k];
-        s = (k == b) ? t : s + t;
-    }
-    return s;
-}
 
 // ghosts g0 .. g1 of the set: interpolate from the field, closure, blend (k_bc_blend) -- into `gval`, NOT into the field:
 // every ghost cell of these boundaries is interpolated from the field as it was before any of them is written
@@ -37,19 +26,11 @@ __global__ void k_bcset_interp(int32_t g0, int32_t g1, const float* __restrict__
                                const int32_t* __restrict__ bidx, const int32_t* __restrict__ mode,
                                const float* __restrict__ value, const float* __restrict__ a, float* __restrict__ gval,
                                const int32_t* __restrict__ ghost, float* a_out) {
-    for (int32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += gridDim.x * blockDim.x) {
-        const float i = bc_interp1(off, donor, w, a, g);
-        const int32_t k = bidx[g];
-        const float e = eta[g];
-        const float b = mode[k] ? i : value[k];
-        const float v = e * i + (1.0f - e) * b;
-        if (ghost) a_out[ghost[g]] = v;  // (level without a ghost cell among its donors: nobody reads what is written here)
-        else gval[g] = v;
-    }
+    bcset_dev::interp_wg(blockIdx.x, gridDim.x, g0, g1, eta, off, donor, w, bidx, mode, value, a, gval, ghost, a_out);
 }
 __global__ void k_bcset_scatter(int32_t g0, int32_t g1, const int32_t* __restrict__ ghost, const float* __restrict__ gval,
                                 float* __restrict__ a) {
-    for (int32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += gridDim.x * blockDim.x) a[ghost[g]] = gval[g];
+    bcset_dev::scatter_wg(blockIdx.x, gridDim.x, g0, g1, ghost, gval, a);
 }
 
 // ---- every level of the set in ONE launch: at most 256 workgroups, all resident at once (a launch starts when the stream's

@@ -6,9 +6,15 @@
 //
 // Arithmetic follows the reference's broadcast order operation by operation (compiled
 // with -ffp-contract=off, IEEE divide/sqrt) so results are bit-comparable with the oracle.
+#include "ibh_bcset_dev.h"
 #include "ibh_common.h"
 
 #define OPS_BLOCK 256
+#include "ibh_dt_dev.h"
+using dt_dev::GradDims;
+using dt_dev::grad_dims;
+using dt_dev::dt_partial_wg;
+using dt_dev::dt_final_wg;
 
 namespace {
 
@@ -114,11 +120,6 @@ __device__ __forceinline__ float csr_mean_face_avg(const int32_t* __restrict__ o
 // (thread per cell and field; out[(d * nv + v) * ldo + c], the layout of ibh_cell_gradient_nd)
 // Sides with ONE face (side table of the partition, ibh_common.h) are evaluated directly from the cell across -- the same
 // expression the CSR walk evaluates for its single entry (weight 1.0f) -- the others walk the lists.
-struct GradDims {
-    DimData d[IBH_MAXD];
-    const float* h[IBH_MAXD];
-    const int32_t* side;
-};
 template <int ND>
 __global__ void k_cell_gradient_all(int32_t nc, GradDims G, const float* __restrict__ u, int64_t ldu, int nv,
                                     float* __restrict__ out, int64_t ldo) {
@@ -157,55 +158,44 @@ __global__ void k_cell_gradient_all(int32_t nc, GradDims G, const float* __restr
 template <int ND, bool TILED>
 __global__ __launch_bounds__(OPS_BLOCK) void k_timestep_advection(int32_t nc, GradDims G, const float* __restrict__ C,
                                                                   int64_t ldc, float* __restrict__ partial) {
-    float m = 0.0f;
-    for (int64_t c = IBH_WG_X() * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
-        int32_t sd[2 * ND];
-#pragma unroll
-        for (int s = 0; s < 2 * ND; ++s) {
-            if (TILED) {
-                const int pos = ((int)c >> (3 * (s >> 1))) & 7, st = 1 << (3 * (s >> 1));
-                const bool inb = (s & 1) ? pos < 7 : pos > 0;
-                sd[s] = inb ? (int32_t)c + ((s & 1) ? st : -st) : G.side[(int64_t)s * nc + c];
-            } else sd[s] = G.side[(int64_t)s * nc + c];
-        }
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const float* Cd = C + (int64_t)d * ldc;
-            const float hc = G.h[d][c], uc = Cd[c];
-            const int32_t l = sd[2 * d], r = sd[2 * d + 1];
-            float ar, al;
-            if (r >= 0) ar = face_avg(uc, Cd[r], hc, G.h[d][r]) * 1.0f;
-            else if (r == -2) ar = 0.0f;
-            else ar = csr_mean_face_avg(G.d[d].roff, G.d[d].ridx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], Cd);
-            if (l >= 0) al = face_avg(Cd[l], uc, G.h[d][l], hc) * 1.0f;
-            else if (l == -2) al = 0.0f;
-            else al = csr_mean_face_avg(G.d[d].loff, G.d[d].lidx, (int32_t)c, G.d[d].owners, G.d[d].neighbors, G.h[d], Cd);
-            m = fmaxf(m, (ar + al) / hc);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    __shared__ float wm[OPS_BLOCK / 64];
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float b = wm[0];
-        for (int w = 1; w < OPS_BLOCK / 64; ++w) b = fmaxf(b, wm[w]);
-        partial[blockIdx.x] = b;
-    }
+    dt_partial_wg<ND, TILED>(blockIdx.x, gridDim.x, nc, G, C, ldc, partial);
 }
 __global__ __launch_bounds__(OPS_BLOCK) void k_dt_from_partials(int n, const float* __restrict__ partial, float scale,
                                                                 float* __restrict__ dt) {
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < n; i += OPS_BLOCK) m = fmaxf(m, partial[i]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    __shared__ float wm[OPS_BLOCK / 64];
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float b = wm[0];
-        for (int w = 1; w < OPS_BLOCK / 64; ++w) b = fmaxf(b, wm[w]);
-        *dt = (0.5f / b) * scale;  // advection.jl:53 and :65
-    }
+    dt_final_wg(n, partial, scale, dt);
+}
+// ---- a march step's BC-set launches with the time step of the NEXT step riding beside them (horizontal fusion: the time
+// step depends on C alone, the boundary conditions on the field; both are short launches bound by dependent loads, and side
+// by side they cost what the longer one costs): workgroups [0, nwg_bc) run the BC-set body, the rest the dt body.
+struct BcLaunch {
+    int32_t g0, g1;
+    const float *eta, *w, *value;
+    const int32_t *off, *donor, *bidx, *mode, *ghost_direct, *ghost;
+    float* gval;
+};
+template <int ND, bool TILED>
+__global__ __launch_bounds__(OPS_BLOCK) void k_bcinterp_dt(int nwg_bc, BcLaunch B, float* a, int32_t nc, GradDims G,
+                                                           const float* __restrict__ C, int64_t ldc,
+                                                           float* __restrict__ partial) {
+    if ((int)blockIdx.x < nwg_bc)
+        bcset_dev::interp_wg(blockIdx.x, nwg_bc, B.g0, B.g1, B.eta, B.off, B.donor, B.w, B.bidx, B.mode, B.value, a, B.gval,
+                             B.ghost_direct, a);
+    else dt_partial_wg<ND, TILED>(blockIdx.x - nwg_bc, gridDim.x - nwg_bc, nc, G, C, ldc, partial);
+}
+__global__ __launch_bounds__(OPS_BLOCK) void k_bcscatter_dt(int nwg_bc, BcLaunch B, float* a, int npart,
+                                                            const float* __restrict__ partial, float scale,
+                                                            float* __restrict__ dt) {
+    if ((int)blockIdx.x < nwg_bc) bcset_dev::scatter_wg(blockIdx.x, nwg_bc, B.g0, B.g1, B.ghost, B.gval, a);
+    else dt_final_wg(npart, partial, scale, dt);
+}
+// a direct level (interpolation blended straight into the field) as the second launch of the set: interp body + dt final
+__global__ __launch_bounds__(OPS_BLOCK) void k_bcinterp_dtfinal(int nwg_bc, BcLaunch B, float* a, int npart,
+                                                                const float* __restrict__ partial, float scale,
+                                                                float* __restrict__ dt) {
+    if ((int)blockIdx.x < nwg_bc)
+        bcset_dev::interp_wg(blockIdx.x, nwg_bc, B.g0, B.g1, B.eta, B.off, B.donor, B.w, B.bidx, B.mode, B.value, a, B.gval,
+                             B.ghost_direct, a);
+    else dt_final_wg(npart, partial, scale, dt);
 }
 
 // gradient of one field at cell c in every dimension: the expressions of k_cell_gradient_all
@@ -740,15 +730,6 @@ int ibh_cell_gradient_all(const ibh_part* p, const float* u, int nv, int64_t ldu
     return 0;
 }
 
-static GradDims grad_dims(const ibh_part* p) {
-    GradDims G;
-    for (int d = 0; d < p->nd; ++d) {
-        G.d[d] = p->dim[d];
-        G.h[d] = p->spacing + (int64_t)d * p->nc;
-    }
-    G.side = p->side;
-    return G;
-}
 // face-list forms of ibh_shear_rate_of_velocity / ibh_wray_agarwal_of (ibh_fused.hip dispatches here on partitions
 // without block structure)
 int ibh_shear_rate_of_velocity_cells(const ibh_part* p, const float* vel, int64_t ldv, float* S, float* Gout, int64_t ldg) {
@@ -796,6 +777,76 @@ int ibh_timestep_advection(ibh_part* p, const float* C, int64_t ldc, float scale
 #undef DT_LAUNCH
     hipLaunchKernelGGL(k_dt_from_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg, p->march_tmp, scale, dt_dev);
     IBH_LAUNCH_CHECK();
+    return 0;
+}
+
+// ibh_bcset_apply(s, a) with ibh_timestep_advection(p, C, ldc, scale, dt_next) riding in its launches: the partial maxima
+// beside the first launch of the set, the final reduction beside the second.  Same kernels' bodies, same results; sets with
+// fewer than two launches take the separate launches for what is left.
+int ibh_dt_finish(ibh_part* p, int nwg_dt, float scale, float* dt_next) {   // the final reduction as its own launch
+    IBH_REQUIRE(p && p->march_tmp && dt_next, "ibh_dt_finish: bad argument");
+    hipLaunchKernelGGL(k_dt_from_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg_dt, p->march_tmp, scale, dt_next);
+    IBH_LAUNCH_CHECK();
+    return 0;
+}
+// partials_done: the partial maxima were launched beside the sweep of the step (ibh_fused.hip: k_step_quad_dt); the final
+// reduction then rides in the FIRST launch of the set
+int ibh_bcset_apply_with_dt(const ibh_bcset* s, float* a, ibh_part* p, const float* C, int64_t ldc, float scale,
+                            float* dt_next, int partials_done) {
+    IBH_REQUIRE(s && a && p && C && dt_next && (p->nd == 2 || p->nd == 3) && p->nc > 0, "ibh_bcset_apply_with_dt: bad argument");
+    if (!p->march_tmp) {
+        IBH_HIP(hipMalloc((void**)&p->march_tmp, 8192 * sizeof(float)));
+        p->march_tmp_n = 8192;
+    }
+    const GradDims G = grad_dims(p);
+    const int nwg_dt = std::min(ibh_grid(p->nc, OPS_BLOCK), 8192);
+    const bool tiled = p->info[20] != 0;
+    int stage = partials_done ? 1 : 0;   // 0: partial maxima not launched yet, 1: final reduction not launched yet, 2: done
+    for (int lv = 0; lv < s->nlev; ++lv) {
+        const int32_t g0 = s->seg[lv], g1 = s->seg[lv + 1];
+        if (g1 == g0) continue;
+        const int nwg = std::min(ibh_grid(g1 - g0, OPS_BLOCK), 2048);
+        BcLaunch B{g0, g1, s->eta, s->w, s->value, s->off, s->donor, s->bidx, s->mode, s->direct[lv] ? s->ghost : nullptr,
+                   s->ghost, s->gval};
+        // the interpolation launch of the level
+        if (stage == 0) {
+#define BCDT_LAUNCH(ND_, T_)                                                                                              \
+    hipLaunchKernelGGL((k_bcinterp_dt<ND_, T_>), dim3(nwg + nwg_dt), dim3(OPS_BLOCK), 0, ibh_stream, nwg, B, a, p->nc, G, C, \
+                       ldc, p->march_tmp)
+            if (p->nd == 2) {
+                if (tiled) BCDT_LAUNCH(2, true);
+                else BCDT_LAUNCH(2, false);
+            } else {
+                if (tiled) BCDT_LAUNCH(3, true);
+                else BCDT_LAUNCH(3, false);
+            }
+#undef BCDT_LAUNCH
+            stage = 1;
+        } else if (stage == 1) {
+            hipLaunchKernelGGL(k_bcinterp_dtfinal, dim3(nwg + 1), dim3(OPS_BLOCK), 0, ibh_stream, nwg, B, a, nwg_dt,
+                               p->march_tmp, scale, dt_next);
+            stage = 2;
+        } else {
+            hipLaunchKernelGGL(k_bcinterp_dtfinal, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, nwg, B, a, 0, p->march_tmp, scale,
+                               dt_next);
+        }
+        if (s->direct[lv]) continue;
+        // the scatter launch of the level
+        if (stage == 1) {
+            hipLaunchKernelGGL(k_bcscatter_dt, dim3(nwg + 1), dim3(OPS_BLOCK), 0, ibh_stream, nwg, B, a, nwg_dt, p->march_tmp,
+                               scale, dt_next);
+            stage = 2;
+        } else {
+            hipLaunchKernelGGL(k_bcscatter_dt, dim3(nwg), dim3(OPS_BLOCK), 0, ibh_stream, nwg, B, a, 0, p->march_tmp, scale,
+                               dt_next);
+        }
+    }
+    IBH_LAUNCH_CHECK();
+    if (stage == 0) return ibh_timestep_advection(p, C, ldc, scale, dt_next);
+    if (stage == 1) {
+        hipLaunchKernelGGL(k_dt_from_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg_dt, p->march_tmp, scale, dt_next);
+        IBH_LAUNCH_CHECK();
+    }
     return 0;
 }
 

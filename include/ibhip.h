@@ -375,6 +375,12 @@ int ibh_timestep_advection(ibh_part*, const float* C, int64_t ldc, float scale, 
 int ibh_update_dev(int64_t n, const float* dt_device, const float* u, const float* r, float* out);
 int ibh_step_advection(ibh_part*, const float* u, float* u_out, const float* C, int64_t ldc, const float* dt_device,
                        const ibh_bcset* bcs /* or NULL */);
+/* The same step with the time step of the NEXT one evaluated on the way: dt_next = ibh_timestep_advection(p, C, ldc, scale)
+ * -- it depends on C alone -- computed by extra workgroups of the BC set's own launches (partial maxima beside the first,
+ * final reduction beside the second) instead of two launches in front of the next sweep.  Results identical to the separate
+ * calls; dt_next may alias dt_dev. */
+int ibh_step_advection_dt(ibh_part* p, const float* u, float* u_out, const float* C, int64_t ldc, const float* dt_dev,
+                          const ibh_bcset* bcs, float scale, float* dt_next);
 int ibh_axpy_clamped(int64_t n, float omega, const float* r, float* q);
 /* y = a*x + y */
 int ibh_axpy(int64_t n, float a, const float* x, float* y);

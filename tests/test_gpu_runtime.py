@@ -360,3 +360,41 @@ def test_advection_march_through_the_fused_step(adv_mesh):
     f = ibamd.step_advection(dpart, ibamd.hip(u0), C, dt, bcs)
     assert rel_inf(ibamd.to_host(f), ibamd.to_host(w)) <= 1e-6
     assert bcs.healthy() and bcs.n_levels >= 1
+
+
+@pytest.mark.parametrize("sets", ["three", "one_direct", "none"])
+def test_step_with_the_next_time_step_beside_the_bc_set(adv_mesh, sets):
+    """``ibh_step_advection_dt``: the step with the time step of the NEXT step evaluated by extra workgroups of the BC set's
+    own launches (it depends on ``C`` alone) -- against ``timestep_advection`` + ``step_advection`` as separate launches: the
+    same ``dt`` and the same field, bit for bit, over several steps with a non-uniform ``C``; BC sets with several launches,
+    with a single launch (the final reduction falls back to its own launch) and without boundary conditions."""
+    from conftest import ADV_FAMILIES
+    kw = dict(hypercube_families=ADV_FAMILIES, max_partition_size=10 ** 9)
+    dp = ibamd.Domain(adv_mesh, **kw)
+    (part,) = dp.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    n = len(dp)
+    X = dp.global_centers()
+    u0 = seeded_field(X, kind="step")
+    Ch = np.stack([1.0 + 0.3 * np.sin(3 * X[:, 1]), 0.8 + 0.2 * np.cos(2 * X[:, 0])], axis=1).astype(f32)
+    C = ibamd.hip(Ch)
+    bcs = {"three": lambda: ibamd.BCSet(dp, [("upper", 1.0), ("lower", 0.0), ("outlet", "copy")]),
+           "one_direct": lambda: ibamd.BCSet(dp, [("upper", 1.0)]), "none": lambda: None}[sets]()
+    # separate launches
+    dt_a = ibamd.timestep_advection(dpart, C, scale=0.75)
+    ua, ub = ibamd.hip(u0), torch.empty(n, dtype=torch.float32, device="cuda")
+    # dt beside the BC set: the first dt from the plain call, every later one from the step before
+    dt_b = ibamd.timestep_advection(dpart, C, scale=0.75)
+    va, vb = ibamd.hip(u0), torch.empty(n, dtype=torch.float32, device="cuda")
+    for k in range(4):
+        ibamd.timestep_advection(dpart, C, scale=0.75, out=dt_a)
+        ibamd.step_advection(dpart, ua, C, dt_a, bcs, out=ub)
+        ua, ub = ub, ua
+        dt_b_before = float(dt_b.item())
+        ibamd.step_advection(dpart, va, C, dt_b, bcs, out=vb, next_dt=dt_b, scale=0.75)
+        va, vb = vb, va
+        assert float(dt_b.item()) == float(dt_a.item()) == dt_b_before
+        assert torch.equal(ua, va), k
+    assert not torch.equal(ua, ibamd.hip(u0))
+    if bcs is not None:
+        assert bcs.healthy()
