@@ -568,6 +568,17 @@ function step_advection!(u_out::HipArray{Float32}, part::HipPartition, u::HipArr
     u_out
 end
 
+"The same step with `timestep_advection!(next_dt, part, C; scale)` for the NEXT step evaluated on the way (it depends on `C`
+alone): extra workgroups of the BC set's own launches instead of two launches in front of the next sweep.  `next_dt` may be
+`dt` itself."
+function step_advection!(u_out::HipArray{Float32}, part::HipPartition, u::HipArray{Float32}, C::HipArray{Float32},
+                         dt::HipArray{Float32}, bcs::Union{HipBCSet, Nothing}, next_dt::HipArray{Float32}; scale = 1f0)
+    check(ccall((:ibh_step_advection_dt, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}),
+        part.handle, u.ptr, u_out.ptr, C.ptr, ld(C), dt.ptr, isnothing(bcs) ? C_NULL : bcs.handle, Float32(scale), next_dt.ptr))
+    u_out
+end
+
 "`S .+ Σ_d green_gauss(at_faces(ν .+ νR, d) .* face_gradient(R, d) .- at_faces(vel[:, d] .* R, d), d)` in one launch
 (the transport residual closed by `Wray_Agarwal`, src/turbulence.jl:222-241), bit-identical to the composition."
 function scalar_transport!(out::HipArray{Float32}, part::HipPartition, R::HipArray{Float32}, νR::HipArray{Float32},
