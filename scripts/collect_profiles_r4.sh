@@ -61,6 +61,11 @@ if [ "$MODE" = "c5" ]; then
   say "config5 33M"; bash scripts/with_heartbeat.sh $O/progress.log python3 bench.py --no-cpu-baseline --workload sphere3d_33M --residual euler --step config5 --steps 3 --warmup 1 --repeats 2 > $O/bench_config5_33M.json 2>>$O/bench.err
 fi
 if [ "$MODE" = "c5kt" ]; then
+  # (the 33.6 M-cell domain takes minutes to build and rocprofv3 must start python itself: a background writer keeps the
+  # run from looking hung)
+  ( while sleep 60; do echo "$(date +%T) still tracing config5_33M" >> $O/progress.log; done ) &
+  HB=$!
+  trap "kill $HB 2>/dev/null" EXIT
   kernel_trace config5_33M --workload sphere3d_33M --residual euler --step config5 --steps 3 --warmup 1 --repeats 1
 fi
 if [ "$MODE" = "28M" ]; then
