@@ -369,8 +369,16 @@ __device__ __forceinline__ void visc_accumulate(const ibh_fluid& f, const ViscDi
 #pragma unroll
     for (int v = 0; v <= ND; ++v) acc[v] = acc[v] + div_by(ar[v] - al[v], rh);
 }
+// Eight waves per SIMD (64 VGPRs, 40 spilled words; four workgroups = 154 KB of LDS per CU): the phases of a workgroup wait
+// on one another at barriers, and what fills the gaps is other workgroups -- 246 us with the 94 registers the compiler takes
+// unconstrained (two workgroups per CU), 214 at six waves per SIMD (79 registers, no spill, three workgroups), **205 at
+// eight**, at 4.56 M cells on one box, alternating builds.
+#ifndef VISC_WAVES
+#define VISC_WAVES 8
+#endif
+#define VISC_ATTR __attribute__((amdgpu_waves_per_eu(VISC_WAVES, VISC_WAVES)))
 template <int ND>
-__global__ __launch_bounds__(VISC_WG) void k_viscous_residual_shared(ibh_fluid f, int32_t nc, ViscDims<ND> V,
+__global__ __launch_bounds__(VISC_WG) VISC_ATTR void k_viscous_residual_shared(ibh_fluid f, int32_t nc, ViscDims<ND> V,
                                                                      const float* __restrict__ P, int64_t ldp, int64_t ldg,
                                                                      const float* __restrict__ mut, float* __restrict__ R,
                                                                      int64_t ldr) {
