@@ -1,6 +1,6 @@
 // libibhip: device bodies of the time-step evaluation of an explicit advection step (ibh_timestep_advection, ibh_ops.hip), with
-// the workgroup's index and count as arguments: the same code runs as its own launches, beside the BC-set workgroups of a
-// march step (ibh_ops.hip: k_bcinterp_dt / k_bcscatter_dt) and beside the sweep of the step (ibh_fused.hip: k_step_quad_dt).
+// the workgroup's index and count as arguments: the same code runs as its own launches and beside the BC-set workgroups of a
+// march step (ibh_ops.hip: k_bcinterp_dt / k_bcscatter_dt).
 #pragma once
 #include "ibh_common.h"
 

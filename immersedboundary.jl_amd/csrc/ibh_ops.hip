@@ -783,14 +783,8 @@ int ibh_timestep_advection(ibh_part* p, const float* C, int64_t ldc, float scale
 // ibh_bcset_apply(s, a) with ibh_timestep_advection(p, C, ldc, scale, dt_next) riding in its launches: the partial maxima
 // beside the first launch of the set, the final reduction beside the second.  Same kernels' bodies, same results; sets with
 // fewer than two launches take the separate launches for what is left.
-int ibh_dt_finish(ibh_part* p, int nwg_dt, float scale, float* dt_next) {   // the final reduction as its own launch
-    IBH_REQUIRE(p && p->march_tmp && dt_next, "ibh_dt_finish: bad argument");
-    hipLaunchKernelGGL(k_dt_from_partials, dim3(1), dim3(OPS_BLOCK), 0, ibh_stream, nwg_dt, p->march_tmp, scale, dt_next);
-    IBH_LAUNCH_CHECK();
-    return 0;
-}
-// partials_done: the partial maxima were launched beside the sweep of the step (ibh_fused.hip: k_step_quad_dt); the final
-// reduction then rides in the FIRST launch of the set
+// partials_done: the partial maxima are in p->march_tmp already (a caller that launched them elsewhere); the final reduction
+// then rides in the FIRST launch of the set
 int ibh_bcset_apply_with_dt(const ibh_bcset* s, float* a, ibh_part* p, const float* C, int64_t ldc, float scale,
                             float* dt_next, int partials_done) {
     IBH_REQUIRE(s && a && p && C && dt_next && (p->nd == 2 || p->nd == 3) && p->nc > 0, "ibh_bcset_apply_with_dt: bad argument");
