@@ -1140,6 +1140,8 @@ __global__ __launch_bounds__(64 * WPB) void k_passB_euler_blk(uint32_t nc, const
                           lane);
 }
 
+// (127 VGPRs = four waves per SIMD.  Six and eight waves per SIMD by capping the registers -- what paid in the viscous sum --
+// were measured here: 216 and 293 against 171 us on 1.67 M cells; this pass is arithmetic in Float64, the spills cost more.)
 template <int ND>
 __global__ __launch_bounds__(64 * WPB) void k_passB_euler(PartView p, const float* __restrict__ P, int64_t ldp,
                                                      const float* __restrict__ G, float* __restrict__ R, int64_t ldr,
