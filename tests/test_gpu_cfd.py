@@ -167,3 +167,33 @@ def test_viscous_residual_is_the_operator_composition(rae_domains):
         finally:
             _lib.call("ibh_set_tuning", b"viscous_per_cell", 0)
         assert torch.equal(got3, ref)
+
+
+def test_viscous_residual_of_a_parabolic_shear_flow(adv_mesh):
+    """The analytic pin of tests/test_oracle_known_answers.py on the device: ``u = a y^2``, ``v = 0``, uniform ``p`` and ``T``
+    through ``ibh_viscous_residual`` (the fused sum, with the gradients of the velocities from the shear-rate kernel's tuple
+    form where it applies) -> ``2 a mu`` in the x-momentum row, 0 in the y-momentum row, wherever the spacing is uniform."""
+    from ibamd import cfd as gcfd
+    dom = ibamd.Domain(adv_mesh, max_partition_size=10 ** 9)
+    (part,) = dom.partitions.values()
+    dpart = ibamd.to_backend(part, ibamd.hip)
+    X = part.centers
+    n = X.shape[0]
+    a = f32(3.0)
+    P_h = np.empty((n, 4), dtype=f32)
+    P_h[:, 0], P_h[:, 1] = 1.0e5, 300.0
+    P_h[:, 2] = a * X[:, 1] * X[:, 1]
+    P_h[:, 3] = 0.0
+    fluid = gcfd.Fluid()
+    mu = float(ibamd.to_host(gcfd.dynamic_viscosity(fluid, ibamd.hip(f32([300.0]))))[0])
+    P = ibamd.hip(P_h)
+    R = ibamd.hip(np.zeros((n, 4), dtype=f32))
+    gcfd.viscous_residual(dpart, fluid, P, ibamd.cell_gradient(dpart, P[:, 2:]), ibamd.hip(np.zeros(n, f32)), R,
+                          velocity_gradients_only=True)
+    r = ibamd.to_host(R)
+    exact = 2.0 * float(a) * mu
+    inner = (np.abs(X[:, 0] - X[:, 0].mean()) < 0.35 * np.ptp(X[:, 0])) & (np.abs(X[:, 1] - X[:, 1].mean()) < 0.35 * np.ptp(X[:, 1]))
+    rel = np.abs(r[inner, 2] - exact) / exact
+    assert np.median(rel) <= 1e-5 and np.percentile(rel, 90) <= 1e-4, (np.median(rel), np.percentile(rel, 90))
+    assert np.percentile(np.abs(r[inner, 3]), 90) <= 1e-4 * exact
+    assert np.all(r[:, 0] == 0)

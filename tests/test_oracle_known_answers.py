@@ -211,3 +211,42 @@ def test_surface_known_answers(rae_domains):
         for ln in sa:
             assert np.array_equal(sa[ln][0], sb[ln][0]) and np.array_equal(sa[ln][1], sb[ln][1])
             assert np.abs(sa[ln][2] - sb[ln][2]).max() <= 1e-5
+
+
+def test_viscous_sum_of_a_parabolic_shear_flow(adv_mesh):
+    """Analytic pin of the viscous chain (cfd.jl:664-736 over ImmersedBoundary.jl:899-926, 980-988, 1039-1069):
+    ``u = a y^2``, ``v = 0``, uniform ``p`` and ``T`` -> ``tau_xy = mu 2 a y``, and
+    ``sum_d green_gauss(viscous_fluxes(at_faces(P, d), face_gradient(P, grad P, d), d), d)`` is ``2 a mu`` in the x-momentum
+    row and 0 in the y-momentum row -- exactly (to Float32 rounding of a second difference) wherever the spacing is uniform
+    around a cell: the normal derivative at a face is the two-point difference, exact at the face midpoint for a parabola."""
+    dom = od.Domain(adv_mesh, max_partition_size=10 ** 9)
+    (part,) = dom.partitions.values()
+    X = part.centers
+    n = X.shape[0]
+    a = f32(3.0)
+    fl = ocfd.Fluid()
+    P = np.empty((n, 4), dtype=f32)
+    P[:, 0], P[:, 1] = 1.0e5, 300.0
+    P[:, 2] = a * X[:, 1] * X[:, 1]
+    P[:, 3] = 0.0
+    mu = float(ocfd.dynamic_viscosity(fl, f32([300.0]))[0])
+    gP = tuple(od.cell_gradient(part, P, d) for d in (1, 2))
+    r = np.zeros_like(P)
+    for d in (1, 2):
+        Fv = ocfd.viscous_fluxes(fl, od.at_faces(part, P, d), od.face_gradient(part, P, gP, d), d)
+        r += od.green_gauss(part, Fv, d)
+    exact = 2.0 * float(a) * mu
+    # cells with uniform spacing around them: own spacing = the four neighbours' (through the face averages of h)
+    h = part.spacing
+    uniform = np.ones(n, dtype=bool)
+    for d in (1, 2):
+        hd = np.ascontiguousarray(h[:, d - 1])
+        same = od.unsigned_green_gauss(part, od.at_faces(part, hd, d), d) * hd      # (h_r + h_l) with face-averaged h
+        uniform &= np.abs(same - 2 * hd) <= 1e-6 * hd
+    inner = uniform & (np.abs(X[:, 0] - X[:, 0].mean()) < 0.35 * np.ptp(X[:, 0])) & \
+        (np.abs(X[:, 1] - X[:, 1].mean()) < 0.35 * np.ptp(X[:, 1]))
+    assert inner.sum() > 0.2 * n
+    rel = np.abs(r[inner, 2] - exact) / exact
+    assert np.median(rel) <= 1e-5 and np.percentile(rel, 90) <= 1e-4, (np.median(rel), np.percentile(rel, 90))   # measured 5e-7 / 2e-6
+    assert np.percentile(np.abs(r[inner, 3]), 90) <= 1e-4 * exact
+    assert np.all(r[:, 0] == 0)                           # (row 1 of a flux array is the energy row: nothing in the mass row)
