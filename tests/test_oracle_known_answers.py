@@ -250,3 +250,47 @@ def test_viscous_sum_of_a_parabolic_shear_flow(adv_mesh):
     assert np.median(rel) <= 1e-5 and np.percentile(rel, 90) <= 1e-4, (np.median(rel), np.percentile(rel, 90))   # measured 5e-7 / 2e-6
     assert np.percentile(np.abs(r[inner, 3]), 90) <= 1e-4 * exact
     assert np.all(r[:, 0] == 0)                           # (row 1 of a flux array is the energy row: nothing in the mass row)
+
+
+def test_residual_sweeps_preserve_a_free_stream_and_differentiate_a_ramp(rae_domains):
+    """Two analytic pins of the WHOLE residual closures of SURVEY.md 8d on a mesh with level jumps (RAE2822, three
+    partitions with skirts):
+
+    * a uniform state is a fixed point -- the Euler HLL-JST-MUSCL residual (R2) and the advection residual (R1) of a uniform
+      field are EXACTLY zero on every cell, coarse-fine sides included (identical face states give identical fluxes, and the
+      mean of four equal fluxes with weights 1/4 is that flux);
+    * R1 of the ramp ``u = x`` under ``C = (1, 0)`` is ``-d(C u)/dx = -1`` wherever the spacing is uniform around a cell
+      (cell gradients, MUSCL states and the upwind flux are exact for a linear field)."""
+    from test_gpu_residual import oracle_advection_residual, oracle_euler_residual
+    _, do = rae_domains
+    fl = ocfd.Fluid()
+    checked = 0
+    for opart in do.partitions.values():
+        n = opart.centers.shape[0]
+        P = np.tile(f32([1.0e5, 288.15, 100.0, -35.0]), (n, 1))
+        assert not oracle_euler_residual(opart, P, fl).any()
+        u = np.full(n, f32(0.7))
+        C = np.tile(f32([1.0, -0.5]), (n, 1))
+        assert not oracle_advection_residual(opart, u, C).any()
+        # the ramp
+        x = np.ascontiguousarray(opart.centers[:, 0])
+        C1 = np.tile(f32([1.0, 0.0]), (n, 1))
+        r = oracle_advection_residual(opart, x, C1)
+        h = np.ascontiguousarray(opart.spacing[:, 0])
+        ok = np.abs(od.unsigned_green_gauss(opart, od.at_faces(opart, h, 1), 1) * h - 2 * h) <= 1e-6 * h   # same h left, right
+        hy = np.ascontiguousarray(opart.spacing[:, 1])
+        ok &= np.abs(od.unsigned_green_gauss(opart, od.at_faces(opart, hy, 2), 2) * hy - 2 * hy) <= 1e-6 * hy
+        # ... away from the domain boundary (a mirror face halves the gradient there): the gradient of the ramp is 1 at the
+        # cell and -- the MUSCL state of a neighbour uses ITS gradient -- at its x-neighbours
+        ok &= np.abs(od.cell_gradient(opart, x, 1) - 1.0) <= 1e-4
+        okf = ok.astype(f32)
+        ring = od.unsigned_green_gauss(opart, od.at_faces(opart, okf, 1), 1) * h
+        ok &= np.abs(ring - 2.0) <= 1e-5
+        img = np.zeros(n, dtype=bool)
+        img[np.asarray(opart.image_in_domain) - 1] = True
+        sel = ok & img
+        assert sel.sum() > 0.3 * img.sum()
+        err = np.abs(r[sel] + 1.0)
+        assert err.max() <= 1e-5, float(err.max())        # (measured: exactly -1 on 84 % of the image cells)
+        checked += int(sel.sum())
+    assert checked > 1000
