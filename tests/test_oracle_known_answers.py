@@ -294,3 +294,38 @@ def test_residual_sweeps_preserve_a_free_stream_and_differentiate_a_ramp(rae_dom
         assert err.max() <= 1e-5, float(err.max())        # (measured: exactly -1 on 84 % of the image cells)
         checked += int(sel.sum())
     assert checked > 1000
+
+
+def test_transfer_operators_preserve_constants_and_3d_free_stream():
+    """On a 3-D octree with level jumps (refinement ball off-centre): the IDW prolongator and coarsener of ``multigrid``
+    (ImmersedBoundary.jl:1355-1407) are partitions of unity -- a constant field goes to the same constant on the other level --
+    and the 3-D Euler residual of a uniform state is exactly zero on every cell, the advection residual of the ramp ``u = z``
+    under ``C = (0, 0, 1)`` is -1 wherever the gradient of the ramp is exact at a cell and its z-neighbours."""
+    from ibamd import Ball, Mesh
+    from test_gpu_residual import oracle_advection_residual, oracle_euler_residual
+    msh = Mesh(f32([-2, -2, -2]), f32([4, 4, 4]), block_size=4,
+               refinement_regions=[(Ball(np.array([1.2, 1.2, 1.2]), 0.1), f32(0.12))])
+    dom = od.Domain(msh, max_partition_size=10 ** 9)
+    coarse_doms, prolongators, coarseners = od.multigrid(dom, max_levels=1)
+    n = len(dom)
+    one = np.full(n, f32(2.5))
+    uc = coarseners[0](one)
+    assert uc.shape[0] == len(coarse_doms[0]) and np.abs(uc - 2.5).max() <= 1e-6
+    up = prolongators[0](np.full(len(coarse_doms[0]), f32(-1.25)))
+    assert up.shape[0] == n and np.abs(up + 1.25).max() <= 1e-6
+    (part,) = dom.partitions.values()
+    assert len(np.unique(part.spacing[:, 0])) >= 2                       # the mesh does have level jumps
+    P = np.tile(f32([1.0e5, 288.15, 100.0, -35.0, 20.0]), (n, 1))
+    assert not oracle_euler_residual(part, P, ocfd.Fluid()).any()
+    z = np.ascontiguousarray(part.centers[:, 2])
+    r = oracle_advection_residual(part, z, np.tile(f32([0.0, 0.0, 1.0]), (n, 1)))
+    h = np.ascontiguousarray(part.spacing[:, 2])
+    ok = np.ones(n, dtype=bool)
+    for d in (1, 2, 3):
+        hd = np.ascontiguousarray(part.spacing[:, d - 1])
+        ok &= np.abs(od.unsigned_green_gauss(part, od.at_faces(part, hd, d), d) * hd - 2 * hd) <= 1e-6 * hd
+    ok &= np.abs(od.cell_gradient(part, z, 3) - 1.0) <= 1e-4
+    ring = od.unsigned_green_gauss(part, od.at_faces(part, ok.astype(f32), 3), 3) * h
+    ok &= np.abs(ring - 2.0) <= 1e-5
+    assert ok.sum() > 0.3 * n
+    assert np.abs(r[ok] + 1.0).max() <= 1e-5
