@@ -96,7 +96,8 @@ def test_binding_covers_the_closures_of_every_config():
             "ibh_turb_smagorinsky", "ibh_turb_k_epsilon", "ibh_turb_wray_agarwal", "ibh_turb_ducros", "ibh_turb_wale",
             "ibh_fas_update", "ibh_sumsq", "ibh_viscous_residual", "ibh_partition_destroy", "ibh_acc_destroy",
             "ibh_bc_destroy", "ibh_residual_euler_hll", "ibh_residual_advection", "ibh_accumulate", "ibh_bc_interp",
-            "ibh_bc_blend"}
+            "ibh_bc_blend", "ibh_step_advection", "ibh_step_advection_dt", "ibh_timestep_advection",
+            "ibh_shear_rate_of_velocity", "ibh_shear_rate_of_velocity_grad", "ibh_wray_agarwal_of", "ibh_scalar_transport"}
     assert not (need - bound), sorted(need - bound)
 
 
