@@ -43,6 +43,7 @@ profile_one 3d_4.6M --workload sphere3d_4.6M --steps 100 --warmup 10
 profile_one 3.47M --workload rae2822_3.47M
 say "march"; python3 bench.py --no-cpu-baseline --step march > $O/bench_march.json 2>>$O/bench.err
 python3 bench.py --no-cpu-baseline --step march --dt-every 10 > $O/bench_march_dt_every_10.json 2>>$O/bench.err
+python3 bench.py --no-cpu-baseline --step march --dt-separate > $O/bench_march_dt_separate_launches.json 2>>$O/bench.err
 kernel_trace march --step march --repeats 3
 say probes
 python3 scripts/probe_3d_euler.py sphere3d_1.6M > $O/probe_3d_euler_1.6M.json 2>>$O/bench.err
