@@ -329,3 +329,16 @@ def test_transfer_operators_preserve_constants_and_3d_free_stream():
     ok &= np.abs(ring - 2.0) <= 1e-5
     assert ok.sum() > 0.3 * n
     assert np.abs(r[ok] + 1.0).max() <= 1e-5
+
+
+def test_time_step_of_the_advection_script_in_closed_form(adv_mesh):
+    """``dt = 0.75 * 0.5 / maximum(max.(unsigned_green_gauss(part, at_faces(part, C[:, d], d), d) ...))`` (test/advection.jl:52-59,
+    :65) for ``C = (1, 1)``: ``unsigned_green_gauss`` of the unit face field is ``2 / h`` away from the domain boundary, so
+    ``dt = 0.1875 h_min``."""
+    dom = od.Domain(adv_mesh, max_partition_size=10 ** 9)
+    (part,) = dom.partitions.values()
+    n = part.centers.shape[0]
+    one = np.ones(n, f32)
+    m = max(float(od.unsigned_green_gauss(part, od.at_faces(part, one, d), d).max()) for d in (1, 2))
+    hmin = float(part.spacing.min())
+    assert abs(0.75 * 0.5 / m - 0.1875 * hmin) <= 1e-6 * hmin
